@@ -1,0 +1,610 @@
+"""CPU oracle for the LRCN hot path  --  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this module, and only as the checker.  The product path (``video-learning-tf_amd``) never
+imports it and fails loudly when its HIP library is missing.
+
+PARITY UNPINNED.  The reference (npit/video-learning-tf) is Python over TensorFlow 1.x graph
+ops.  TensorFlow is not vendored, not pinned (reference ``dependencies.txt:1-4``) and not
+installable here, and the reference ships no tests, golden vectors or known-answer values
+(SURVEY.md section 4, 8c).  This file therefore restates the published TF-1.x op semantics the
+reference's call sites rely on, in numpy, and is cross-checked op by op against torch-CPU
+functional ops / autograd (an independent implementation) in ``tests/test_oracle.py``.
+
+Layouts follow the reference: activations NHWC, conv kernels HWIO, fc weights [in, out],
+LSTM kernel [D+H, 4H] with gate order i, j, f, o.
+
+Every function cites the reference file:line it follows (paths relative to /root/reference).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+F64 = np.float64
+
+
+# ----------------------------------------------------------------------------------------------
+# TF padding rule used by every conv of models/alexnet/alexnet.py (padding="SAME") and every
+# max-pool (padding="VALID").
+# ----------------------------------------------------------------------------------------------
+def same_pad(in_size: int, k: int, s: int):
+    """TF 'SAME': out = ceil(in/s); pad_total = max((out-1)*s + k - in, 0); before = floor(pad/2)."""
+    out = -(-in_size // s)
+    pad_total = max((out - 1) * s + k - in_size, 0)
+    before = pad_total // 2
+    return out, before, pad_total - before
+
+
+def valid_out(in_size: int, k: int, s: int) -> int:
+    return (in_size - k) // s + 1
+
+
+def _im2col(x, kh, kw, s, pt, pl, oh, ow):
+    """x [N,H,W,C] -> cols [N,oh,ow,kh,kw,C] (zero padded)."""
+    n, h, w, c = x.shape
+    pb = max((oh - 1) * s + kh - h - pt, 0)
+    pr = max((ow - 1) * s + kw - w - pl, 0)
+    xp = np.pad(x, ((0, 0), (pt, pb), (pl, pr), (0, 0)))
+    cols = np.empty((n, oh, ow, kh, kw, c), dtype=x.dtype)
+    for i in range(kh):
+        for j in range(kw):
+            cols[:, :, :, i, j, :] = xp[:, i:i + (oh - 1) * s + 1:s, j:j + (ow - 1) * s + 1:s, :]
+    return cols
+
+
+def conv2d_same(x, w, stride, dtype=F64):
+    """tf.nn.conv2d(x, w, [1,s,s,1], 'SAME'), NHWC x HWIO (alexnet.py:21)."""
+    x = x.astype(dtype, copy=False)
+    w = w.astype(dtype, copy=False)
+    n, h, wd, c = x.shape
+    kh, kw, ci, co = w.shape
+    assert ci == c
+    oh, pt, _ = same_pad(h, kh, stride)
+    ow, pl, _ = same_pad(wd, kw, stride)
+    cols = _im2col(x, kh, kw, stride, pt, pl, oh, ow).reshape(n * oh * ow, kh * kw * c)
+    return (cols @ w.reshape(kh * kw * c, co)).reshape(n, oh, ow, co)
+
+
+def conv2d_same_grad(x, w, dy, stride, dtype=F64, need_dx=True):
+    """Gradients of conv2d_same wrt x and w (what tf.gradients yields for alexnet.py:21)."""
+    x = x.astype(dtype, copy=False)
+    w = w.astype(dtype, copy=False)
+    dy = dy.astype(dtype, copy=False)
+    n, h, wd, c = x.shape
+    kh, kw, ci, co = w.shape
+    oh, pt, _ = same_pad(h, kh, stride)
+    ow, pl, _ = same_pad(wd, kw, stride)
+    cols = _im2col(x, kh, kw, stride, pt, pl, oh, ow).reshape(n * oh * ow, kh * kw * c)
+    dy2 = dy.reshape(n * oh * ow, co)
+    dw = (cols.T @ dy2).reshape(kh, kw, ci, co)
+    dx = None
+    if need_dx:
+        dcols = (dy2 @ w.reshape(kh * kw * c, co).T).reshape(n, oh, ow, kh, kw, c)
+        pb = max((oh - 1) * stride + kh - h - pt, 0)
+        pr = max((ow - 1) * stride + kw - wd - pl, 0)
+        dxp = np.zeros((n, h + pt + pb, wd + pl + pr, c), dtype=dtype)
+        for i in range(kh):
+            for j in range(kw):
+                dxp[:, i:i + (oh - 1) * stride + 1:stride, j:j + (ow - 1) * stride + 1:stride, :] += dcols[:, :, :, i, j, :]
+        dx = dxp[:, pt:pt + h, pl:pl + wd, :]
+    return dx, dw
+
+
+def grouped_conv(x, w, b, stride, group, dtype=F64):
+    """dcnn.conv (alexnet.py:15-31): split input on C and kernel on C_out (axis 3), SAME conv
+    per group, concat on C, bias_add."""
+    if group == 1:
+        y = conv2d_same(x, w, stride, dtype)
+    else:
+        cin = x.shape[-1] // group
+        cout = w.shape[-1] // group
+        y = np.concatenate([conv2d_same(x[..., g * cin:(g + 1) * cin], w[..., g * cout:(g + 1) * cout], stride, dtype)
+                            for g in range(group)], axis=3)
+    return y + b.astype(dtype)
+
+
+def grouped_conv_grad(x, w, dy, stride, group, dtype=F64, need_dx=True):
+    db = dy.astype(dtype).sum(axis=(0, 1, 2))
+    if group == 1:
+        dx, dw = conv2d_same_grad(x, w, dy, stride, dtype, need_dx)
+        return dx, dw, db
+    cin = x.shape[-1] // group
+    cout = w.shape[-1] // group
+    dxs, dws = [], []
+    for g in range(group):
+        dxg, dwg = conv2d_same_grad(x[..., g * cin:(g + 1) * cin], w[..., g * cout:(g + 1) * cout],
+                                    dy[..., g * cout:(g + 1) * cout], stride, dtype, need_dx)
+        dxs.append(dxg)
+        dws.append(dwg)
+    dx = np.concatenate(dxs, axis=3) if need_dx else None
+    return dx, np.concatenate(dws, axis=3), db
+
+
+def relu(x):
+    return np.maximum(x, 0)
+
+
+def relu_grad(y, dy):
+    """TF ReluGrad: dy where y > 0, else 0 (alexnet.py:77)."""
+    return dy * (y > 0)
+
+
+def lrn(x, radius=2, alpha=2e-5, beta=0.75, bias=1.0, dtype=F64):
+    """tf.nn.local_response_normalization (alexnet.py:79-89): out = x / (bias + alpha *
+    sum_{c'=max(0,c-r)}^{min(C-1,c+r)} x^2)^beta.  alpha is NOT divided by the window size."""
+    x = x.astype(dtype, copy=False)
+    c = x.shape[-1]
+    sq = x * x
+    pad = np.pad(sq, [(0, 0)] * (x.ndim - 1) + [(radius, radius)])
+    s = np.zeros_like(x)
+    for d in range(2 * radius + 1):
+        s += pad[..., d:d + c]
+    scale = bias + alpha * s
+    return x * scale ** (-beta), scale
+
+
+def lrn_grad(x, dy, radius=2, alpha=2e-5, beta=0.75, bias=1.0, dtype=F64):
+    """d/dx of lrn: dx_i = dy_i s_i^-b - 2ab x_i sum_{c: |c-i|<=r} dy_c x_c s_c^(-b-1)."""
+    x = x.astype(dtype, copy=False)
+    dy = dy.astype(dtype, copy=False)
+    c = x.shape[-1]
+    _, scale = lrn(x, radius, alpha, beta, bias, dtype)
+    t = dy * x * scale ** (-beta - 1.0)
+    pad = np.pad(t, [(0, 0)] * (x.ndim - 1) + [(radius, radius)])
+    acc = np.zeros_like(x)
+    for d in range(2 * radius + 1):
+        acc += pad[..., d:d + c]
+    return dy * scale ** (-beta) - 2.0 * alpha * beta * x * acc
+
+
+def max_pool_valid(x, k=3, s=2):
+    """tf.nn.max_pool ksize k, stride s, VALID (alexnet.py:91-98).  Returns (y, argmax) where
+    argmax is the window-local index (kh*k+kw) of the FIRST maximum in row-major scan order
+    (TF-CPU MaxPoolGrad routes the gradient there)."""
+    n, h, w, c = x.shape
+    oh, ow = valid_out(h, k, s), valid_out(w, k, s)
+    y = np.full((n, oh, ow, c), -np.inf, dtype=x.dtype)
+    arg = np.zeros((n, oh, ow, c), dtype=np.int8)
+    for i in range(k):
+        for j in range(k):
+            v = x[:, i:i + (oh - 1) * s + 1:s, j:j + (ow - 1) * s + 1:s, :]
+            upd = v > y
+            y = np.where(upd, v, y)
+            arg = np.where(upd, i * k + j, arg)
+    return y, arg
+
+
+def max_pool_valid_grad(x_shape, arg, dy, k=3, s=2):
+    n, h, w, c = x_shape
+    oh, ow = dy.shape[1], dy.shape[2]
+    dx = np.zeros(x_shape, dtype=dy.dtype)
+    for i in range(k):
+        for j in range(k):
+            dx[:, i:i + (oh - 1) * s + 1:s, j:j + (ow - 1) * s + 1:s, :] += dy * (arg == i * k + j)
+    return dx
+
+
+def xw_plus_b(x, w, b, dtype=F64):
+    """tf.nn.xw_plus_b (alexnet.py:275, tf_util.py:56)."""
+    return x.astype(dtype) @ w.astype(dtype) + b.astype(dtype)
+
+
+def sigmoid(x):
+    return 1.0 / (1.0 + np.exp(-x))
+
+
+# ----------------------------------------------------------------------------------------------
+# AlexNet (CaffeNet-style) -- models/alexnet/alexnet.py:49-275
+# ----------------------------------------------------------------------------------------------
+ALEXNET_CONVS = (
+    # name, kh, kw, cout, stride, group      (alexnet.py:60-77, 100-118, 141-202)
+    ("conv1", 11, 11, 96, 4, 1),
+    ("conv2", 5, 5, 256, 1, 2),
+    ("conv3", 3, 3, 384, 1, 1),
+    ("conv4", 3, 3, 384, 1, 2),
+    ("conv5", 3, 3, 256, 1, 2),
+)
+
+
+def alexnet_param_shapes(num_classes, final_layer="fc6", image_shape=(227, 227, 3)):
+    """Variable shapes in creation order, names as the TF checkpoint keys (alexnet.py:59,70-74)."""
+    shapes = []
+    h, w, c = image_shape
+    for name, kh, kw, co, s, g in ALEXNET_CONVS:
+        shapes.append(("dcnn/%sW" % name, (kh, kw, c // g, co)))
+        shapes.append(("dcnn/%sb" % name, (co,)))
+        h, _, _ = same_pad(h, kh, s)
+        w, _, _ = same_pad(w, kw, s)
+        c = co
+        if name in ("conv1", "conv2", "conv5"):
+            h, w = valid_out(h, 3, 2), valid_out(w, 3, 2)
+    shapes.append(("dcnn/fc6W", (h * w * c, 4096)))
+    shapes.append(("dcnn/fc6b", (4096,)))
+    if final_layer == "fc6":
+        return shapes
+    shapes.append(("dcnn/fc7W", (4096, 4096)))
+    shapes.append(("dcnn/fc7b", (4096,)))
+    if final_layer == "fc7":
+        return shapes
+    shapes.append(("dcnn/fc8W", (4096, num_classes)))
+    shapes.append(("dcnn/fc8b", (num_classes,)))
+    return shapes
+
+
+def truncated_normal(rng, shape, stddev):
+    """tf.truncated_normal: N(0, stddev) with samples beyond 2 stddev re-drawn (alexnet.py:41)."""
+    out = rng.standard_normal(shape)
+    bad = np.abs(out) > 2.0
+    while bad.any():
+        out[bad] = rng.standard_normal(int(bad.sum()))
+        bad = np.abs(out) > 2.0
+    return (out * stddev).astype(np.float32)
+
+
+def init_params(rng, num_classes=101, final_layer="fc6", lstm_hidden=256, lstm_layers=1,
+                image_shape=(227, 227, 3), classifier="lstm", stddev=0.05, well_scaled=False):
+    """Reference initialisers: conv/fc W ~ truncated_normal(0.05), b = 0.1 (alexnet.py:40-46,
+    tf_util.py:44-45); BasicLSTMCell kernel glorot-uniform, bias 0 (TF default initialiser).
+    ``well_scaled`` replaces sigma by sqrt(2/fan_in) so activations stay O(1)."""
+    p = {}
+    for name, shp in alexnet_param_shapes(num_classes, final_layer, image_shape):
+        if name.endswith("W"):
+            fan_in = int(np.prod(shp[:-1]))
+            sd = math.sqrt(2.0 / fan_in) if well_scaled else stddev
+            p[name] = truncated_normal(rng, shp, sd)
+        else:
+            p[name] = np.full(shp, 0.1, np.float32)
+    dim = {"fc6": 4096, "fc7": 4096}.get(final_layer, num_classes)
+    if classifier == "lstm":
+        d = dim
+        for l in range(lstm_layers):
+            lim = math.sqrt(6.0 / (d + lstm_hidden + 4 * lstm_hidden))
+            p["rnn/multi_rnn_cell/cell_%d/basic_lstm_cell/kernel" % l] = rng.uniform(
+                -lim, lim, (d + lstm_hidden, 4 * lstm_hidden)).astype(np.float32)
+            p["rnn/multi_rnn_cell/cell_%d/basic_lstm_cell/bias" % l] = np.zeros(4 * lstm_hidden, np.float32)
+            d = lstm_hidden
+        if lstm_hidden != num_classes:
+            sd = math.sqrt(2.0 / lstm_hidden) if well_scaled else stddev
+            p["output_fc_w"] = truncated_normal(rng, (lstm_hidden, num_classes), sd)
+            p["output_fc_b"] = np.full(num_classes, 0.1, np.float32)
+    elif classifier == "fc" and dim != num_classes:
+        sd = math.sqrt(2.0 / dim) if well_scaled else stddev
+        p["fc_convert_w"] = truncated_normal(rng, (dim, num_classes), sd)
+        p["fc_convert_b"] = np.full(num_classes, 0.1, np.float32)
+    return p
+
+
+def alexnet_forward(p, x, final_layer="fc6", dtype=F64, keep=False):
+    """dcnn.create (alexnet.py:49-275).  x: [N,H,W,3] float (BGR, mean-subtracted), NHWC.
+    Returns (output, cache).  final_layer: 'fc6' | 'fc7' | anything else -> fc8 logits."""
+    cache = {"x": x} if keep else {}
+    a = x.astype(dtype, copy=False)
+    for name, kh, kw, co, s, g in ALEXNET_CONVS:
+        z = grouped_conv(a, p["dcnn/%sW" % name], p["dcnn/%sb" % name], s, g, dtype)
+        a_in = a
+        a = relu(z)
+        if keep:
+            cache[name + "_in"] = a_in
+            cache[name] = a
+        if name in ("conv1", "conv2"):
+            r = a
+            a, _ = lrn(a, dtype=dtype)
+            if keep:
+                cache["lrn" + name[-1] + "_in"] = r
+                cache["lrn" + name[-1]] = a
+        if name in ("conv1", "conv2", "conv5"):
+            pin = a
+            a, arg = max_pool_valid(a)
+            if keep:
+                cache["pool" + name[-1] + "_in_shape"] = pin.shape
+                cache["pool" + name[-1] + "_arg"] = arg
+                cache["pool" + name[-1]] = a
+    n = a.shape[0]
+    flat = a.reshape(n, -1)                    # (h, w, c)-major flatten (alexnet.py:228)
+    fc6 = relu(xw_plus_b(flat, p["dcnn/fc6W"], p["dcnn/fc6b"], dtype))
+    if keep:
+        cache["flat"], cache["fc6"] = flat, fc6
+    if final_layer == "fc6":
+        return fc6, cache
+    fc7 = relu(xw_plus_b(fc6, p["dcnn/fc7W"], p["dcnn/fc7b"], dtype))
+    if keep:
+        cache["fc7"] = fc7
+    if final_layer == "fc7":
+        return fc7, cache
+    fc8 = xw_plus_b(fc7, p["dcnn/fc8W"], p["dcnn/fc8b"], dtype)
+    return fc8, cache
+
+
+def alexnet_backward(p, cache, dout, final_layer="fc6", dtype=F64):
+    """Gradients of alexnet_forward wrt every parameter; dout is d(loss)/d(output)."""
+    g = {}
+    d = dout.astype(dtype)
+    if final_layer not in ("fc6", "fc7"):
+        g["dcnn/fc8W"] = cache["fc7"].T @ d
+        g["dcnn/fc8b"] = d.sum(0)
+        d = d @ p["dcnn/fc8W"].astype(dtype).T
+    if final_layer != "fc6":
+        d = relu_grad(cache["fc7"], d)
+        g["dcnn/fc7W"] = cache["fc6"].T @ d
+        g["dcnn/fc7b"] = d.sum(0)
+        d = d @ p["dcnn/fc7W"].astype(dtype).T
+    d = relu_grad(cache["fc6"], d)
+    g["dcnn/fc6W"] = cache["flat"].T @ d
+    g["dcnn/fc6b"] = d.sum(0)
+    d = (d @ p["dcnn/fc6W"].astype(dtype).T).reshape(cache["pool5"].shape)
+    for name, kh, kw, co, s, grp in reversed(ALEXNET_CONVS):
+        i = name[-1]
+        if name in ("conv1", "conv2", "conv5"):
+            d = max_pool_valid_grad(cache["pool%s_in_shape" % i], cache["pool%s_arg" % i], d)
+        if name in ("conv1", "conv2"):
+            d = lrn_grad(cache["lrn%s_in" % i], d, dtype=dtype)
+        d = relu_grad(cache[name], d)
+        dx, dw, db = grouped_conv_grad(cache[name + "_in"], p["dcnn/%sW" % name], d, s, grp, dtype,
+                                       need_dx=(name != "conv1"))
+        g["dcnn/%sW" % name] = dw
+        g["dcnn/%sb" % name] = db
+        d = dx
+    return g
+
+
+# ----------------------------------------------------------------------------------------------
+# LSTM -- models/lstm/lstm.py:9-20, 59-143 (BasicLSTMCell + MultiRNNCell + dynamic_rnn)
+# ----------------------------------------------------------------------------------------------
+FORGET_BIAS = 1.0   # tf.contrib.rnn.BasicLSTMCell default, not overridden at lstm.py:17
+
+
+def lstm_layer_forward(x, kernel, bias, h0=None, c0=None, dtype=F64):
+    """One BasicLSTMCell unrolled by dynamic_rnn over x [B,T,D] (all rows full length, lstm.py:136).
+    gates = concat([x_t, h]) @ kernel + bias; split i, j, f, o;
+    c' = c*sigmoid(f + 1.0) + sigmoid(i)*tanh(j); h' = tanh(c')*sigmoid(o)."""
+    x = x.astype(dtype, copy=False)
+    kernel = kernel.astype(dtype, copy=False)
+    bias = bias.astype(dtype, copy=False)
+    b, t, d = x.shape
+    hdim = kernel.shape[1] // 4
+    h = np.zeros((b, hdim), dtype) if h0 is None else h0.astype(dtype)
+    c = np.zeros((b, hdim), dtype) if c0 is None else c0.astype(dtype)
+    hs, cs, gates = [], [], []
+    for s in range(t):
+        z = np.concatenate([x[:, s, :], h], axis=1) @ kernel + bias
+        i, j, f, o = np.split(z, 4, axis=1)
+        gi, gj, gf, go = sigmoid(i), np.tanh(j), sigmoid(f + FORGET_BIAS), sigmoid(o)
+        c_prev = c
+        c = c * gf + gi * gj
+        h_prev = h
+        h = np.tanh(c) * go
+        hs.append(h)
+        cs.append(c)
+        gates.append((gi, gj, gf, go, c_prev, h_prev))
+    out = np.stack(hs, axis=1)
+    return out, (c, h), {"x": x, "gates": gates, "cs": cs}
+
+
+def lstm_layer_backward(kernel, cache, dout, dh_last=None, dc_last=None, dtype=F64):
+    """BPTT through lstm_layer_forward.  dout [B,T,H] = d/d(outputs)."""
+    kernel = kernel.astype(dtype, copy=False)
+    x = cache["x"]
+    b, t, d = x.shape
+    hdim = kernel.shape[1] // 4
+    dk = np.zeros_like(kernel)
+    db = np.zeros(4 * hdim, dtype)
+    dx = np.zeros_like(x)
+    dh = np.zeros((b, hdim), dtype) if dh_last is None else dh_last.astype(dtype)
+    dc = np.zeros((b, hdim), dtype) if dc_last is None else dc_last.astype(dtype)
+    for s in reversed(range(t)):
+        gi, gj, gf, go, c_prev, h_prev = cache["gates"][s]
+        c = cache["cs"][s]
+        dh = dh + dout[:, s, :]
+        tc = np.tanh(c)
+        do = dh * tc
+        dc = dc + dh * go * (1.0 - tc * tc)
+        di = dc * gj
+        dj = dc * gi
+        df = dc * c_prev
+        dc = dc * gf
+        dz = np.concatenate([di * gi * (1 - gi), dj * (1 - gj * gj), df * gf * (1 - gf), do * go * (1 - go)], axis=1)
+        xin = np.concatenate([x[:, s, :], h_prev], axis=1)
+        dk += xin.T @ dz
+        db += dz.sum(0)
+        dxin = dz @ kernel.T
+        dx[:, s, :] = dxin[:, :d]
+        dh = dxin[:, d:]
+    return dx, dk, db, dh, dc
+
+
+def temporal_fusion(x, method):
+    """apply_temporal_fusion (tf_util.py:4-30): x [B,T,H]."""
+    if method == "avg":
+        return x.mean(axis=1)
+    if method == "last":
+        return x[:, -1, :]
+    if method == "reshape":
+        return x.reshape(-1, x.shape[-1])
+    raise ValueError("Undefined frame fusion type : %s" % method)
+
+
+def temporal_fusion_grad(shape, method, d):
+    b, t, h = shape
+    if method == "avg":
+        return np.repeat(d[:, None, :] / t, t, axis=1)
+    if method == "last":
+        out = np.zeros(shape, d.dtype)
+        out[:, -1, :] = d
+        return out
+    if method == "reshape":
+        return d.reshape(shape)
+    raise ValueError(method)
+
+
+def softmax_xent_mean(logits, onehot, dtype=F64):
+    """train.py:120-123: mean_b softmax_cross_entropy_with_logits(logits, labels).
+    Returns (loss, dlogits) with TF's registered backprop (softmax - labels)/B."""
+    z = logits.astype(dtype)
+    y = onehot.astype(dtype)
+    zmax = z.max(axis=1, keepdims=True)
+    e = np.exp(z - zmax)
+    lse = np.log(e.sum(axis=1, keepdims=True)) + zmax
+    logp = z - lse
+    loss = float((-(y * logp).sum(axis=1)).mean())
+    dlogits = (np.exp(logp) - y) / z.shape[0]
+    return loss, dlogits
+
+
+def accuracy(logits, onehot):
+    """train.py:142-149 / val.py:199-203."""
+    return float(np.mean(np.argmax(logits, 1) == np.argmax(onehot, 1)))
+
+
+def clip_by_global_norm(grads, clip_norm):
+    """tf.clip_by_global_norm (train.py:215): scale = clip / max(global_norm, clip)."""
+    gn = math.sqrt(sum(float((g.astype(F64) ** 2).sum()) for g in grads.values()))
+    scale = clip_norm / max(gn, clip_norm) if clip_norm else 1.0
+    return {k: v * scale for k, v in grads.items()}, gn
+
+
+def labels_to_one_hot(labels, num_classes):
+    """utils_.py:160-169."""
+    onehots = np.zeros((len(labels), num_classes), np.int32)
+    for i, l in enumerate(labels):
+        onehots[i][l] = 1
+    return onehots
+
+
+# ----------------------------------------------------------------------------------------------
+# LRCN pipeline -- models/model.py:18-155 (dcnn representation -> lstm | fc classifier)
+# ----------------------------------------------------------------------------------------------
+def lrcn_forward(p, frames, fpc, final_layer="fc6", lstm_layers=1, fusion="avg", classifier="lstm",
+                 frame_fusion=None, dtype=F64, keep=False, chunk=32):
+    """frames [B*T,H,W,3] NHWC float, fpc = T.  Returns (logits [B,C], cache)."""
+    n = frames.shape[0]
+    feats, caches = [], []
+    for s in range(0, n, chunk):
+        f, c = alexnet_forward(p, frames[s:s + chunk], final_layer, dtype, keep)
+        feats.append(f)
+        caches.append(c)
+    feat = np.concatenate(feats, axis=0)
+    cache = {"cnn": caches, "feat": feat, "chunk": chunk}
+    dim = feat.shape[1]
+    if classifier == "lstm":
+        x = feat.reshape(-1, fpc, dim)                         # lstm.py:120
+        lcaches = []
+        for l in range(lstm_layers):
+            x, _, lc = lstm_layer_forward(x, p["rnn/multi_rnn_cell/cell_%d/basic_lstm_cell/kernel" % l],
+                                          p["rnn/multi_rnn_cell/cell_%d/basic_lstm_cell/bias" % l], dtype=dtype)
+            lcaches.append(lc)
+        fused = temporal_fusion(x, fusion)                     # lstm.py:83
+        cache.update(lstm=lcaches, seq_shape=x.shape, fused=fused)
+        if "output_fc_w" in p:
+            logits = xw_plus_b(fused, p["output_fc_w"], p["output_fc_b"], dtype)   # lstm.py:88-90
+        else:
+            logits = fused
+    else:  # classifier fc (model.py:115-119) with optional early/late frame fusion (model.py:103-106,149-151)
+        v = feat
+        if frame_fusion and frame_fusion[0] == "early" and fpc > 1:
+            v = temporal_fusion(v.reshape(-1, fpc, dim), frame_fusion[1])
+        cache["fc_in"] = v
+        logits = xw_plus_b(v, p["fc_convert_w"], p["fc_convert_b"], dtype) if "fc_convert_w" in p else v
+        cache["pre_late"] = logits
+        if frame_fusion and frame_fusion[0] == "late" and fpc > 1:
+            logits = temporal_fusion(logits.reshape(-1, fpc, logits.shape[1]), frame_fusion[1])
+    return logits, cache
+
+
+def lrcn_backward(p, cache, dlogits, fpc, final_layer="fc6", lstm_layers=1, fusion="avg", dtype=F64):
+    """Gradients of lrcn_forward (classifier lstm) wrt every parameter."""
+    g = {}
+    d = dlogits.astype(dtype)
+    if "output_fc_w" in p:
+        g["output_fc_w"] = cache["fused"].T @ d
+        g["output_fc_b"] = d.sum(0)
+        d = d @ p["output_fc_w"].astype(dtype).T
+    d = temporal_fusion_grad(cache["seq_shape"], fusion, d)
+    for l in reversed(range(lstm_layers)):
+        kname = "rnn/multi_rnn_cell/cell_%d/basic_lstm_cell/kernel" % l
+        d, dk, db, _, _ = lstm_layer_backward(p[kname], cache["lstm"][l], d, dtype=dtype)
+        g[kname] = dk
+        g[kname[:-6] + "bias"] = db
+    dfeat = d.reshape(-1, d.shape[-1])
+    chunk = cache["chunk"]
+    for ci, cc in enumerate(cache["cnn"]):
+        gc = alexnet_backward(p, cc, dfeat[ci * chunk:(ci + 1) * chunk], final_layer, dtype)
+        for k, v in gc.items():
+            g[k] = g[k] + v if k in g else v
+    return g
+
+
+def lrcn_train_step(p, frames, onehot, fpc, lr, clip_norm=0.0, final_layer="fc6", lstm_layers=1,
+                    fusion="avg", dtype=F64, chunk=32):
+    """One single-tier SGD step (train.py:199-222): loss, grads, global-norm clip, w -= lr*g.
+    Returns (new_params, loss, global_norm, accuracy, logits, grads_unclipped)."""
+    logits, cache = lrcn_forward(p, frames, fpc, final_layer, lstm_layers, fusion, "lstm", None, dtype, True, chunk)
+    loss, dlogits = softmax_xent_mean(logits, onehot, dtype)
+    grads = lrcn_backward(p, cache, dlogits, fpc, final_layer, lstm_layers, fusion, dtype)
+    clipped, gn = clip_by_global_norm(grads, clip_norm)
+    new_p = {k: (p[k].astype(dtype) - lr * clipped[k]).astype(np.float32) for k in p}
+    return new_p, loss, gn, accuracy(logits, onehot), logits, grads
+
+
+# ----------------------------------------------------------------------------------------------
+# Host image processing -- dataset_.py:444-501, 521-530, 571-577
+# ----------------------------------------------------------------------------------------------
+def center_crop_offsets(raw_shape, want_shape):
+    """compute_crop center mode: floor((raw - want)/2) (dataset_.py:572-573)."""
+    return tuple(int(np.floor((r - w) / 2)) for r, w in zip(raw_shape[:2], want_shape[:2]))
+
+
+def rand_crop_range(raw_shape, want_shape):
+    """compute_crop rand mode: offsets in range(0, raw - want - 1) (dataset_.py:574-576)."""
+    return (list(range(0, raw_shape[0] - want_shape[0] - 1)), list(range(0, raw_shape[1] - want_shape[1] - 1)))
+
+
+def process_image(img_u8, want_shape, crop_yx=None, mean_bgr=None, mirror=False):
+    """process_image (dataset_.py:481-501) for already raw-sized frames: crop -> minus mean
+    (float32 HWC, mean_image[0] = blue, dataset_.py:521-530) -> optional mirror of the W axis."""
+    img = img_u8
+    if crop_yx is not None:
+        y, x = crop_yx
+        img = img[y:y + want_shape[0], x:x + want_shape[1], :]
+    img = img.astype(np.float32)
+    if mean_bgr is not None:
+        img = img - np.asarray(mean_bgr, np.float32).reshape(1, 1, 3)
+    if mirror:
+        img = img[:, ::-1, :]
+    return img
+
+
+# ----------------------------------------------------------------------------------------------
+# LR schedule -- train.py:50-109
+# ----------------------------------------------------------------------------------------------
+def precompute_learning_rates(base_lr, decay_params, num_batches, epochs):
+    total = num_batches * epochs
+    if decay_params is None:
+        return [base_lr] * total
+    offset = 0 if len(tuple(decay_params)) == 4 else decay_params[-1]
+    strategy, scheme, freq, factor = tuple(decay_params[:4])
+    staircase = strategy == "staircase"
+    period = freq if scheme == "interval" else math.ceil(total / freq)
+    lrs, idx = [], 0
+    while len(lrs) < total:
+        fraction = idx // freq if staircase else idx / freq
+        lrs.extend([base_lr * pow(factor, fraction)] * period)
+        idx += freq
+    lrs = lrs[:total]
+    if offset:
+        lrs = [base_lr] * offset + lrs[0:-offset]
+    return lrs
+
+
+# ----------------------------------------------------------------------------------------------
+# Validation aggregation -- val.py:91-110, 158-203
+# ----------------------------------------------------------------------------------------------
+def clip_fusion_per_video(clip_logits, cpv_list, method="avg"):
+    out, pos = [], 0
+    for cpv in cpv_list:
+        cur = clip_logits[pos:pos + cpv]
+        out.append(cur.mean(axis=0) if method == "avg" else cur[-1])
+        pos += cpv
+    assert pos == len(clip_logits)
+    return np.stack(out).astype(np.float32)
