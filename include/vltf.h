@@ -1,0 +1,158 @@
+/* vltf.h -- C-ABI of libvltf_hip.so: the MI355X (gfx950) hot path of npit/video-learning-tf.
+ *
+ * The reference has no FFI: every FLOP of its hot path runs inside two TensorFlow executor calls,
+ *   train:   sess.run([summaries, loss, lr, global_step, optimizer], feed_dict)   run_task.py:29,44
+ *   forward: sess.run(model.logits, feed_dict)                                     run_task.py:95
+ * over a graph assembled from stock TF ops (models/alexnet/alexnet.py, models/lstm/lstm.py,
+ * tf_util.py, train.py).  Each entry point below replaces one of those TF ops (cited per
+ * function); the Python host (video-learning-tf_amd/) composes them exactly where the
+ * reference composes the TF ops, so the two sess.run calls become two host functions.
+ *
+ * Conventions
+ *   - extern "C"; every function returns 0 on success, non-zero on failure;
+ *     vl_last_error() returns a thread-local human readable message for the last failure.
+ *   - Every data pointer is a DEVICE pointer owned by the caller (torch-ROCm tensors are used
+ *     only as allocations).  Nothing is allocated after vl_conv_create(); workspaces are
+ *     caller provided.  All work is enqueued asynchronously on `stream` (a hipStream_t).
+ *   - Activations are NCHW fp32.  Parameters keep the reference's layouts: conv kernels HWIO
+ *     [kh][kw][cin/group][cout] (alexnet.py:73,113), fc weights [in][out] (alexnet.py:225),
+ *     LSTM kernel [D+H][4H] with gate order i, j, f, o (TF BasicLSTMCell; lstm.py:17).
+ *   - Thread-compatible: one stream/descriptor set per host thread.
+ */
+#ifndef VLTF_H
+#define VLTF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* vl_stream_t;                 /* hipStream_t */
+typedef struct vl_conv_desc vl_conv_desc;  /* opaque convolution descriptor */
+
+const char* vl_last_error(void);
+int vl_version(void);
+/* Number of HIP devices visible; <0 on error.  Does not create a context. */
+int vl_device_count(void);
+
+/* ---- input preparation: Dataset.process_image (dataset_.py:481-501) on device ------------------
+ * src: uint8 [n][raw_h][raw_w][3] HWC, BGR (the TFRecord 'image_raw' bytes, dataset_.py:125-126).
+ * dst: fp32  [n][3][out_h][out_w] NCHW.  crop_y/crop_x: int32[n] top-left crop offsets
+ * (center: floor((raw-want)/2), dataset_.py:572-573); mirror: uint8[n] flips the W axis
+ * (dataset_.py:497-499); mean_bgr: float[3] subtracted per channel (dataset_.py:521-530), may be NULL.
+ * crop_y, crop_x, mirror may be NULL (= 0). */
+int vl_input_prep_u8(const uint8_t* src, float* dst, int n, int raw_h, int raw_w, int out_h, int out_w,
+                     const int32_t* crop_y, const int32_t* crop_x, const uint8_t* mirror,
+                     const float* mean_bgr, vl_stream_t stream);
+/* The reference's own feed format: fp32 NHWC placeholder (models/model.py:54) -> NCHW. */
+int vl_nhwc_to_nchw(const float* src, float* dst, int n, int h, int w, int c, vl_stream_t stream);
+int vl_nchw_to_nhwc(const float* src, float* dst, int n, int c, int h, int w, vl_stream_t stream);
+
+/* ---- convolution: dcnn.conv (alexnet.py:15-31) = tf.nn.conv2d 'SAME' per group + bias_add ------
+ * The descriptor fixes geometry and owns small device index tables (allocated at create). */
+int vl_conv_create(vl_conv_desc** out, int cin, int h, int w, int cout, int kh, int kw, int stride, int groups);
+void vl_conv_destroy(vl_conv_desc* d);
+int vl_conv_out_hw(const vl_conv_desc* d, int* oh, int* ow);
+/* y[n][cout][oh][ow] = conv(x[n][cin][h][w], w_hwio) + bias, optional fused ReLU (alexnet.py:77). */
+int vl_conv_fwd(const vl_conv_desc* d, const float* x, const float* w_hwio, const float* bias, float* y,
+                int n, int relu, vl_stream_t stream);
+/* wt = flipped/transposed copy of w used by vl_conv_dgrad: wt[kh'][kw'][co][g*cin_g+ci] =
+ * w[KH-1-kh'][KW-1-kw'][ci][g*cout_g+co].  Same element count as w. */
+int vl_conv_wt_transpose(const vl_conv_desc* d, const float* w_hwio, float* wt, vl_stream_t stream);
+/* dx = d(loss)/dx given dy (stride-1 layers only; conv1 never needs it).  If relu_mask != NULL
+ * (same shape as dx) the ReluGrad of the producing layer is fused: dx = relu_mask > 0 ? dx : 0. */
+int vl_conv_dgrad(const vl_conv_desc* d, const float* dy, const float* wt, float* dx, const float* relu_mask,
+                  int n, vl_stream_t stream);
+/* dw (HWIO) = d(loss)/dw.  Deterministic split reduction through `ws` (>= vl_conv_wgrad_ws_bytes). */
+size_t vl_conv_wgrad_ws_bytes(const vl_conv_desc* d, int n);
+int vl_conv_wgrad(const vl_conv_desc* d, const float* x, const float* dy, float* dw, void* ws, size_t ws_bytes,
+                  int n, vl_stream_t stream);
+/* db[c] = sum_{n,h,w} dy[n][c][h][w]  (gradient of tf.nn.bias_add, alexnet.py:31).
+ * ws: float[64*c] scratch. */
+int vl_bias_grad_nchw(const float* dy, float* db, float* ws, int n, int c, int hw, vl_stream_t stream);
+
+/* ---- tf.nn.local_response_normalization (alexnet.py:79-89,120-130), across channels ------------
+ * y = x / (bias + alpha * sum_{|c'-c|<=radius} x^2)^beta   (alpha not divided by the window). */
+int vl_lrn_fwd(const float* x, float* y, int n, int c, int hw, int radius, float alpha, float beta, float bias,
+               vl_stream_t stream);
+/* dx for the above; relu_fused != 0 additionally applies the ReluGrad of the layer that produced
+ * x (x is a ReLU output, alexnet.py:77): dx = x > 0 ? dx : 0. */
+int vl_lrn_bwd(const float* x, const float* dy, float* dx, int n, int c, int hw, int radius, float alpha,
+               float beta, float bias, int relu_fused, vl_stream_t stream);
+
+/* ---- tf.nn.max_pool k x k, stride s, VALID (alexnet.py:91-98,132-139,204-211) ------------------
+ * x NCHW [n][c][h][w]; y element (n,c,oh,ow) is stored at y[n*ys_n + c*ys_c + oh*ys_h + ow*ys_w]
+ * (NCHW: ys = {c*oh*ow, oh*ow, ow, 1}; (h,w,c)-flat for fc6, alexnet.py:228: {oh*ow*c, 1, ow*c, c}).
+ * argmax: uint8 per output element, stored with the same strides: window-local index of the
+ * first maximum in scan order (TF-CPU MaxPoolGrad target). */
+int vl_maxpool_fwd(const float* x, float* y, uint8_t* argmax, int n, int c, int h, int w, int k, int s,
+                   int64_t ys_n, int64_t ys_c, int64_t ys_h, int64_t ys_w, vl_stream_t stream);
+/* dx NCHW (fully written).  relu_mask (the pool input, NCHW) optional: fused ReluGrad. */
+int vl_maxpool_bwd(const float* dy, const uint8_t* argmax, float* dx, const float* relu_mask, int n, int c,
+                   int h, int w, int k, int s, int64_t ys_n, int64_t ys_c, int64_t ys_h, int64_t ys_w,
+                   vl_stream_t stream);
+
+/* ---- dense GEMM on fp32 MFMA: tf.nn.relu_layer / xw_plus_b / matmul gradients ------------------
+ * C[m][n] = sum_k opA(m,k) * opB(k,n) (+ bias[n]) (ReLU) ; then C = relu_mask>0 ? C : 0 if given.
+ * transa == 0: A is [m][k] row-major (lda);  transa != 0: A is stored [k][m] (lda).
+ * transb == 0: B is [k][n] row-major (ldb);  transb != 0: B is stored [n][k] (ldb).
+ * relu_mask has C's layout (ldc).  ws/ws_bytes: scratch for split-K (may be NULL/0: no split). */
+int vl_gemm(int transa, int transb, int m, int n, int k, const float* a, int64_t lda, const float* b, int64_t ldb,
+            float* c, int64_t ldc, const float* bias, int relu, const float* relu_mask, void* ws, size_t ws_bytes,
+            vl_stream_t stream);
+/* out[n] = sum_m a[m][n] (bias gradients of fc layers); ws: float[64*n]. */
+int vl_colsum(const float* a, int64_t lda, float* out, float* ws, int m, int n, vl_stream_t stream);
+
+/* ---- LSTM: tf.contrib.rnn.BasicLSTMCell under tf.nn.dynamic_rnn (lstm.py:9-20,102-143) ---------
+ * Rows are clip-major: row r = b*T + t.  gx = X @ kernel[:D] + bias for all rows is hoisted into one
+ * vl_gemm; per step the host calls vl_gemm for gh = h_{t-1} @ kernel[D:] and then this kernel:
+ *   z = gx[r] + gh[b];  i,j,f,o = split(z);  c = c_prev*sigmoid(f+forget_bias) + sigmoid(i)*tanh(j);
+ *   h = tanh(c)*sigmoid(o).
+ * act[r][4H] receives the activated gates (i, j, f, o), cseq[r][H] the cell state, hseq[r][H] the
+ * output, hprev[r][H] a copy of h_{t-1} (zeros at t == 0).  gh may be NULL at t == 0. */
+int vl_lstm_step_fwd(const float* gx, const float* gh, float* act, float* cseq, float* hseq, float* hprev,
+                     int batch, int T, int t, int H, float forget_bias, vl_stream_t stream);
+/* BPTT step t: dh = dout[r] + dh_next[b] (dh_next may be NULL at t == T-1); writes dz[r][4H] and
+ * dc (in/out, [batch][H], zero before t == T-1). */
+int vl_lstm_step_bwd(const float* dout, const float* dh_next, const float* act, const float* cseq, float* dc,
+                     float* dz, int batch, int T, int t, int H, vl_stream_t stream);
+
+/* ---- apply_temporal_fusion (tf_util.py:4-30) over x[batch][T][H] ---------------------------------
+ * method 0 = avg, 1 = last. */
+int vl_temporal_fusion_fwd(const float* x, float* y, int batch, int T, int H, int method, vl_stream_t stream);
+int vl_temporal_fusion_bwd(const float* dy, float* dx, int batch, int T, int H, int method, vl_stream_t stream);
+
+/* ---- tf.nn.dropout (lstm.py:50-56): y = x * mask / keep, mask ~ Bernoulli(keep) ------------------
+ * Counter-based RNG keyed by (seed, element index); mask (uint8) is written for the backward. */
+int vl_dropout_fwd(const float* x, float* y, uint8_t* mask, int64_t count, float keep, uint64_t seed, vl_stream_t stream);
+int vl_dropout_bwd(const float* dy, const uint8_t* mask, float* dx, int64_t count, float keep, vl_stream_t stream);
+
+/* ---- loss: mean_b softmax_cross_entropy_with_logits (train.py:120-123) + accuracy (142-149) ----
+ * labels: int32 one/multi-hot [batch][classes] (the reference's labels placeholder, train.py:117).
+ * dlogits = (softmax - labels) * grad_scale   (grad_scale = 1/global_batch); may be NULL.
+ * stats[0] += sum_b loss_b, stats[1] += number of rows with argmax(logits) == argmax(labels);
+ * zero `stats` first (vl_fill). */
+int vl_softmax_xent(const float* logits, const int32_t* labels, float* dlogits, float* stats, int batch,
+                    int classes, float grad_scale, vl_stream_t stream);
+
+/* ---- optimizer: clip_by_global_norm + GradientDescentOptimizer (train.py:199-222) ---------------
+ * vl_sumsq: out[0] (+)= sum g^2 over count elements (ws: float[1024]); accumulate != 0 adds to out. */
+int vl_sumsq(const float* g, int64_t count, float* out, float* ws, int accumulate, vl_stream_t stream);
+/* w -= lr * gscale * clip_scale * g with clip_scale = clip_norm / max(gscale*sqrt(*sumsq), clip_norm)
+ * (1 if clip_norm <= 0 or sumsq == NULL).  gscale folds the 1/world averaging of DP all-reduce. */
+int vl_sgd_apply(float* w, const float* g, int64_t count, float lr, float clip_norm, const float* sumsq,
+                 float gscale, vl_stream_t stream);
+/* tf.train.AdamOptimizer (train.py:205-206) with TF defaults beta1=.9 beta2=.999 eps=1e-8; step >= 1. */
+int vl_adam_apply(float* w, const float* g, float* m, float* v, int64_t count, float lr, float clip_norm,
+                  const float* sumsq, float gscale, int step, vl_stream_t stream);
+
+/* ---- utilities ------------------------------------------------------------------------------- */
+int vl_fill(float* p, int64_t count, float value, vl_stream_t stream);
+/* truncated-normal / uniform parameter initialisers are host side; nothing here. */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VLTF_H */

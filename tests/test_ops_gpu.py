@@ -1,0 +1,345 @@
+"""Per-op parity: every HIP entry point (through the C-ABI) against the CPU oracle on the same
+seeded inputs.  Oracle works NHWC/HWIO (the reference's layouts); the device works NCHW/HWIO.
+Tolerances are ours (parity unpinned): fp32 fma-chain error ~1e-7 * sum|a*b|."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import lrcn_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import vltf_amd.ops as ops_
+    return ops_
+
+
+def dev(a, dtype=torch.float32):
+    return torch.tensor(np.ascontiguousarray(a), dtype=dtype, device=DEV)
+
+
+def host(t):
+    torch.cuda.synchronize()
+    return t.detach().cpu().numpy()
+
+
+def nchw(a):
+    return np.ascontiguousarray(np.transpose(a, (0, 3, 1, 2)))
+
+
+def nhwc(a):
+    return np.ascontiguousarray(np.transpose(a, (0, 2, 3, 1)))
+
+
+def close(got, want, rtol=3e-5, atol_rel=3e-5, msg=""):
+    want = np.asarray(want, np.float64)
+    scale = float(np.abs(want).max()) or 1.0
+    np.testing.assert_allclose(np.asarray(got, np.float64), want, rtol=rtol, atol=atol_rel * scale, err_msg=msg)
+
+
+# ---- GEMM ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("ta", [False, True])
+@pytest.mark.parametrize("tb", [False, True])
+@pytest.mark.parametrize("m,n,k", [(70, 150, 37), (130, 260, 100), (8, 1024, 256), (256, 128, 512), (1, 5, 3)])
+def test_gemm(ops, ta, tb, m, n, k):
+    rng = np.random.default_rng(m * 1000 + n + k)
+    a = rng.standard_normal((m, k)).astype(np.float32)
+    b = rng.standard_normal((k, n)).astype(np.float32)
+    bias = rng.standard_normal(n).astype(np.float32)
+    mask = rng.standard_normal((m, n)).astype(np.float32)
+    ad = dev(a.T if ta else a)
+    bd = dev(b.T if tb else b)
+    c = torch.full((m, n), 7.0, device=DEV)
+    ops.gemm(ad, bd, c, m, n, k, transa=ta, transb=tb)
+    close(host(c), a.astype(np.float64) @ b)
+    ops.gemm(ad, bd, c, m, n, k, transa=ta, transb=tb, bias=dev(bias), relu=True, relu_mask=dev(mask))
+    want = np.maximum(a.astype(np.float64) @ b + bias, 0) * (mask > 0)
+    close(host(c), want)
+
+
+def test_gemm_ld_and_splitk(ops):
+    rng = np.random.default_rng(7)
+    m, n, k = 64, 200, 2048
+    a = rng.standard_normal((m, k + 5)).astype(np.float32)     # lda = k + 5
+    b = rng.standard_normal((k, n + 3)).astype(np.float32)     # ldb = n + 3
+    bias = rng.standard_normal(n).astype(np.float32)
+    c = torch.zeros((m, n + 9), device=DEV)                    # ldc = n + 9
+    ws = torch.empty(16 * m * n, device=DEV)
+    ops.gemm(dev(a), dev(b), c, m, n, k, lda=k + 5, ldb=n + 3, ldc=n + 9, bias=dev(bias), relu=True, ws=ws)
+    want = np.maximum(a[:, :k].astype(np.float64) @ b[:, :n] + bias, 0)
+    got = host(c)
+    close(got[:, :n], want)
+    assert np.all(got[:, n:] == 0)                             # padding untouched
+
+
+# ---- convolution -----------------------------------------------------------------------------------
+CONV_CASES = [
+    # n, h, w, cin, cout, k, stride, groups
+    (2, 23, 23, 3, 8, 11, 4, 1),
+    (3, 24, 20, 3, 8, 11, 4, 1),        # asymmetric SAME padding
+    (2, 9, 9, 6, 8, 5, 1, 2),
+    (2, 7, 6, 8, 6, 3, 1, 2),
+    (1, 227, 227, 3, 96, 11, 4, 1),     # conv1
+    (2, 28, 28, 96, 256, 5, 1, 2),      # conv2
+    (3, 13, 13, 256, 384, 3, 1, 1),     # conv3
+    (3, 13, 13, 384, 384, 3, 1, 2),     # conv4
+    (3, 13, 13, 384, 256, 3, 1, 2),     # conv5
+]
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout,k,s,g", CONV_CASES)
+def test_conv_fwd_bwd(ops, n, h, w, cin, cout, k, s, g):
+    rng = np.random.default_rng(h * 100 + cin)
+    x = rng.standard_normal((n, h, w, cin)).astype(np.float32)
+    wt = (rng.standard_normal((k, k, cin // g, cout)) / math.sqrt(k * k * cin / g)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    conv = ops.Conv(cin, h, w, cout, k, k, s, g)
+    oh, _, _ = O.same_pad(h, k, s)
+    ow, _, _ = O.same_pad(w, k, s)
+    assert (conv.oh, conv.ow) == (oh, ow)
+    xd, wd, bd = dev(nchw(x)), dev(wt), dev(b)
+    y = torch.empty((n, cout, oh, ow), device=DEV)
+    conv.fwd(xd, wd, bd, y, relu=False)
+    z = O.grouped_conv(x, wt, b, s, g)
+    close(nhwc(host(y)), z, msg="conv fwd")
+    conv.fwd(xd, wd, bd, y, relu=True)
+    close(nhwc(host(y)), np.maximum(z, 0), msg="conv fwd+relu")
+
+    dy = rng.standard_normal(z.shape).astype(np.float32)
+    dxo, dwo, dbo = O.grouped_conv_grad(x, wt, dy, s, g, need_dx=(s == 1))
+    dyd = dev(nchw(dy))
+    dw = torch.empty_like(wd)
+    ws = torch.empty(max(conv.wgrad_ws_bytes(n) // 4, 1), device=DEV)
+    conv.wgrad(xd, dyd, dw, ws)
+    close(host(dw), dwo, msg="conv wgrad")
+    db = torch.empty(cout, device=DEV)
+    ops.bias_grad_nchw(dyd, db, torch.empty(64 * cout, device=DEV))
+    close(host(db), dbo, msg="bias grad")
+    if s == 1:
+        wtt = torch.empty(wd.numel(), device=DEV)
+        conv.wt_transpose(wd, wtt)
+        dx = torch.empty_like(xd)
+        conv.dgrad(dyd, wtt, dx)
+        close(nhwc(host(dx)), dxo, msg="conv dgrad")
+        mask = rng.standard_normal(x.shape).astype(np.float32)
+        conv.dgrad(dyd, wtt, dx, relu_mask=dev(nchw(mask)))
+        close(nhwc(host(dx)), dxo * (mask > 0), msg="conv dgrad+mask")
+    else:
+        with pytest.raises(Exception):
+            conv.dgrad(dyd, wd, torch.empty_like(xd))
+
+
+# ---- LRN / pool ------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,h,w,c", [(2, 5, 4, 11), (2, 9, 7, 96), (1, 6, 6, 256), (3, 3, 3, 33)])
+def test_lrn(ops, n, h, w, c):
+    rng = np.random.default_rng(c)
+    x = np.maximum(rng.standard_normal((n, h, w, c)) * 40, 0).astype(np.float32)     # relu outputs, large to exercise the scale
+    dy = rng.standard_normal(x.shape).astype(np.float32)
+    xd = dev(nchw(x))
+    y = torch.empty_like(xd)
+    ops.lrn_fwd(xd, y)
+    want, _ = O.lrn(x)
+    close(nhwc(host(y)), want, rtol=2e-6, atol_rel=1e-7, msg="lrn fwd")
+    dx = torch.empty_like(xd)
+    ops.lrn_bwd(xd, dev(nchw(dy)), dx)
+    g = O.lrn_grad(x, dy)
+    close(nhwc(host(dx)), g, rtol=1e-5, atol_rel=1e-6, msg="lrn bwd")
+    ops.lrn_bwd(xd, dev(nchw(dy)), dx, relu_fused=True)
+    close(nhwc(host(dx)), g * (x > 0), rtol=1e-5, atol_rel=1e-6, msg="lrn bwd + relu grad")
+
+
+@pytest.mark.parametrize("hwc", [False, True])
+@pytest.mark.parametrize("n,h,w,c", [(2, 9, 11, 3), (2, 13, 13, 16), (1, 57, 57, 5), (2, 28, 28, 7)])
+def test_maxpool(ops, hwc, n, h, w, c):
+    rng = np.random.default_rng(h + c)
+    x = np.maximum(rng.standard_normal((n, h, w, c)), 0).astype(np.float32)           # ties at 0 like post-ReLU data
+    y, arg = O.max_pool_valid(x)
+    oh, ow = y.shape[1], y.shape[2]
+    xd = dev(nchw(x))
+    yd = torch.empty((n, oh, ow, c) if hwc else (n, c, oh, ow), device=DEV)
+    ad = torch.empty(yd.shape, dtype=torch.uint8, device=DEV)
+    ops.maxpool_fwd(xd, yd, ad, hwc=hwc)
+    got = host(yd) if hwc else nhwc(host(yd))
+    np.testing.assert_array_equal(got, y)
+    ga = host(ad) if hwc else nhwc(host(ad))
+    np.testing.assert_array_equal(ga, arg)
+    dy = rng.standard_normal(y.shape).astype(np.float32)
+    dyd = dev(dy if hwc else nchw(dy))
+    dx = torch.full(xd.shape, 9.0, device=DEV)
+    ops.maxpool_bwd(dyd, ad, dx, hwc=hwc)
+    want = O.max_pool_valid_grad(x.shape, arg, dy.astype(np.float64))
+    close(nhwc(host(dx)), want, rtol=1e-6, atol_rel=1e-7)
+    ops.maxpool_bwd(dyd, ad, dx, relu_mask=xd, hwc=hwc)
+    close(nhwc(host(dx)), want * (x > 0), rtol=1e-6, atol_rel=1e-7)
+
+
+def test_colsum(ops):
+    rng = np.random.default_rng(0)
+    a = rng.standard_normal((100, 300)).astype(np.float32)
+    out = torch.empty(300, device=DEV)
+    ops.colsum(dev(a), out, torch.empty(64 * 300, device=DEV), 100, 300)
+    close(host(out), a.astype(np.float64).sum(0))
+
+
+# ---- input prep ------------------------------------------------------------------------------------
+def test_input_prep(ops):
+    rng = np.random.default_rng(3)
+    n, rh, rw, oh, ow = 5, 24, 32, 17, 19
+    src = rng.integers(0, 256, (n, rh, rw, 3), dtype=np.uint8)
+    cy = rng.integers(0, rh - oh + 1, n).astype(np.int32)
+    cx = rng.integers(0, rw - ow + 1, n).astype(np.int32)
+    mir = rng.integers(0, 2, n).astype(np.uint8)
+    mean = np.array([99.197148, 105.293620, 109.503945], np.float32)
+    dst = torch.empty((n, 3, oh, ow), device=DEV)
+    ops.input_prep_u8(dev(src, torch.uint8), dst, dev(cy, torch.int32), dev(cx, torch.int32), dev(mir, torch.uint8), dev(mean))
+    want = np.stack([O.process_image(src[i], (oh, ow, 3), (cy[i], cx[i]), mean, bool(mir[i])) for i in range(n)])
+    np.testing.assert_array_equal(nhwc(host(dst)), want)          # bit exact: u8 -> f32 minus f32
+    ops.input_prep_u8(dev(src, torch.uint8)[:, :oh, :ow].contiguous(), dst)
+    np.testing.assert_array_equal(nhwc(host(dst)), src[:, :oh, :ow].astype(np.float32))
+    # layout converters
+    x = rng.standard_normal((2, 5, 7, 3)).astype(np.float32)
+    t = torch.empty((2, 3, 5, 7), device=DEV)
+    ops.nhwc_to_nchw(dev(x), t)
+    np.testing.assert_array_equal(host(t), nchw(x))
+    back = torch.empty((2, 5, 7, 3), device=DEV)
+    ops.nchw_to_nhwc(t, back)
+    np.testing.assert_array_equal(host(back), x)
+
+
+# ---- LSTM step / fusion / dropout -------------------------------------------------------------------
+def test_lstm_steps_match_layer(ops):
+    """Drives the step kernels + vl_gemm exactly as the host does and compares with the oracle layer."""
+    rng = np.random.default_rng(11)
+    b, T, d, H = 5, 4, 24, 16
+    x = rng.standard_normal((b, T, d)).astype(np.float32)
+    kern = (rng.standard_normal((d + H, 4 * H)) * 0.3).astype(np.float32)
+    bias = (rng.standard_normal(4 * H) * 0.1).astype(np.float32)
+    out, (c_last, h_last), cache = O.lstm_layer_forward(x, kern, bias)
+    xd, kd, bd = dev(x.reshape(b * T, d)), dev(kern), dev(bias)
+    gx = torch.empty((b * T, 4 * H), device=DEV)
+    ops.gemm(xd, kd, gx, b * T, 4 * H, d, bias=bd)
+    gh = torch.empty((b, 4 * H), device=DEV)
+    act = torch.empty((b * T, 4 * H), device=DEV)
+    cseq = torch.empty((b * T, H), device=DEV)
+    hseq = torch.empty((b * T, H), device=DEV)
+    hprev = torch.empty((b * T, H), device=DEV)
+    kh = kd[d:]
+    for t in range(T):
+        if t > 0:
+            ops.gemm(hseq[t - 1:], kh, gh, b, 4 * H, H, lda=T * H)
+        ops.lstm_step_fwd(gx, gh if t > 0 else None, act, cseq, hseq, hprev, b, T, t, H)
+    close(host(hseq).reshape(b, T, H), out, rtol=1e-5, atol_rel=1e-6, msg="lstm outputs")
+    close(host(cseq).reshape(b, T, H)[:, -1], c_last, rtol=1e-5, atol_rel=1e-6)
+    hp = np.concatenate([np.zeros((b, 1, H)), out[:, :-1]], axis=1)
+    close(host(hprev).reshape(b, T, H), hp, rtol=1e-5, atol_rel=1e-6)
+
+    dout = rng.standard_normal(out.shape).astype(np.float32)
+    dxo, dko, dbo, _, _ = O.lstm_layer_backward(kern, cache, dout)
+    dd = dev(dout.reshape(b * T, H))
+    dz = torch.empty((b * T, 4 * H), device=DEV)
+    dc = torch.zeros((b, H), device=DEV)
+    dh = torch.empty((b, H), device=DEV)
+    for t in reversed(range(T)):
+        ops.lstm_step_bwd(dd, dh if t < T - 1 else None, act, cseq, dc, dz, b, T, t, H)
+        if t > 0:
+            ops.gemm(dz[t:], kh, dh, b, H, 4 * H, transb=True, lda=T * 4 * H)
+    dk = torch.empty_like(kd)
+    ops.gemm(xd, dz, dk, d, 4 * H, b * T, transa=True)
+    ops.gemm(hprev, dz, dk[d:], H, 4 * H, b * T, transa=True)
+    dbias = torch.empty(4 * H, device=DEV)
+    ops.colsum(dz, dbias, torch.empty(64 * 4 * H, device=DEV), b * T, 4 * H)
+    dx = torch.empty((b * T, d), device=DEV)
+    ops.gemm(dz, kd, dx, b * T, d, 4 * H, transb=True)
+    close(host(dk), dko, rtol=1e-4, atol_rel=1e-5, msg="lstm dkernel")
+    close(host(dbias), dbo, rtol=1e-4, atol_rel=1e-5, msg="lstm dbias")
+    close(host(dx).reshape(b, T, d), dxo, rtol=1e-4, atol_rel=1e-5, msg="lstm dx")
+
+
+@pytest.mark.parametrize("method", ["avg", "last"])
+def test_temporal_fusion(ops, method):
+    rng = np.random.default_rng(5)
+    b, T, H = 3, 5, 7
+    x = rng.standard_normal((b, T, H)).astype(np.float32)
+    y = torch.empty((b, H), device=DEV)
+    ops.temporal_fusion_fwd(dev(x), y, b, T, H, method)
+    close(host(y), O.temporal_fusion(x.astype(np.float64), method), rtol=1e-6, atol_rel=1e-7)
+    dy = rng.standard_normal((b, H)).astype(np.float32)
+    dx = torch.empty((b, T, H), device=DEV)
+    ops.temporal_fusion_bwd(dev(dy), dx, b, T, H, method)
+    close(host(dx), O.temporal_fusion_grad(x.shape, method, dy.astype(np.float64)), rtol=1e-6, atol_rel=1e-7)
+
+
+def test_dropout(ops):
+    n, keep = 1 << 16, 0.5
+    x = torch.ones(n, device=DEV)
+    y = torch.empty(n, device=DEV)
+    m = torch.empty(n, dtype=torch.uint8, device=DEV)
+    ops.dropout_fwd(x, y, m, keep, 1234)
+    yh, mh = host(y), host(m)
+    assert set(np.unique(yh)) <= {0.0, 2.0} and np.array_equal(yh > 0, mh > 0)
+    assert abs(mh.mean() - keep) < 0.01
+    y2 = torch.empty(n, device=DEV)
+    ops.dropout_fwd(x, y2, m, keep, 1234)
+    assert np.array_equal(host(y2), yh)                         # counter based: same seed, same mask
+    ops.dropout_fwd(x, y2, torch.empty_like(m), keep, 99)
+    assert not np.array_equal(host(y2), yh)
+    dx = torch.empty(n, device=DEV)
+    ops.dropout_bwd(x, m, dx, keep)
+    assert np.array_equal(host(dx), yh)
+
+
+# ---- loss / optimizer --------------------------------------------------------------------------------
+@pytest.mark.parametrize("b,c", [(6, 9), (64, 101), (9, 200)])
+def test_softmax_xent(ops, b, c):
+    rng = np.random.default_rng(b)
+    z = (rng.standard_normal((b, c)) * 5).astype(np.float32)
+    lab = rng.integers(0, c, b)
+    z[0, lab[0]] = 50.0                                         # at least one correct prediction
+    onehot = O.labels_to_one_hot([[l] for l in lab], c)
+    loss, dz = O.softmax_xent_mean(z, onehot)
+    stats = torch.zeros(2, device=DEV)
+    dl = torch.empty((b, c), device=DEV)
+    ops.softmax_xent(dev(z), dev(onehot, torch.int32), dl, stats, 1.0 / b)
+    s = host(stats)
+    assert abs(s[0] / b - loss) < 1e-5 * max(1.0, abs(loss))
+    assert s[1] == round(O.accuracy(z, onehot) * b)
+    close(host(dl), dz, rtol=1e-4, atol_rel=1e-6)
+
+
+def test_optimizer(ops):
+    rng = np.random.default_rng(2)
+    n = 100003
+    w = rng.standard_normal(n).astype(np.float32)
+    g = (rng.standard_normal(n) * 3).astype(np.float32)
+    ss = torch.zeros(1, device=DEV)
+    ws = torch.empty(1024, device=DEV)
+    gd = dev(g)
+    ops.sumsq(gd[:50000], ss, ws)
+    ops.sumsq(gd[50000:], ss, ws, accumulate=True)
+    want_ss = float((g.astype(np.float64) ** 2).sum())
+    assert abs(host(ss)[0] - want_ss) / want_ss < 1e-6
+    for clip, gscale in [(10.0, 1.0), (1e9, 1.0), (0.0, 1.0), (10.0, 0.125)]:
+        wd = dev(w)
+        ops.sgd_apply(wd, gd, 0.01, clip, ss, gscale)
+        norm = gscale * math.sqrt(want_ss)
+        scale = gscale * (clip / max(norm, clip) if clip > 0 else 1.0)
+        close(host(wd), w - 0.01 * scale * g.astype(np.float64), rtol=1e-6, atol_rel=1e-7)
+    # Adam, two steps, TF formulation (train.py:205-206)
+    wd, m, v = dev(w), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    wr, mr, vr = w.astype(np.float64), np.zeros(n), np.zeros(n)
+    for step in (1, 2):
+        ops.adam_apply(wd, gd, m, v, 0.001, step)
+        mr = 0.9 * mr + 0.1 * g
+        vr = 0.999 * vr + 0.001 * g.astype(np.float64) ** 2
+        lr_t = 0.001 * math.sqrt(1 - 0.999 ** step) / (1 - 0.9 ** step)
+        wr = wr - lr_t * mr / (np.sqrt(vr) + 1e-8)
+    close(host(wd), wr, rtol=1e-5, atol_rel=1e-6)
+    f = torch.empty(1000, device=DEV)
+    ops.fill(f, 0.1)
+    assert np.all(host(f) == np.float32(0.1))

@@ -1,0 +1,19 @@
+#!/bin/bash
+# Builds libvltf_hip.so (gfx950 only) in-tree next to the sources' parent package.
+set -euo pipefail
+here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+out="$here/../libvltf_hip.so"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
+mkdir -p "$here/obj"
+pids=()
+for f in api mfma_gemm pointwise; do
+  if [ ! -f "$here/obj/$f.o" ] || [ "$here/$f.hip" -nt "$here/obj/$f.o" ] || [ "$here/common.h" -nt "$here/obj/$f.o" ] \
+     || [ "$here/../../include/vltf.h" -nt "$here/obj/$f.o" ]; then
+    $HIPCC $FLAGS -c "$here/$f.hip" -o "$here/obj/$f.o" &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$out" "$here/obj/api.o" "$here/obj/mfma_gemm.o" "$here/obj/pointwise.o"
+echo "built $out"

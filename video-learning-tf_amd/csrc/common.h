@@ -1,0 +1,60 @@
+// Shared helpers for libvltf_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/vltf.h"
+
+// ---- error convention: int return + thread-local message (include/vltf.h) ----------------------
+void vl_set_error(const char* fmt, ...);
+
+#define VL_CHECK(cond, ...)                \
+    do {                                   \
+        if (!(cond)) {                     \
+            vl_set_error(__VA_ARGS__);     \
+            return 1;                      \
+        }                                  \
+    } while (0)
+
+#define VL_HIP(expr)                                                                             \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess) {                                                                  \
+            vl_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return 2;                                                                            \
+        }                                                                                        \
+    } while (0)
+
+#define VL_LAUNCH_CHECK() VL_HIP(hipGetLastError())
+
+// ---- division by a runtime constant: q = (mulhi(n, m) + n) >> s, valid for n < 2^31 -------------
+struct FastDiv {
+    uint32_t d, m, s;
+};
+
+static inline FastDiv make_fastdiv(uint32_t d) {
+    FastDiv f;
+    f.d = d;
+    uint32_t s = 0;
+    while ((1ull << s) < d) ++s;
+    f.s = s;
+    f.m = (uint32_t)(((1ull << 32) * ((1ull << s) - d)) / d + 1);
+    return f;
+}
+
+__device__ __forceinline__ uint32_t fd_div(uint32_t n, const FastDiv& f) { return (__umulhi(n, f.m) + n) >> f.s; }
+
+static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// one 64-lane wavefront reductions (gfx950: wave = 64)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}

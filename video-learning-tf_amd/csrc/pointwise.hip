@@ -1,0 +1,654 @@
+// HBM-bound kernels of the LRCN path: input prep, LRN, max-pool, bias/column sums, LSTM gate
+// pointwise, temporal fusion, dropout, softmax cross-entropy, global-norm + SGD/Adam.
+// All activations NCHW fp32; lanes always walk the contiguous (w / hw / column) dimension.
+#include "common.h"
+
+static inline int grid_for(int64_t work, int threads, int cap) {
+    int64_t b = (work + threads - 1) / threads;
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+// ---- input prep (dataset_.py:481-501) ---------------------------------------------------------
+__global__ void input_prep_u8_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst, int n, int rh, int rw, int oh,
+                                     int ow, const int32_t* __restrict__ cy, const int32_t* __restrict__ cx,
+                                     const uint8_t* __restrict__ mir, const float* __restrict__ mean) {
+    const int64_t plane = (int64_t)oh * ow, total = plane * n;
+    const float m0 = mean ? mean[0] : 0.f, m1 = mean ? mean[1] : 0.f, m2 = mean ? mean[2] : 0.f;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int img = (int)(e / plane);
+        const int p = (int)(e - (int64_t)img * plane);
+        const int y = p / ow, x = p - y * ow;
+        const int sy = y + (cy ? cy[img] : 0);
+        const int sx = ((mir && mir[img]) ? ow - 1 - x : x) + (cx ? cx[img] : 0);
+        const uint8_t* s = src + (((int64_t)img * rh + sy) * rw + sx) * 3;
+        float* d = dst + (int64_t)img * 3 * plane + p;
+        d[0] = (float)s[0] - m0;
+        d[plane] = (float)s[1] - m1;
+        d[2 * plane] = (float)s[2] - m2;
+    }
+}
+
+extern "C" int vl_input_prep_u8(const uint8_t* src, float* dst, int n, int raw_h, int raw_w, int out_h, int out_w,
+                                const int32_t* crop_y, const int32_t* crop_x, const uint8_t* mirror, const float* mean_bgr,
+                                vl_stream_t stream) {
+    VL_CHECK(src && dst, "vl_input_prep_u8: null argument");
+    VL_CHECK(n > 0 && out_h > 0 && out_w > 0 && out_h <= raw_h && out_w <= raw_w, "vl_input_prep_u8: bad shape");
+    const int64_t total = (int64_t)n * out_h * out_w;
+    hipLaunchKernelGGL(input_prep_u8_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, (hipStream_t)stream, src, dst, n,
+                       raw_h, raw_w, out_h, out_w, crop_y, crop_x, mirror, mean_bgr);
+    VL_LAUNCH_CHECK();
+    return 0;
+}
+
+// generic 3-level strided copy: dst[(a*nb + b)*nc + c] = src[a*sa + b*sb + c*sc]
+__global__ void permute3_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t na, int nb, int nc, int64_t sa,
+                                int64_t sb, int64_t sc) {
+    const int64_t total = na * nb * nc;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e % nc);
+        const int b = (int)((e / nc) % nb);
+        const int64_t a = e / ((int64_t)nc * nb);
+        dst[e] = src[a * sa + b * sb + c * sc];
+    }
+}
+
+extern "C" int vl_nhwc_to_nchw(const float* src, float* dst, int n, int h, int w, int c, vl_stream_t stream) {
+    VL_CHECK(src && dst && n > 0 && h > 0 && w > 0 && c > 0, "vl_nhwc_to_nchw: bad argument");
+    const int64_t hw = (int64_t)h * w;
+    hipLaunchKernelGGL(permute3_kernel, dim3(grid_for(n * hw * c, 256, 8192)), dim3(256), 0, (hipStream_t)stream, src, dst,
+                       (int64_t)n, c, (int)hw, hw * c, (int64_t)1, (int64_t)c);
+    VL_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vl_nchw_to_nhwc(const float* src, float* dst, int n, int c, int h, int w, vl_stream_t stream) {
+    VL_CHECK(src && dst && n > 0 && h > 0 && w > 0 && c > 0, "vl_nchw_to_nhwc: bad argument");
+    const int64_t hw = (int64_t)h * w;
+    hipLaunchKernelGGL(permute3_kernel, dim3(grid_for(n * hw * c, 256, 8192)), dim3(256), 0, (hipStream_t)stream, src, dst,
+                       (int64_t)n, (int)hw, c, hw * c, (int64_t)1, hw);
+    VL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- LRN across channels (alexnet.py:79-89) ---------------------------------------------------
+// One thread = one (image, pixel) column x CH consecutive channels; lanes walk pixels, so every
+// load is a coalesced row of a channel plane.  The window lives in registers (static unroll).
+__device__ __forceinline__ float pow_neg(float v, float beta) {
+    // v >= bias > 0.  beta = 0.75 (the only value the reference uses) maps to two 1-ulp ops.
+    if (beta == 0.75f) {
+        const float r = __builtin_amdgcn_rsqf(v);
+        return r * __builtin_amdgcn_sqrtf(r);
+    }
+    return powf(v, -beta);
+}
+
+template <int CH, int R>
+__global__ void lrn_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int n, int C, int HW, float alpha, float beta,
+                               float bias) {
+    const int64_t pos = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos >= (int64_t)n * HW) return;
+    const int img = (int)(pos / HW);
+    const int p = (int)(pos - (int64_t)img * HW);
+    const int c0 = blockIdx.y * CH;
+    const float* xp = x + (int64_t)img * C * HW + p;
+    float* yp = y + (int64_t)img * C * HW + p;
+    float v[CH + 2 * R];
+#pragma unroll
+    for (int i = 0; i < CH + 2 * R; ++i) {
+        const int c = c0 - R + i;
+        v[i] = (c >= 0 && c < C) ? xp[(int64_t)c * HW] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        if (c0 + i < C) {
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d <= 2 * R; ++d) s += v[i + d] * v[i + d];
+            yp[(int64_t)(c0 + i) * HW] = v[i + R] * pow_neg(bias + alpha * s, beta);
+        }
+    }
+}
+
+template <int CH, int R>
+__global__ void lrn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, int n, int C,
+                               int HW, float alpha, float beta, float bias, int relu_fused) {
+    const int64_t pos = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos >= (int64_t)n * HW) return;
+    const int img = (int)(pos / HW);
+    const int p = (int)(pos - (int64_t)img * HW);
+    const int c0 = blockIdx.y * CH;
+    const int64_t off = (int64_t)img * C * HW + p;
+    const float* xp = x + off;
+    const float* gp = dy + off;
+    float xv[CH + 4 * R];  // channels c0-2R .. c0+CH+2R-1
+#pragma unroll
+    for (int i = 0; i < CH + 4 * R; ++i) {
+        const int c = c0 - 2 * R + i;
+        xv[i] = (c >= 0 && c < C) ? xp[(int64_t)c * HW] : 0.f;
+    }
+    float t[CH + 2 * R];  // dy_c * x_c * s_c^(-beta-1) for c0-R .. c0+CH+R-1
+    float u[CH];          // s_c^-beta for the owned channels
+#pragma unroll
+    for (int i = 0; i < CH + 2 * R; ++i) {
+        const int c = c0 - R + i;
+        float s = 0.f;
+#pragma unroll
+        for (int d = 0; d <= 2 * R; ++d) s += xv[i + d] * xv[i + d];
+        const float sc = bias + alpha * s;
+        const float pw = pow_neg(sc, beta);
+        const float g = (c >= 0 && c < C) ? gp[(int64_t)c * HW] : 0.f;
+        t[i] = g * xv[i + R] * pw / sc;
+        if (i >= R && i < CH + R) u[i - R] = g * pw;
+    }
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        if (c0 + i < C) {
+            float a = 0.f;
+#pragma unroll
+            for (int d = 0; d <= 2 * R; ++d) a += t[i + d];
+            const float xc = xv[i + 2 * R];
+            float r = u[i] - 2.f * alpha * beta * xc * a;
+            if (relu_fused) r = xc > 0.f ? r : 0.f;
+            dx[off + (int64_t)(c0 + i) * HW] = r;
+        }
+    }
+}
+
+extern "C" int vl_lrn_fwd(const float* x, float* y, int n, int c, int hw, int radius, float alpha, float beta, float bias,
+                          vl_stream_t stream) {
+    VL_CHECK(x && y && n > 0 && c > 0 && hw > 0, "vl_lrn_fwd: bad argument");
+    VL_CHECK(radius == 2, "vl_lrn_fwd: only depth_radius 2 is built (alexnet.py:81); got %d", radius);
+    constexpr int CH = 32;
+    dim3 grid(ceil_div((int64_t)n * hw, 256), ceil_div(c, CH));
+    hipLaunchKernelGGL((lrn_fwd_kernel<CH, 2>), grid, dim3(256), 0, (hipStream_t)stream, x, y, n, c, hw, alpha, beta, bias);
+    VL_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vl_lrn_bwd(const float* x, const float* dy, float* dx, int n, int c, int hw, int radius, float alpha, float beta,
+                          float bias, int relu_fused, vl_stream_t stream) {
+    VL_CHECK(x && dy && dx && n > 0 && c > 0 && hw > 0, "vl_lrn_bwd: bad argument");
+    VL_CHECK(radius == 2, "vl_lrn_bwd: only depth_radius 2 is built (alexnet.py:81); got %d", radius);
+    constexpr int CH = 16;
+    dim3 grid(ceil_div((int64_t)n * hw, 256), ceil_div(c, CH));
+    hipLaunchKernelGGL((lrn_bwd_kernel<CH, 2>), grid, dim3(256), 0, (hipStream_t)stream, x, dy, dx, n, c, hw, alpha, beta, bias,
+                       relu_fused);
+    VL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- max-pool VALID (alexnet.py:91-98) --------------------------------------------------------
+__global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, uint8_t* __restrict__ arg, int n, int C,
+                                   int H, int W, int OH, int OW, int k, int s, int64_t ysn, int64_t ysc, int64_t ysh,
+                                   int64_t ysw) {
+    const int64_t total = (int64_t)n * C * OH * OW;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int ow = (int)(e % OW);
+        const int oh = (int)((e / OW) % OH);
+        const int c = (int)((e / ((int64_t)OW * OH)) % C);
+        const int img = (int)(e / ((int64_t)OW * OH * C));
+        const float* xp = x + (((int64_t)img * C + c) * H + oh * s) * W + ow * s;
+        float best = -INFINITY;
+        int bi = 0;
+        for (int i = 0; i < k; ++i)
+            for (int j = 0; j < k; ++j) {
+                const float v = xp[i * W + j];
+                if (v > best) {  // strict: the first maximum in scan order wins
+                    best = v;
+                    bi = i * k + j;
+                }
+            }
+        const int64_t o = img * ysn + c * ysc + oh * ysh + ow * ysw;
+        y[o] = best;
+        if (arg) arg[o] = (uint8_t)bi;
+    }
+}
+
+__global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ arg, float* __restrict__ dx,
+                                   const float* __restrict__ mask, int n, int C, int H, int W, int OH, int OW, int k, int s,
+                                   int64_t ysn, int64_t ysc, int64_t ysh, int64_t ysw) {
+    const int64_t total = (int64_t)n * C * H * W;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int iw = (int)(e % W);
+        const int ih = (int)((e / W) % H);
+        const int c = (int)((e / ((int64_t)W * H)) % C);
+        const int img = (int)(e / ((int64_t)W * H * C));
+        float acc = 0.f;
+        if (!mask || mask[e] > 0.f) {
+            int oh_lo = (ih - k + s) / s;  // ceil((ih - k + 1) / s) for ih-k+1 >= 0
+            if (ih - k + 1 < 0) oh_lo = 0;
+            int ow_lo = (iw - k + s) / s;
+            if (iw - k + 1 < 0) ow_lo = 0;
+            const int oh_hi = min(ih / s, OH - 1), ow_hi = min(iw / s, OW - 1);
+            const int64_t base = img * ysn + c * ysc;
+            for (int oh = oh_lo; oh <= oh_hi; ++oh)
+                for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+                    const int64_t o = base + oh * ysh + ow * ysw;
+                    if ((int)arg[o] == (ih - oh * s) * k + (iw - ow * s)) acc += dy[o];
+                }
+        }
+        dx[e] = acc;
+    }
+}
+
+extern "C" int vl_maxpool_fwd(const float* x, float* y, uint8_t* argmax, int n, int c, int h, int w, int k, int s, int64_t ys_n,
+                              int64_t ys_c, int64_t ys_h, int64_t ys_w, vl_stream_t stream) {
+    VL_CHECK(x && y && n > 0 && c > 0 && k > 0 && s > 0 && h >= k && w >= k && k * k <= 255, "vl_maxpool_fwd: bad argument");
+    const int oh = (h - k) / s + 1, ow = (w - k) / s + 1;
+    const int64_t total = (int64_t)n * c * oh * ow;
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(total, 256, 16384)), dim3(256), 0, (hipStream_t)stream, x, y, argmax, n, c,
+                       h, w, oh, ow, k, s, ys_n, ys_c, ys_h, ys_w);
+    VL_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vl_maxpool_bwd(const float* dy, const uint8_t* argmax, float* dx, const float* relu_mask, int n, int c, int h,
+                              int w, int k, int s, int64_t ys_n, int64_t ys_c, int64_t ys_h, int64_t ys_w, vl_stream_t stream) {
+    VL_CHECK(dy && argmax && dx && n > 0 && c > 0 && k > 0 && s > 0 && h >= k && w >= k, "vl_maxpool_bwd: bad argument");
+    const int oh = (h - k) / s + 1, ow = (w - k) / s + 1;
+    const int64_t total = (int64_t)n * c * h * w;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total, 256, 16384)), dim3(256), 0, (hipStream_t)stream, dy, argmax, dx,
+                       relu_mask, n, c, h, w, oh, ow, k, s, ys_n, ys_c, ys_h, ys_w);
+    VL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- bias gradients ---------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum_256(float v, float* sm) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) sm[wv] = v;
+    __syncthreads();
+    const float r = sm[0] + sm[1] + sm[2] + sm[3];
+    __syncthreads();
+    return r;
+}
+
+// grid (C, S): block (c, s) sums channel c over images [s*per, (s+1)*per) -> ws[s*C + c]
+__global__ void bias_grad_stage1(const float* __restrict__ dy, float* __restrict__ ws, int n, int C, int HW, int per) {
+    __shared__ float sm[4];
+    const int c = blockIdx.x, s = blockIdx.y;
+    const int n0 = s * per, n1 = min(n, n0 + per);
+    float acc = 0.f;
+    for (int img = n0; img < n1; ++img) {
+        const float* p = dy + ((int64_t)img * C + c) * HW;
+        for (int i = threadIdx.x; i < HW; i += 256) acc += p[i];
+    }
+    acc = block_sum_256(acc, sm);
+    if (threadIdx.x == 0) ws[s * C + c] = acc;
+}
+
+__global__ void sum_partials_kernel(const float* __restrict__ ws, float* __restrict__ out, int count, int S) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= count) return;
+    float a = 0.f;
+    for (int s = 0; s < S; ++s) a += ws[(int64_t)s * count + c];
+    out[c] = a;
+}
+
+extern "C" int vl_bias_grad_nchw(const float* dy, float* db, float* ws, int n, int c, int hw, vl_stream_t stream) {
+    VL_CHECK(dy && db && ws && n > 0 && c > 0 && hw > 0, "vl_bias_grad_nchw: bad argument");
+    const int S = n < 64 ? n : 64;
+    const int per = ceil_div(n, S);
+    const int S2 = ceil_div(n, per);
+    hipLaunchKernelGGL(bias_grad_stage1, dim3(c, S2), dim3(256), 0, (hipStream_t)stream, dy, ws, n, c, hw, per);
+    VL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(ceil_div(c, 256)), dim3(256), 0, (hipStream_t)stream, ws, db, c, S2);
+    VL_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void colsum_stage1(const float* __restrict__ a, int64_t lda, float* __restrict__ ws, int m, int ncol, int per) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= ncol) return;
+    const int s = blockIdx.y;
+    const int r0 = s * per, r1 = min(m, r0 + per);
+    float acc = 0.f;
+    for (int r = r0; r < r1; ++r) acc += a[(int64_t)r * lda + j];
+    ws[(int64_t)s * ncol + j] = acc;
+}
+
+extern "C" int vl_colsum(const float* a, int64_t lda, float* out, float* ws, int m, int n, vl_stream_t stream) {
+    VL_CHECK(a && out && ws && m > 0 && n > 0 && lda >= n, "vl_colsum: bad argument");
+    const int S = m < 64 ? m : 64;
+    const int per = ceil_div(m, S);
+    const int S2 = ceil_div(m, per);
+    hipLaunchKernelGGL(colsum_stage1, dim3(ceil_div(n, 256), S2), dim3(256), 0, (hipStream_t)stream, a, lda, ws, m, n, per);
+    VL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, ws, out, n, S2);
+    VL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- LSTM gate pointwise (TF BasicLSTMCell; lstm.py:17) ---------------------------------------
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+__global__ void lstm_step_fwd_kernel(const float* __restrict__ gx, const float* __restrict__ gh, float* __restrict__ act,
+                                     float* __restrict__ cseq, float* __restrict__ hseq, float* __restrict__ hprev, int batch,
+                                     int T, int t, int H, float forget_bias) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= batch * H) return;
+    const int b = e / H, u = e - b * H;
+    const int64_t r = (int64_t)b * T + t;
+    const float* zx = gx + r * 4 * H;
+    float zi = zx[u], zj = zx[H + u], zf = zx[2 * H + u], zo = zx[3 * H + u];
+    if (gh) {
+        const float* zh = gh + (int64_t)b * 4 * H;
+        zi += zh[u];
+        zj += zh[H + u];
+        zf += zh[2 * H + u];
+        zo += zh[3 * H + u];
+    }
+    const float gi = sigmoidf_(zi), gj = tanhf(zj), gf = sigmoidf_(zf + forget_bias), go = sigmoidf_(zo);
+    const float cp = t > 0 ? cseq[(r - 1) * H + u] : 0.f;
+    const float hp = t > 0 ? hseq[(r - 1) * H + u] : 0.f;
+    const float c = cp * gf + gi * gj;
+    const float h = tanhf(c) * go;
+    float* a = act + r * 4 * H;
+    a[u] = gi;
+    a[H + u] = gj;
+    a[2 * H + u] = gf;
+    a[3 * H + u] = go;
+    cseq[r * H + u] = c;
+    hseq[r * H + u] = h;
+    hprev[r * H + u] = hp;
+}
+
+__global__ void lstm_step_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ dh_next,
+                                     const float* __restrict__ act, const float* __restrict__ cseq, float* __restrict__ dc,
+                                     float* __restrict__ dz, int batch, int T, int t, int H) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= batch * H) return;
+    const int b = e / H, u = e - b * H;
+    const int64_t r = (int64_t)b * T + t;
+    float dh = dout ? dout[r * H + u] : 0.f;
+    if (dh_next) dh += dh_next[(int64_t)b * H + u];
+    const float* a = act + r * 4 * H;
+    const float gi = a[u], gj = a[H + u], gf = a[2 * H + u], go = a[3 * H + u];
+    const float c = cseq[r * H + u];
+    const float cp = t > 0 ? cseq[(r - 1) * H + u] : 0.f;
+    const float tc = tanhf(c);
+    const float d_o = dh * tc;
+    const float dcv = dc[e] + dh * go * (1.f - tc * tc);
+    float* z = dz + r * 4 * H;
+    z[u] = dcv * gj * gi * (1.f - gi);
+    z[H + u] = dcv * gi * (1.f - gj * gj);
+    z[2 * H + u] = dcv * cp * gf * (1.f - gf);
+    z[3 * H + u] = d_o * go * (1.f - go);
+    dc[e] = dcv * gf;
+}
+
+extern "C" int vl_lstm_step_fwd(const float* gx, const float* gh, float* act, float* cseq, float* hseq, float* hprev, int batch,
+                                int T, int t, int H, float forget_bias, vl_stream_t stream) {
+    VL_CHECK(gx && act && cseq && hseq && hprev, "vl_lstm_step_fwd: null argument");
+    VL_CHECK(batch > 0 && H > 0 && T > 0 && t >= 0 && t < T, "vl_lstm_step_fwd: bad shape");
+    VL_CHECK(gh || t == 0, "vl_lstm_step_fwd: gh required for t > 0");
+    hipLaunchKernelGGL(lstm_step_fwd_kernel, dim3(ceil_div((int64_t)batch * H, 256)), dim3(256), 0, (hipStream_t)stream, gx, gh,
+                       act, cseq, hseq, hprev, batch, T, t, H, forget_bias);
+    VL_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vl_lstm_step_bwd(const float* dout, const float* dh_next, const float* act, const float* cseq, float* dc,
+                                float* dz, int batch, int T, int t, int H, vl_stream_t stream) {
+    VL_CHECK(act && cseq && dc && dz, "vl_lstm_step_bwd: null argument");
+    VL_CHECK(batch > 0 && H > 0 && T > 0 && t >= 0 && t < T, "vl_lstm_step_bwd: bad shape");
+    hipLaunchKernelGGL(lstm_step_bwd_kernel, dim3(ceil_div((int64_t)batch * H, 256)), dim3(256), 0, (hipStream_t)stream, dout,
+                       dh_next, act, cseq, dc, dz, batch, T, t, H);
+    VL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- temporal fusion (tf_util.py:4-30) --------------------------------------------------------
+__global__ void temporal_fusion_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int batch, int T, int H,
+                                           int method) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= batch * H) return;
+    const int b = e / H, u = e - b * H;
+    const float* p = x + (int64_t)b * T * H + u;
+    if (method == 1) {
+        y[e] = p[(int64_t)(T - 1) * H];
+    } else {
+        float a = 0.f;
+        for (int t = 0; t < T; ++t) a += p[(int64_t)t * H];
+        y[e] = a / (float)T;
+    }
+}
+
+__global__ void temporal_fusion_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int batch, int T, int H,
+                                           int method) {
+    const int64_t total = (int64_t)batch * T * H;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int u = (int)(e % H);
+        const int t = (int)((e / H) % T);
+        const int b = (int)(e / ((int64_t)H * T));
+        const float g = dy[(int64_t)b * H + u];
+        dx[e] = method == 1 ? (t == T - 1 ? g : 0.f) : g / (float)T;
+    }
+}
+
+extern "C" int vl_temporal_fusion_fwd(const float* x, float* y, int batch, int T, int H, int method, vl_stream_t stream) {
+    VL_CHECK(x && y && batch > 0 && T > 0 && H > 0 && (method == 0 || method == 1), "vl_temporal_fusion_fwd: bad argument");
+    hipLaunchKernelGGL(temporal_fusion_fwd_kernel, dim3(ceil_div((int64_t)batch * H, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       y, batch, T, H, method);
+    VL_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vl_temporal_fusion_bwd(const float* dy, float* dx, int batch, int T, int H, int method, vl_stream_t stream) {
+    VL_CHECK(dy && dx && batch > 0 && T > 0 && H > 0 && (method == 0 || method == 1), "vl_temporal_fusion_bwd: bad argument");
+    hipLaunchKernelGGL(temporal_fusion_bwd_kernel, dim3(grid_for((int64_t)batch * T * H, 256, 4096)), dim3(256), 0,
+                       (hipStream_t)stream, dy, dx, batch, T, H, method);
+    VL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- dropout (lstm.py:50-56) ------------------------------------------------------------------
+__device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ void dropout_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, uint8_t* __restrict__ mask, int64_t count,
+                                   float keep, uint64_t seed) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t h = splitmix64(seed ^ splitmix64((uint64_t)e));
+        const float uni = (float)(h >> 40) * (1.0f / 16777216.0f);
+        const uint8_t m = uni < keep ? 1 : 0;
+        mask[e] = m;
+        y[e] = m ? x[e] / keep : 0.f;
+    }
+}
+
+__global__ void dropout_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ mask, float* __restrict__ dx,
+                                   int64_t count, float keep) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (int64_t)gridDim.x * blockDim.x)
+        dx[e] = mask[e] ? dy[e] / keep : 0.f;
+}
+
+extern "C" int vl_dropout_fwd(const float* x, float* y, uint8_t* mask, int64_t count, float keep, uint64_t seed,
+                              vl_stream_t stream) {
+    VL_CHECK(x && y && mask && count > 0 && keep > 0.f && keep <= 1.f, "vl_dropout_fwd: bad argument");
+    hipLaunchKernelGGL(dropout_fwd_kernel, dim3(grid_for(count, 256, 4096)), dim3(256), 0, (hipStream_t)stream, x, y, mask, count,
+                       keep, seed);
+    VL_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vl_dropout_bwd(const float* dy, const uint8_t* mask, float* dx, int64_t count, float keep, vl_stream_t stream) {
+    VL_CHECK(dy && dx && mask && count > 0 && keep > 0.f && keep <= 1.f, "vl_dropout_bwd: bad argument");
+    hipLaunchKernelGGL(dropout_bwd_kernel, dim3(grid_for(count, 256, 4096)), dim3(256), 0, (hipStream_t)stream, dy, mask, dx, count,
+                       keep);
+    VL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- softmax cross-entropy, mean over the batch (train.py:120-123) + accuracy (142-149) --------
+// One workgroup; wave w takes rows w, w+4, ...; fixed summation order -> bitwise reproducible.
+__global__ void softmax_xent_kernel(const float* __restrict__ logits, const int32_t* __restrict__ labels,
+                                    float* __restrict__ dlogits, float* __restrict__ stats, int batch, int C, float gscale) {
+    __shared__ float sl[4], sc[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float loss_acc = 0.f, corr_acc = 0.f;
+    for (int b = wv; b < batch; b += 4) {
+        const float* z = logits + (int64_t)b * C;
+        const int32_t* y = labels + (int64_t)b * C;
+        float mx = -INFINITY;
+        int am = 0x7fffffff;
+        for (int c = lane; c < C; c += 64) {
+            const float v = z[c];
+            if (v > mx) {
+                mx = v;
+                am = c;
+            }
+        }
+        const float gmx = wave_max(mx);
+        // first index attaining the maximum
+        int cand = (mx == gmx) ? am : 0x7fffffff;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o, 64));
+        float se = 0.f;
+        for (int c = lane; c < C; c += 64) se += expf(z[c] - gmx);
+        se = wave_sum(se);
+        const float lse = logf(se) + gmx;
+        float l = 0.f;
+        int ymax = -2147483647 - 1, yarg = 0x7fffffff;
+        for (int c = lane; c < C; c += 64) {
+            const int yv = y[c];
+            l += (float)yv * (lse - z[c]);
+            if (yv > ymax) {
+                ymax = yv;
+                yarg = c;
+            }
+            if (dlogits) dlogits[(int64_t)b * C + c] = (expf(z[c] - lse) - (float)yv) * gscale;
+        }
+        l = wave_sum(l);
+        int gy = ymax;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) gy = max(gy, __shfl_xor(gy, o, 64));
+        int ycand = (ymax == gy) ? yarg : 0x7fffffff;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ycand = min(ycand, __shfl_xor(ycand, o, 64));
+        loss_acc += l;
+        corr_acc += (cand == ycand) ? 1.f : 0.f;
+    }
+    if (lane == 0) {
+        sl[wv] = loss_acc;
+        sc[wv] = corr_acc;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        stats[0] += sl[0] + sl[1] + sl[2] + sl[3];
+        stats[1] += sc[0] + sc[1] + sc[2] + sc[3];
+    }
+}
+
+extern "C" int vl_softmax_xent(const float* logits, const int32_t* labels, float* dlogits, float* stats, int batch, int classes,
+                               float grad_scale, vl_stream_t stream) {
+    VL_CHECK(logits && labels && stats && batch > 0 && classes > 0, "vl_softmax_xent: bad argument");
+    hipLaunchKernelGGL(softmax_xent_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, labels, dlogits, stats, batch,
+                       classes, grad_scale);
+    VL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- global norm + SGD / Adam (train.py:199-222) ----------------------------------------------
+__global__ void sumsq_stage1(const float* __restrict__ g, int64_t count, float* __restrict__ ws) {
+    __shared__ float sm[4];
+    float acc = 0.f;
+    const int64_t nvec = count / 4;
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    const bool aligned = ((uintptr_t)g & 15) == 0;
+    if (aligned) {
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+            const float4 v = g4[i];
+            acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        }
+        for (int64_t i = nvec * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
+            acc += g[i] * g[i];
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
+            acc += g[i] * g[i];
+    }
+    acc = block_sum_256(acc, sm);
+    if (threadIdx.x == 0) ws[blockIdx.x] = acc;
+}
+
+__global__ void sumsq_stage2(const float* __restrict__ ws, int nblocks, float* __restrict__ out, int accumulate) {
+    __shared__ float sm[4];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < nblocks; i += 256) acc += ws[i];
+    acc = block_sum_256(acc, sm);
+    if (threadIdx.x == 0) out[0] = accumulate ? out[0] + acc : acc;
+}
+
+extern "C" int vl_sumsq(const float* g, int64_t count, float* out, float* ws, int accumulate, vl_stream_t stream) {
+    VL_CHECK(g && out && ws && count > 0, "vl_sumsq: bad argument");
+    const int blocks = grid_for(count / 4 + 1, 256, 1024);
+    hipLaunchKernelGGL(sumsq_stage1, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, count, ws);
+    VL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sumsq_stage2, dim3(1), dim3(256), 0, (hipStream_t)stream, ws, blocks, out, accumulate);
+    VL_LAUNCH_CHECK();
+    return 0;
+}
+
+__device__ __forceinline__ float clip_scale(float clip_norm, const float* sumsq, float gscale) {
+    if (clip_norm <= 0.f || !sumsq) return gscale;
+    const float norm = gscale * sqrtf(sumsq[0]);
+    return gscale * clip_norm / fmaxf(norm, clip_norm);
+}
+
+__global__ void sgd_apply_kernel(float* __restrict__ w, const float* __restrict__ g, int64_t count, float lr, float clip_norm,
+                                 const float* __restrict__ sumsq, float gscale) {
+    const float a = lr * clip_scale(clip_norm, sumsq, gscale);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
+        w[i] -= a * g[i];
+}
+
+__global__ void adam_apply_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                  int64_t count, float lr_t, float clip_norm, const float* __restrict__ sumsq, float gscale) {
+    const float sc = clip_scale(clip_norm, sumsq, gscale);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gi = g[i] * sc;
+        const float mi = 0.9f * m[i] + 0.1f * gi;
+        const float vi = 0.999f * v[i] + 0.001f * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        w[i] -= lr_t * mi / (sqrtf(vi) + 1e-8f);
+    }
+}
+
+extern "C" int vl_sgd_apply(float* w, const float* g, int64_t count, float lr, float clip_norm, const float* sumsq, float gscale,
+                            vl_stream_t stream) {
+    VL_CHECK(w && g && count > 0, "vl_sgd_apply: bad argument");
+    hipLaunchKernelGGL(sgd_apply_kernel, dim3(grid_for(count, 256, 4096)), dim3(256), 0, (hipStream_t)stream, w, g, count, lr,
+                       clip_norm, sumsq, gscale);
+    VL_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vl_adam_apply(float* w, const float* g, float* m, float* v, int64_t count, float lr, float clip_norm,
+                             const float* sumsq, float gscale, int step, vl_stream_t stream) {
+    VL_CHECK(w && g && m && v && count > 0 && step >= 1, "vl_adam_apply: bad argument");
+    const double b1t = 1.0 - pow(0.9, (double)step), b2t = 1.0 - pow(0.999, (double)step);
+    const float lr_t = (float)(lr * sqrt(b2t) / b1t);
+    hipLaunchKernelGGL(adam_apply_kernel, dim3(grid_for(count, 256, 4096)), dim3(256), 0, (hipStream_t)stream, w, g, m, v, count,
+                       lr_t, clip_norm, sumsq, gscale);
+    VL_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void fill_kernel(float* __restrict__ p, int64_t count, float value) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) p[i] = value;
+}
+
+extern "C" int vl_fill(float* p, int64_t count, float value, vl_stream_t stream) {
+    VL_CHECK(p && count > 0, "vl_fill: bad argument");
+    hipLaunchKernelGGL(fill_kernel, dim3(grid_for(count, 256, 4096)), dim3(256), 0, (hipStream_t)stream, p, count, value);
+    VL_LAUNCH_CHECK();
+    return 0;
+}

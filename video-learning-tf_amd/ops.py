@@ -1,0 +1,236 @@
+"""Thin torch-tensor wrappers over the C-ABI (include/vltf.h).  Tensors are device allocations
+only: every wrapper passes ``data_ptr()`` and the current HIP stream; no torch math runs here."""
+import ctypes as C
+
+import torch
+
+from . import _ffi
+
+F32 = torch.float32
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _f32(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not (t.is_cuda and t.dtype == F32):
+            raise _ffi.VltfError("expected a CUDA/HIP float32 tensor, got %s on %s" % (t.dtype, t.device))
+
+
+def _dense(*ts):
+    for t in ts:
+        if t is not None and not t.is_contiguous():
+            raise _ffi.VltfError("expected a contiguous tensor")
+
+
+# ---- input ---------------------------------------------------------------------------------------
+def input_prep_u8(src, dst, crop_y=None, crop_x=None, mirror=None, mean_bgr=None):
+    """src uint8 [n, raw_h, raw_w, 3] (HWC, BGR) -> dst f32 [n, 3, out_h, out_w] (dataset_.py:481-501)."""
+    if src.dtype != torch.uint8 or not src.is_cuda:
+        raise _ffi.VltfError("input_prep_u8: src must be a device uint8 tensor")
+    _f32(dst, mean_bgr)
+    _dense(src, dst, crop_y, crop_x, mirror, mean_bgr)
+    n, rh, rw, c = src.shape
+    if c != 3 or dst.shape[0] != n or dst.shape[1] != 3:
+        raise _ffi.VltfError("input_prep_u8: shape mismatch %s -> %s" % (tuple(src.shape), tuple(dst.shape)))
+    _ffi.call("vl_input_prep_u8", _p(src), _p(dst), n, rh, rw, dst.shape[2], dst.shape[3], _p(crop_y), _p(crop_x),
+              _p(mirror), _p(mean_bgr), stream())
+
+
+def nhwc_to_nchw(src, dst):
+    _f32(src, dst); _dense(src, dst)
+    n, h, w, c = src.shape
+    _ffi.call("vl_nhwc_to_nchw", _p(src), _p(dst), n, h, w, c, stream())
+
+
+def nchw_to_nhwc(src, dst):
+    _f32(src, dst); _dense(src, dst)
+    n, c, h, w = src.shape
+    _ffi.call("vl_nchw_to_nhwc", _p(src), _p(dst), n, c, h, w, stream())
+
+
+# ---- convolution ---------------------------------------------------------------------------------
+class Conv:
+    """Descriptor for one dcnn.conv layer (alexnet.py:15-31): TF 'SAME' conv per group."""
+
+    def __init__(self, cin, h, w, cout, kh, kw, stride, groups):
+        self.cin, self.h, self.w, self.cout = cin, h, w, cout
+        self.kh, self.kw, self.stride, self.groups = kh, kw, stride, groups
+        self._d = C.c_void_p()
+        _ffi.check(_ffi.lib().vl_conv_create(C.byref(self._d), cin, h, w, cout, kh, kw, stride, groups), "vl_conv_create")
+        oh, ow = C.c_int(), C.c_int()
+        _ffi.check(_ffi.lib().vl_conv_out_hw(self._d, C.byref(oh), C.byref(ow)), "vl_conv_out_hw")
+        self.oh, self.ow = oh.value, ow.value
+        self.w_shape = (kh, kw, cin // groups, cout)
+
+    def __del__(self):
+        try:
+            if self._d:
+                _ffi.lib().vl_conv_destroy(self._d)
+                self._d = None
+        except Exception:
+            pass
+
+    def fwd(self, x, w, bias, y, relu=True):
+        _f32(x, w, bias, y); _dense(x, w, bias, y)
+        n = x.shape[0]
+        if tuple(x.shape[1:]) != (self.cin, self.h, self.w) or tuple(y.shape) != (n, self.cout, self.oh, self.ow):
+            raise _ffi.VltfError("conv.fwd: shape mismatch x=%s y=%s" % (tuple(x.shape), tuple(y.shape)))
+        _ffi.call("vl_conv_fwd", self._d, _p(x), _p(w), _p(bias), _p(y), n, int(relu), stream())
+
+    def wt_transpose(self, w, wt):
+        _f32(w, wt); _dense(w, wt)
+        _ffi.call("vl_conv_wt_transpose", self._d, _p(w), _p(wt), stream())
+
+    def dgrad(self, dy, wt, dx, relu_mask=None):
+        _f32(dy, wt, dx, relu_mask); _dense(dy, wt, dx, relu_mask)
+        _ffi.call("vl_conv_dgrad", self._d, _p(dy), _p(wt), _p(dx), _p(relu_mask), dy.shape[0], stream())
+
+    def wgrad_ws_bytes(self, n):
+        return int(_ffi.lib().vl_conv_wgrad_ws_bytes(self._d, n))
+
+    def wgrad(self, x, dy, dw, ws):
+        _f32(x, dy, dw); _dense(x, dy, dw, ws)
+        nbytes = 0 if ws is None else ws.numel() * ws.element_size()
+        _ffi.call("vl_conv_wgrad", self._d, _p(x), _p(dy), _p(dw), _p(ws), nbytes, x.shape[0], stream())
+
+
+def bias_grad_nchw(dy, db, ws):
+    _f32(dy, db, ws); _dense(dy, db, ws)
+    n, c = dy.shape[0], dy.shape[1]
+    hw = dy.numel() // (n * c)
+    if ws.numel() < 64 * c:
+        raise _ffi.VltfError("bias_grad_nchw: workspace needs 64*c floats")
+    _ffi.call("vl_bias_grad_nchw", _p(dy), _p(db), _p(ws), n, c, hw, stream())
+
+
+# ---- LRN / pool ----------------------------------------------------------------------------------
+def lrn_fwd(x, y, radius=2, alpha=2e-5, beta=0.75, bias=1.0):
+    _f32(x, y); _dense(x, y)
+    n, c = x.shape[0], x.shape[1]
+    _ffi.call("vl_lrn_fwd", _p(x), _p(y), n, c, x.numel() // (n * c), radius, alpha, beta, bias, stream())
+
+
+def lrn_bwd(x, dy, dx, radius=2, alpha=2e-5, beta=0.75, bias=1.0, relu_fused=False):
+    _f32(x, dy, dx); _dense(x, dy, dx)
+    n, c = x.shape[0], x.shape[1]
+    _ffi.call("vl_lrn_bwd", _p(x), _p(dy), _p(dx), n, c, x.numel() // (n * c), radius, alpha, beta, bias, int(relu_fused),
+              stream())
+
+
+def pool_out(h, k=3, s=2):
+    return (h - k) // s + 1
+
+
+def _pool_strides(c, oh, ow, hwc):
+    # NCHW, or the (h, w, c)-flat order fc6 expects (alexnet.py:228)
+    return (oh * ow * c, 1, ow * c, c) if hwc else (c * oh * ow, oh * ow, ow, 1)
+
+
+def maxpool_fwd(x, y, argmax, k=3, s=2, hwc=False):
+    _f32(x, y); _dense(x, y, argmax)
+    n, c, h, w = x.shape
+    st = _pool_strides(c, pool_out(h, k, s), pool_out(w, k, s), hwc)
+    _ffi.call("vl_maxpool_fwd", _p(x), _p(y), _p(argmax), n, c, h, w, k, s, st[0], st[1], st[2], st[3], stream())
+
+
+def maxpool_bwd(dy, argmax, dx, relu_mask=None, k=3, s=2, hwc=False):
+    _f32(dy, dx, relu_mask); _dense(dy, dx, argmax, relu_mask)
+    n, c, h, w = dx.shape
+    st = _pool_strides(c, pool_out(h, k, s), pool_out(w, k, s), hwc)
+    _ffi.call("vl_maxpool_bwd", _p(dy), _p(argmax), _p(dx), _p(relu_mask), n, c, h, w, k, s, st[0], st[1], st[2], st[3],
+              stream())
+
+
+# ---- dense ---------------------------------------------------------------------------------------
+def gemm(a, b, c, m, n, k, transa=False, transb=False, lda=None, ldb=None, ldc=None, bias=None, relu=False,
+         relu_mask=None, ws=None):
+    """c[m,n] = op(a) @ op(b) (+bias) (relu) (mask).  a/b/c may be views: only data_ptr + ld are used."""
+    _f32(a, b, c, bias, relu_mask)
+    lda = lda if lda is not None else (m if transa else k)
+    ldb = ldb if ldb is not None else (k if transb else n)
+    ldc = ldc if ldc is not None else n
+    nbytes = 0 if ws is None else ws.numel() * ws.element_size()
+    _ffi.call("vl_gemm", int(transa), int(transb), m, n, k, _p(a), lda, _p(b), ldb, _p(c), ldc, _p(bias), int(relu),
+              _p(relu_mask), _p(ws), nbytes, stream())
+
+
+def colsum(a, out, ws, m, n, lda=None):
+    _f32(a, out, ws)
+    if ws.numel() < 64 * n:
+        raise _ffi.VltfError("colsum: workspace needs 64*n floats")
+    _ffi.call("vl_colsum", _p(a), lda if lda is not None else n, _p(out), _p(ws), m, n, stream())
+
+
+# ---- LSTM ----------------------------------------------------------------------------------------
+def lstm_step_fwd(gx, gh, act, cseq, hseq, hprev, batch, T, t, H, forget_bias=1.0):
+    _f32(gx, gh, act, cseq, hseq, hprev)
+    _ffi.call("vl_lstm_step_fwd", _p(gx), _p(gh), _p(act), _p(cseq), _p(hseq), _p(hprev), batch, T, t, H, forget_bias,
+              stream())
+
+
+def lstm_step_bwd(dout, dh_next, act, cseq, dc, dz, batch, T, t, H):
+    _f32(dout, dh_next, act, cseq, dc, dz)
+    _ffi.call("vl_lstm_step_bwd", _p(dout), _p(dh_next), _p(act), _p(cseq), _p(dc), _p(dz), batch, T, t, H, stream())
+
+
+FUSION_CODE = {"avg": 0, "last": 1}
+
+
+def temporal_fusion_fwd(x, y, batch, T, H, method):
+    _f32(x, y)
+    _ffi.call("vl_temporal_fusion_fwd", _p(x), _p(y), batch, T, H, FUSION_CODE[method], stream())
+
+
+def temporal_fusion_bwd(dy, dx, batch, T, H, method):
+    _f32(dy, dx)
+    _ffi.call("vl_temporal_fusion_bwd", _p(dy), _p(dx), batch, T, H, FUSION_CODE[method], stream())
+
+
+def dropout_fwd(x, y, mask, keep, seed):
+    _f32(x, y)
+    _ffi.call("vl_dropout_fwd", _p(x), _p(y), _p(mask), x.numel(), keep, seed, stream())
+
+
+def dropout_bwd(dy, mask, dx, keep):
+    _f32(dy, dx)
+    _ffi.call("vl_dropout_bwd", _p(dy), _p(mask), _p(dx), dy.numel(), keep, stream())
+
+
+# ---- loss / optimizer ----------------------------------------------------------------------------
+def softmax_xent(logits, labels, dlogits, stats, grad_scale):
+    _f32(logits, dlogits, stats); _dense(logits, labels, dlogits)
+    if labels.dtype != torch.int32:
+        raise _ffi.VltfError("softmax_xent: labels must be int32 one-hot")
+    b, c = logits.shape
+    _ffi.call("vl_softmax_xent", _p(logits), _p(labels), _p(dlogits), _p(stats), b, c, grad_scale, stream())
+
+
+def sumsq(g, out, ws, accumulate=False):
+    _f32(g, out, ws)
+    if ws.numel() < 1024:
+        raise _ffi.VltfError("sumsq: workspace needs 1024 floats")
+    _ffi.call("vl_sumsq", _p(g), g.numel(), _p(out), _p(ws), int(accumulate), stream())
+
+
+def sgd_apply(w, g, lr, clip_norm=0.0, sumsq_t=None, gscale=1.0):
+    _f32(w, g, sumsq_t)
+    _ffi.call("vl_sgd_apply", _p(w), _p(g), w.numel(), lr, clip_norm, _p(sumsq_t), gscale, stream())
+
+
+def adam_apply(w, g, m, v, lr, step, clip_norm=0.0, sumsq_t=None, gscale=1.0):
+    _f32(w, g, m, v, sumsq_t)
+    _ffi.call("vl_adam_apply", _p(w), _p(g), _p(m), _p(v), w.numel(), lr, clip_norm, _p(sumsq_t), gscale, step, stream())
+
+
+def fill(t, value):
+    _f32(t)
+    _ffi.call("vl_fill", _p(t), t.numel(), value, stream())
