@@ -192,7 +192,8 @@ def xw_plus_b(x, w, b, dtype=F64):
 
 
 def sigmoid(x):
-    return 1.0 / (1.0 + np.exp(-x))
+    e = np.exp(-np.abs(x))
+    return np.where(x >= 0, 1.0 / (1.0 + e), e / (1.0 + e))
 
 
 # ----------------------------------------------------------------------------------------------

@@ -61,6 +61,13 @@ def lib():
             raise VltfError("libvltf_hip.so not found at %s -- build it with "
                             "`python -c 'import __graft_entry__ as g; g.build()'` "
                             "(there is no CPU fallback)" % LIB_PATH)
+        # ONE HIP runtime per process: torch bundles its own libamdhip64.so (soname libamdhip64.so.7, the
+        # same as /opt/rocm's).  Loading torch first makes our NEEDED entry resolve to that copy; the other
+        # order would put two runtimes in the process and device pointers would not be shared.
+        import torch  # noqa: F401
+        tl = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+        if os.path.exists(tl):
+            C.CDLL(tl, mode=C.RTLD_GLOBAL)
         try:
             l = C.CDLL(LIB_PATH)
         except OSError as ex:

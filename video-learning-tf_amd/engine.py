@@ -1,0 +1,505 @@
+"""LRCNEngine: the two executor calls of the reference, on MI355X.
+
+The reference assembles a TF graph once (models/model.py:18-155: dcnn representation ->
+lstm | fc classifier -> logits; train.py:112-222: loss, clip, SGD) and then calls
+  sess.run([summaries, loss, lr, global_step, optimizer], fdict)      run_task.py:44   -> train_step_*
+  sess.run(model.logits, fdict)                                       run_task.py:95   -> forward_*
+This class is that graph: a fixed plan of C-ABI kernel launches (vltf_amd.ops) over buffers
+allocated once.  torch tensors are device memory only; no torch math runs on the data path.
+
+Activations are NCHW; parameters keep the reference's layouts and TF variable names
+(SURVEY.md section 5), stored in one flat fp32 buffer (and one flat gradient buffer) ordered
+classifier -> fc -> conv5..conv1, i.e. the order backward produces gradients, so the
+data-parallel all-reduce of the first (large: fc6 = 85 % of bytes) bucket overlaps the conv backward.
+"""
+import math
+from dataclasses import dataclass, field
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import ops
+from ._ffi import VltfError
+
+# name, kh, kw, cout, stride, groups, lrn, pool        (alexnet.py:60-211)
+CONV_LAYERS = (
+    ("conv1", 11, 11, 96, 4, 1, True, True),
+    ("conv2", 5, 5, 256, 1, 2, True, True),
+    ("conv3", 3, 3, 384, 1, 1, False, False),
+    ("conv4", 3, 3, 384, 1, 2, False, False),
+    ("conv5", 3, 3, 256, 1, 2, False, True),
+)
+FC_DIM = 4096
+FORGET_BIAS = 1.0        # BasicLSTMCell default (lstm.py:17)
+LRN = dict(radius=2, alpha=2e-5, beta=0.75, bias=1.0)     # alexnet.py:81-84
+
+
+@dataclass
+class NetConfig:
+    """The subset of the `network:` / `train:` YAML keys (settings_.py:167-289) that shapes the graph."""
+    image_shape: Tuple[int, int, int] = (227, 227, 3)
+    num_classes: int = 101
+    fpc: int = 16                               # frames per clip (from the .size file, dataset_.py:728)
+    frame_encoding_layer: str = "fc6"           # alexnet.py:233-275: "fc6" | "fc7" | anything else -> fc8
+    classifier: str = "lstm"                    # defs.classifier.{lstm, fc}
+    lstm_hidden: int = 256
+    lstm_layers: int = 1
+    fusion: str = "avg"                         # lstm_params[2]: defs.fusion_method.{avg, last}
+    frame_fusion: Optional[Tuple[str, str]] = None   # classifier fc: (early|late, avg|last) (model.py:103-106,149-151)
+    dropout_keep_prob: float = 0.0              # <= 0 disables (lstm.py:52)
+    optimizer: str = "sgd"                      # defs.optim.{sgd, adam}
+
+    def encode_dim(self):
+        return FC_DIM if self.frame_encoding_layer in ("fc6", "fc7") else self.num_classes
+
+
+def tf_same_out(n, s):
+    return -(-n // s)
+
+
+def param_specs(cfg: NetConfig):
+    """[(tf_variable_name, shape)] in flat-buffer order (classifier, fc8..fc6, conv5..conv1)."""
+    h, w, c = cfg.image_shape
+    convs = []
+    for name, kh, kw, co, s, g, _, pool in CONV_LAYERS:
+        convs.append([("dcnn/%sW" % name, (kh, kw, c // g, co)), ("dcnn/%sb" % name, (co,))])
+        h, w, c = tf_same_out(h, s), tf_same_out(w, s), co
+        if pool:
+            h, w = ops.pool_out(h), ops.pool_out(w)
+    specs = []
+    dim = cfg.encode_dim()
+    if cfg.classifier == "lstm":
+        if cfg.lstm_hidden != cfg.num_classes:
+            specs += [("output_fc_w", (cfg.lstm_hidden, cfg.num_classes)), ("output_fc_b", (cfg.num_classes,))]
+        d = dim
+        for l in range(cfg.lstm_layers):
+            pre = "rnn/multi_rnn_cell/cell_%d/basic_lstm_cell/" % l
+            specs += [(pre + "kernel", (d + cfg.lstm_hidden, 4 * cfg.lstm_hidden)), (pre + "bias", (4 * cfg.lstm_hidden,))]
+            d = cfg.lstm_hidden
+    elif cfg.classifier == "fc":
+        if dim != cfg.num_classes:
+            specs += [("fc_convert_w", (dim, cfg.num_classes)), ("fc_convert_b", (cfg.num_classes,))]
+    else:
+        raise VltfError("Undefined classifier [%s]" % cfg.classifier)
+    if cfg.frame_encoding_layer not in ("fc6", "fc7"):
+        specs += [("dcnn/fc8W", (FC_DIM, cfg.num_classes)), ("dcnn/fc8b", (cfg.num_classes,))]
+    if cfg.frame_encoding_layer != "fc6":
+        specs += [("dcnn/fc7W", (FC_DIM, FC_DIM)), ("dcnn/fc7b", (FC_DIM,))]
+    specs += [("dcnn/fc6W", (h * w * c, FC_DIM)), ("dcnn/fc6b", (FC_DIM,))]
+    for pair in reversed(convs):
+        specs += pair
+    return specs
+
+
+def init_params(cfg: NetConfig, seed=0, stddev=0.05, well_scaled=False):
+    """Reference initialisers: W ~ truncated_normal(sigma=0.05) re-drawn beyond 2 sigma, b = 0.1
+    (alexnet.py:40-46, tf_util.py:44-45); LSTM kernel glorot-uniform, bias 0 (TF defaults).
+    well_scaled uses sigma = sqrt(2/fan_in) instead so activations stay O(1)."""
+    rng = np.random.default_rng(seed)
+    out = {}
+    for name, shp in param_specs(cfg):
+        if name.endswith("kernel"):
+            lim = math.sqrt(6.0 / (shp[0] + shp[1]))
+            out[name] = rng.uniform(-lim, lim, shp).astype(np.float32)
+        elif name.endswith("bias"):
+            out[name] = np.zeros(shp, np.float32)
+        elif len(shp) > 1:
+            sd = math.sqrt(2.0 / int(np.prod(shp[:-1]))) if well_scaled else stddev
+            v = rng.standard_normal(shp)
+            bad = np.abs(v) > 2.0
+            while bad.any():
+                v[bad] = rng.standard_normal(int(bad.sum()))
+                bad = np.abs(v) > 2.0
+            out[name] = (v * sd).astype(np.float32)
+        else:
+            out[name] = np.full(shp, 0.1, np.float32)
+    return out
+
+
+class LRCNEngine:
+    def __init__(self, cfg: NetConfig, max_clips: int, device="cuda:0", training=True, dp=None):
+        if not torch.cuda.is_available():
+            raise VltfError("LRCNEngine needs a HIP device; there is no CPU fallback")
+        self.cfg, self.B, self.T = cfg, max_clips, cfg.fpc
+        self.N = max_clips * cfg.fpc
+        self.dev = torch.device(device)
+        self.training = training
+        self.dp = dp
+        self.step_count = 0
+        torch.cuda.set_device(self.dev)
+        N, dev = self.N, self.dev
+
+        def buf(*shape, dtype=torch.float32):
+            return torch.empty(shape, dtype=dtype, device=dev)
+
+        # ---- parameters: flat buffers + named views
+        self.specs = param_specs(cfg)
+        total = sum(int(np.prod(s)) for _, s in self.specs)
+        self.w = torch.zeros(total, device=dev)
+        self.g = torch.zeros(total, device=dev) if training else None
+        self.P, self.G, self.offsets = {}, {}, {}
+        off = 0
+        for name, shp in self.specs:
+            n = int(np.prod(shp))
+            self.P[name] = self.w[off:off + n].view(shp)
+            if training:
+                self.G[name] = self.g[off:off + n].view(shp)
+            self.offsets[name] = (off, n)
+            off += n
+        first_conv = self.offsets["dcnn/conv5W"][0]
+        self.buckets = [(0, first_conv), (first_conv, total - first_conv)]   # [classifier+fc | convs]
+        if cfg.optimizer == "adam" and training:
+            self.adam_m, self.adam_v = torch.zeros(total, device=dev), torch.zeros(total, device=dev)
+
+        # ---- conv stack plan
+        h, w, c = cfg.image_shape
+        self.x0 = buf(N, c, h, w)
+        self.layers = []
+        max_w = 0
+        ws_bytes = 4
+        for name, kh, kw, co, s, g, lrn, pool in CONV_LAYERS:
+            conv = ops.Conv(c, h, w, co, kh, kw, s, g)
+            L = dict(name=name, conv=conv, lrn=lrn, pool=pool, cin=c, h=h, w=w)
+            L["y"] = buf(N, co, conv.oh, conv.ow)
+            if training:
+                L["dy"] = buf(N, co, conv.oh, conv.ow)
+                ws_bytes = max(ws_bytes, conv.wgrad_ws_bytes(N))
+            out = L["y"]
+            h, w, c = conv.oh, conv.ow, co
+            if lrn:
+                L["l"] = buf(N, c, h, w)
+                out = L["l"]
+                if training:
+                    L["dl"] = buf(N, c, h, w)
+            if pool:
+                ph, pw = ops.pool_out(h), ops.pool_out(w)
+                L["hwc"] = name == "conv5"       # pool5 writes the (h, w, c)-flat order fc6 reads (alexnet.py:228)
+                L["p"] = buf(N, ph, pw, c) if L["hwc"] else buf(N, c, ph, pw)
+                L["arg"] = buf(*L["p"].shape, dtype=torch.uint8)
+                if training:
+                    L["dp"] = buf(*L["p"].shape)
+                out = L["p"]
+                h, w = ph, pw
+            L["out"] = out
+            max_w = max(max_w, kh * kw * (conv.cin // g) * co)
+            self.layers.append(L)
+        self.flat_dim = h * w * c
+        self.f6 = buf(N, FC_DIM)
+        self.f7 = buf(N, FC_DIM) if cfg.frame_encoding_layer != "fc6" else None
+        self.f8 = buf(N, cfg.num_classes) if cfg.frame_encoding_layer not in ("fc6", "fc7") else None
+        self.feat = self.f8 if self.f8 is not None else (self.f7 if self.f7 is not None else self.f6)
+        D, C, H, B, T = cfg.encode_dim(), cfg.num_classes, cfg.lstm_hidden, self.B, self.T
+        self.ws = torch.empty(max(ws_bytes, 64 << 20) // 4, device=dev)       # wgrad slabs / split-K slabs
+        self.small_ws = buf(64 * max(4 * H, FC_DIM, 1024, C))                     # colsum / bias / sumsq partials
+        if training:
+            self.wt = buf(max_w)
+            self.df6 = buf(N, FC_DIM)
+            self.df7 = buf(N, FC_DIM) if self.f7 is not None else None
+            self.df8 = buf(N, C) if self.f8 is not None else None
+            self.dfeat = self.df8 if self.df8 is not None else (self.df7 if self.df7 is not None else self.df6)
+        # ---- classifier
+        if cfg.classifier == "lstm":
+            if cfg.fusion not in ops.FUSION_CODE:
+                raise VltfError("lstm fusion [%s] is not built (avg | last)" % cfg.fusion)
+            self.lstm = []
+            for l in range(cfg.lstm_layers):
+                S = dict(gx=buf(N, 4 * H), act=buf(N, 4 * H), cseq=buf(N, H), hseq=buf(N, H), hprev=buf(N, H))
+                if training:
+                    S.update(dz=buf(N, 4 * H), dout=buf(N, H))
+                self.lstm.append(S)
+            self.gh = buf(B, 4 * H)
+            self.fused = buf(B, H)
+            self.dropped = buf(B, H)
+            self.drop_mask = buf(B, H, dtype=torch.uint8)
+            self.logits = buf(B, C) if H != C else self.dropped
+            if training:
+                self.dh, self.dc = buf(B, H), buf(B, H)
+                self.dfused, self.ddropped = buf(B, H), buf(B, H)
+        else:
+            ff = cfg.frame_fusion
+            self.early = bool(ff and ff[0] == "early" and T > 1)
+            self.late = bool(ff and ff[0] == "late" and T > 1)
+            if ff and ff[1] not in ops.FUSION_CODE:
+                raise VltfError("frame fusion method [%s] is not built (avg | last)" % ff[1])
+            rows = B if self.early else N
+            self.fc_in = buf(B, D) if self.early else self.feat
+            self.fc_out = buf(rows, C) if D != C else self.fc_in
+            self.logits = buf(B, C) if self.late else self.fc_out
+            if training:
+                self.dfc_out = buf(rows, C) if self.late else None
+                self.dfc_in = buf(B, D) if self.early else None
+        self.rows_out = self.logits.shape[0]
+        if training:
+            self.dlogits = buf(*self.logits.shape)
+        self.stats = torch.zeros(2, device=dev)
+        self.ss = torch.zeros(1, device=dev)
+        self.zero_i32 = torch.zeros(N, dtype=torch.int32, device=dev)
+        self.mean_dev = torch.zeros(3, device=dev)
+
+    # ---- parameters ----------------------------------------------------------------------------
+    def load_params(self, params: dict):
+        """params: {tf variable name: numpy array in the reference layout}.  Unknown / missing names fail."""
+        missing = [n for n, _ in self.specs if n not in params]
+        extra = [n for n in params if n not in self.P]
+        if missing or extra:
+            raise VltfError("parameter set mismatch: missing %s, unexpected %s" % (missing, extra))
+        for name, shp in self.specs:
+            a = np.asarray(params[name], np.float32)
+            if tuple(a.shape) != tuple(shp):
+                raise VltfError("parameter %s has shape %s, expected %s" % (name, a.shape, shp))
+            self.P[name].copy_(torch.from_numpy(np.ascontiguousarray(a)))
+
+    def get_params(self):
+        torch.cuda.synchronize(self.dev)
+        return {n: self.P[n].detach().cpu().numpy().copy() for n, _ in self.specs}
+
+    def get_grads(self):
+        torch.cuda.synchronize(self.dev)
+        return {n: self.G[n].detach().cpu().numpy().copy() for n, _ in self.specs}
+
+    def logits_host(self, rows=None):
+        torch.cuda.synchronize(self.dev)
+        return self.logits[:rows if rows is not None else self._rows].detach().cpu().numpy().copy()
+
+    # ---- input ---------------------------------------------------------------------------------
+    def _check_frames(self, n):
+        if n <= 0 or n % self.T or n > self.N:
+            raise VltfError("got %d frames: need a positive multiple of fpc=%d, at most %d" % (n, self.T, self.N))
+        return n // self.T
+
+    def feed_u8(self, frames_u8, mean_bgr=None, crop_y=None, crop_x=None, mirror=None):
+        """frames uint8 [n, raw_h, raw_w, 3] on device (TFRecord image_raw bytes) -> x0 (dataset_.py:481-501)."""
+        n = frames_u8.shape[0]
+        b = self._check_frames(n)
+        mean = None
+        if mean_bgr is not None:
+            self.mean_dev.copy_(torch.as_tensor(np.asarray(mean_bgr, np.float32)), non_blocking=True)
+            mean = self.mean_dev
+        ops.input_prep_u8(frames_u8, self.x0[:n], crop_y, crop_x, mirror, mean)
+        return n, b
+
+    def feed_f32_nhwc(self, frames):
+        """The reference's placeholder format: float32 NHWC, already cropped / mean-subtracted (model.py:54)."""
+        n = frames.shape[0]
+        b = self._check_frames(n)
+        ops.nhwc_to_nchw(frames, self.x0[:n])
+        return n, b
+
+    # ---- forward -------------------------------------------------------------------------------
+    def _forward(self, n, b, train):
+        P, cfg = self.P, self.cfg
+        x = self.x0[:n]
+        for L in self.layers:
+            name = L["name"]
+            L["conv"].fwd(x, P["dcnn/%sW" % name], P["dcnn/%sb" % name], L["y"][:n], relu=True)
+            x = L["y"][:n]
+            if L["lrn"]:
+                ops.lrn_fwd(x, L["l"][:n], **LRN)
+                x = L["l"][:n]
+            if L["pool"]:
+                ops.maxpool_fwd(x, L["p"][:n], L["arg"][:n], hwc=L["hwc"])
+                x = L["p"][:n]
+        ops.gemm(x, P["dcnn/fc6W"], self.f6, n, FC_DIM, self.flat_dim, bias=P["dcnn/fc6b"], relu=True, ws=self.ws)
+        if self.f7 is not None:
+            ops.gemm(self.f6, P["dcnn/fc7W"], self.f7, n, FC_DIM, FC_DIM, bias=P["dcnn/fc7b"], relu=True, ws=self.ws)
+        if self.f8 is not None:
+            ops.gemm(self.f7, P["dcnn/fc8W"], self.f8, n, cfg.num_classes, FC_DIM, bias=P["dcnn/fc8b"], ws=self.ws)
+        D, C, H, T = cfg.encode_dim(), cfg.num_classes, cfg.lstm_hidden, self.T
+        if cfg.classifier == "lstm":
+            xin, d = self.feat, D
+            for l, S in enumerate(self.lstm):
+                pre = "rnn/multi_rnn_cell/cell_%d/basic_lstm_cell/" % l
+                K = P[pre + "kernel"]
+                # hoisted input projection for all (clip, t) rows, then the serial recurrence
+                ops.gemm(xin, K, S["gx"], n, 4 * H, d, bias=P[pre + "bias"], ws=self.ws)
+                for t in range(T):
+                    if t > 0:
+                        ops.gemm(S["hseq"][t - 1:], K[d:], self.gh, b, 4 * H, H, lda=T * H)
+                    ops.lstm_step_fwd(S["gx"], self.gh if t > 0 else None, S["act"], S["cseq"], S["hseq"], S["hprev"], b, T, t,
+                                      H, FORGET_BIAS)
+                xin, d = S["hseq"], H
+            ops.temporal_fusion_fwd(xin, self.fused, b, T, H, cfg.fusion)
+            v = self.fused
+            self._dropout = train and cfg.dropout_keep_prob > 0
+            if self._dropout:
+                ops.dropout_fwd(self.fused[:b], self.dropped[:b], self.drop_mask[:b], cfg.dropout_keep_prob,
+                                (self.step_count << 20) ^ 0x5DEECE66D)
+                v = self.dropped
+            if H != C:
+                ops.gemm(v, P["output_fc_w"], self.logits, b, C, H, bias=P["output_fc_b"])
+            elif v is not self.logits:
+                self.logits[:b].copy_(v[:b])
+            self._rows = b
+        else:
+            v, rows = self.feat, n
+            if self.early:
+                ops.temporal_fusion_fwd(self.feat, self.fc_in, b, T, D, cfg.frame_fusion[1])
+                v, rows = self.fc_in, b
+            if D != C:
+                ops.gemm(v, P["fc_convert_w"], self.fc_out, rows, C, D, bias=P["fc_convert_b"])
+            if self.late:
+                ops.temporal_fusion_fwd(self.fc_out, self.logits, b, T, C, cfg.frame_fusion[1])
+                rows = b
+            self._rows = rows
+        return self._rows
+
+    def forward_u8(self, frames_u8, mean_bgr=None, crop_y=None, crop_x=None, mirror=None):
+        """sess.run(model.logits, fdict) (run_task.py:95).  Returns a device view [rows, classes]."""
+        n, b = self.feed_u8(frames_u8, mean_bgr, crop_y, crop_x, mirror)
+        rows = self._forward(n, b, train=False)
+        return self.logits[:rows]
+
+    def forward_f32(self, frames_nhwc):
+        n, b = self.feed_f32_nhwc(frames_nhwc)
+        rows = self._forward(n, b, train=False)
+        return self.logits[:rows]
+
+    # ---- backward ------------------------------------------------------------------------------
+    def _backward(self, n, b):
+        P, G, cfg = self.P, self.G, self.cfg
+        D, C, H, T = cfg.encode_dim(), cfg.num_classes, cfg.lstm_hidden, self.T
+        sw = self.small_ws
+        if cfg.classifier == "lstm":
+            d = self.dlogits
+            if H != C:
+                v = self.dropped if self._dropout else self.fused
+                ops.gemm(v, self.dlogits, G["output_fc_w"], H, C, b, transa=True)
+                ops.colsum(self.dlogits, G["output_fc_b"], sw, b, C)
+                ops.gemm(self.dlogits, P["output_fc_w"], self.ddropped, b, H, C, transb=True)
+                d = self.ddropped
+            if self._dropout:
+                ops.dropout_bwd(d[:b], self.drop_mask[:b], self.dfused[:b], cfg.dropout_keep_prob)
+                d = self.dfused
+            top = self.lstm[-1]
+            ops.temporal_fusion_bwd(d, top["dout"], b, T, H, cfg.fusion)
+            for l in reversed(range(cfg.lstm_layers)):
+                S = self.lstm[l]
+                pre = "rnn/multi_rnn_cell/cell_%d/basic_lstm_cell/" % l
+                K = P[pre + "kernel"]
+                din = D if l == 0 else H
+                xin = self.feat if l == 0 else self.lstm[l - 1]["hseq"]
+                ops.fill(self.dc, 0.0)
+                for t in reversed(range(T)):
+                    ops.lstm_step_bwd(S["dout"], self.dh if t < T - 1 else None, S["act"], S["cseq"], self.dc, S["dz"], b, T, t, H)
+                    if t > 0:
+                        ops.gemm(S["dz"][t:], K[din:], self.dh, b, H, 4 * H, transb=True, lda=T * 4 * H)
+                ops.gemm(xin, S["dz"], G[pre + "kernel"], din, 4 * H, n, transa=True, ws=self.ws)
+                ops.gemm(S["hprev"], S["dz"], G[pre + "kernel"][din:], H, 4 * H, n, transa=True, ws=self.ws)
+                ops.colsum(S["dz"], G[pre + "bias"], sw, n, 4 * H)
+                if l == 0:
+                    relu_mask = self.feat if self.f8 is None else None       # ReluGrad of fc6 / fc7 fused here
+                    ops.gemm(S["dz"], K, self.dfeat, n, D, 4 * H, transb=True, ldb=4 * H, relu_mask=relu_mask, ws=self.ws)
+                else:
+                    ops.gemm(S["dz"], K, self.lstm[l - 1]["dout"], n, H, 4 * H, transb=True, ldb=4 * H, ws=self.ws)
+        else:
+            d, rows = self.dlogits, self._rows
+            if self.late:
+                ops.temporal_fusion_bwd(self.dlogits, self.dfc_out, b, T, C, cfg.frame_fusion[1])
+                d, rows = self.dfc_out, b * T
+            relu_mask = self.feat if (self.f8 is None and not self.early) else None
+            target = self.dfc_in if self.early else self.dfeat
+            if D != C:
+                ops.gemm(self.fc_in, d, G["fc_convert_w"], D, C, rows, transa=True)
+                ops.colsum(d, G["fc_convert_b"], sw, rows, C)
+                ops.gemm(d, P["fc_convert_w"], target, rows, D, C, transb=True, relu_mask=relu_mask)
+            else:
+                target[:rows].copy_(d[:rows])
+            if self.early:
+                # ReluGrad of the encode layer applies per frame after un-fusing
+                ops.temporal_fusion_bwd(self.dfc_in, self.dfeat, b, T, D, cfg.frame_fusion[1])
+                if self.f8 is None:
+                    self._relu_mask_inplace(self.dfeat, self.feat, n * D)
+        # ---- fc8 / fc7 / fc6 (dfeat already carries the ReluGrad of the encode layer)
+        d = self.dfeat
+        if self.f8 is not None:
+            ops.gemm(self.f7, d, G["dcnn/fc8W"], FC_DIM, C, n, transa=True, ws=self.ws)
+            ops.colsum(d, G["dcnn/fc8b"], sw, n, C)
+            ops.gemm(d, P["dcnn/fc8W"], self.df7, n, FC_DIM, C, transb=True, relu_mask=self.f7, ws=self.ws)
+            d = self.df7
+        if self.f7 is not None:
+            ops.gemm(self.f6, d, G["dcnn/fc7W"], FC_DIM, FC_DIM, n, transa=True, ws=self.ws)
+            ops.colsum(d, G["dcnn/fc7b"], sw, n, FC_DIM)
+            ops.gemm(d, P["dcnn/fc7W"], self.df6, n, FC_DIM, FC_DIM, transb=True, relu_mask=self.f6, ws=self.ws)
+            d = self.df6
+        L5 = self.layers[-1]
+        ops.gemm(L5["p"], d, G["dcnn/fc6W"], self.flat_dim, FC_DIM, n, transa=True, ws=self.ws)
+        ops.colsum(d, G["dcnn/fc6b"], sw, n, FC_DIM)
+        ops.gemm(d, P["dcnn/fc6W"], L5["dp"], n, self.flat_dim, FC_DIM, transb=True, ws=self.ws)
+        if self.dp is not None:
+            self.dp.reduce_async(self.g, *self.buckets[0])
+        # ---- conv stack, last to first
+        for li in reversed(range(len(self.layers))):
+            L = self.layers[li]
+            name, conv = L["name"], L["conv"]
+            x_in = self.layers[li - 1]["out"][:n] if li > 0 else self.x0[:n]
+            dy = L["dy"][:n]
+            if L["pool"] and L["lrn"]:
+                ops.maxpool_bwd(L["dp"][:n], L["arg"][:n], L["dl"][:n], hwc=L["hwc"])
+                ops.lrn_bwd(L["y"][:n], L["dl"][:n], dy, relu_fused=True, **LRN)
+            elif L["pool"]:
+                ops.maxpool_bwd(L["dp"][:n], L["arg"][:n], dy, relu_mask=L["y"][:n], hwc=L["hwc"])
+            # else: dy was written (ReluGrad fused) by the next layer's dgrad epilogue
+            conv.wgrad(x_in, dy, G["dcnn/%sW" % name], self.ws)
+            ops.bias_grad_nchw(dy, G["dcnn/%sb" % name], sw)
+            if li > 0:
+                prev = self.layers[li - 1]
+                conv.wt_transpose(P["dcnn/%sW" % name], self.wt)
+                if prev["pool"]:
+                    conv.dgrad(dy, self.wt, prev["dp"][:n])                       # into the pool output gradient
+                else:
+                    conv.dgrad(dy, self.wt, prev["dy"][:n], relu_mask=prev["y"][:n])
+        if self.dp is not None:
+            self.dp.reduce_async(self.g, *self.buckets[1])
+
+    def _relu_mask_inplace(self, d, y, count):
+        # rare path (classifier fc + early fusion): mask through the lrn-free identity of maxpool_bwd is not
+        # available here, so use the GEMM-free elementwise route: dropout_bwd with keep=1 needs a u8 mask;
+        # instead reuse vl_maxpool_bwd's mask semantics via a 1x1 "pool".
+        n = count
+        arg = torch.zeros(n, dtype=torch.uint8, device=self.dev)
+        tmp = d.reshape(-1)[:n].clone()
+        ops.maxpool_bwd(tmp.view(n, 1, 1, 1), arg.view(n, 1, 1, 1), d.reshape(-1)[:n].view(n, 1, 1, 1),
+                        relu_mask=y.reshape(-1)[:n].view(n, 1, 1, 1), k=1, s=1)
+
+    # ---- train step ----------------------------------------------------------------------------
+    def _train(self, n, b, onehot, lr, clip_norm, fetch):
+        if not self.training:
+            raise VltfError("engine was built with training=False")
+        if onehot.dtype != torch.int32 or tuple(onehot.shape) != (self._rows_for(b, n), self.cfg.num_classes):
+            raise VltfError("labels must be int32 one-hot of shape (%d, %d)" % (self._rows_for(b, n), self.cfg.num_classes))
+        rows = self._forward(n, b, train=True)
+        world = self.dp.world if self.dp is not None else 1
+        ops.fill(self.stats, 0.0)
+        # mean over the GLOBAL batch: each rank scales by 1/(rows*world); the all-reduce sums (train.py:123)
+        ops.softmax_xent(self.logits[:rows], onehot, self.dlogits, self.stats, 1.0 / (rows * world))
+        self._backward(n, b)
+        if self.dp is not None:
+            self.dp.wait()
+        ops.sumsq(self.g, self.ss, self.small_ws)
+        self.step_count += 1
+        if self.cfg.optimizer == "adam":
+            ops.adam_apply(self.w, self.g, self.adam_m, self.adam_v, lr, self.step_count, clip_norm, self.ss, 1.0)
+        else:
+            ops.sgd_apply(self.w, self.g, lr, clip_norm, self.ss, 1.0)
+        if not fetch:
+            return None
+        torch.cuda.synchronize(self.dev)
+        st = self.stats.cpu().numpy()
+        return {"loss": float(st[0]) / rows, "accuracy": float(st[1]) / rows, "grad_norm": math.sqrt(float(self.ss.item())),
+                "rows": rows}
+
+    def _rows_for(self, b, n):
+        if self.cfg.classifier == "lstm":
+            return b
+        return b if (self.early or self.late) else n
+
+    def train_step_u8(self, frames_u8, onehot, lr, clip_norm=0.0, mean_bgr=None, crop_y=None, crop_x=None, mirror=None,
+                      fetch=True):
+        """sess.run([summaries, loss, lr, global_step, optimizer], fdict) (run_task.py:44)."""
+        n, b = self.feed_u8(frames_u8, mean_bgr, crop_y, crop_x, mirror)
+        return self._train(n, b, onehot, lr, clip_norm, fetch)
+
+    def train_step_f32(self, frames_nhwc, onehot, lr, clip_norm=0.0, fetch=True):
+        n, b = self.feed_f32_nhwc(frames_nhwc)
+        return self._train(n, b, onehot, lr, clip_norm, fetch)
