@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""bench.py -- clips/s of one full LRCN train step (input-prep -> forward -> loss -> backward ->
+[all-reduce] -> global-norm clip + SGD) on synthetic 16-frame 227x227x3 clips (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+
+Workload (configs[1] of BASELINE.json): AlexNet encode at fc6 -> LSTM(256, 1 layer, avg) -> 101 classes,
+T = 16, 64 clips (= 1024 frames) per GPU per step, fp32.  Data parallel: every rank runs the reference's
+batch_size = 64 on its own clips (weak scaling: global batch 64*N), one RCCL all-reduce of the 178 MB
+gradient per step overlapped with the conv backward.  Inputs are resident in HBM before timing starts.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+# forward MACs per frame; dgrad and wgrad of a layer have the same count
+CONV_MACS = {"conv1": 113221152, "conv2": 240844800, "conv3": 149520384, "conv4": 112140288, "conv5": 74760192}
+CLIP_TRAIN_FLOP = 2 * 33357755136          # T = 16, fc6 encode
+PEAK_FP32_MFMA_TFLOPS = 157.3              # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+# launches that share the single-kernel symbol mfma_contract<128,128,16,2,2,DenseKX,ConvGather,EpiConvNCHW>
+# (output-channel tile 128: conv2/3/5 forward and conv3 dgrad, whose output channel count is 256)
+DOMINANT = ("conv2.fwd", "conv3.fwd", "conv5.fwd", "conv3.dgrad")
+DOMINANT_SYMBOL = "mfma_contract<128,128,16,2,2,DenseKX<128,16>,ConvGather<128,16>,EpiConvNCHW>"
+MEAN_BGR = np.array([99.197148, 105.293620, 109.503945], np.float32)
+
+
+def cpu_baseline(clips, fpc, num_classes):
+    """The oracle (kind 'port': numpy restatement of the reference's TF-CPU op graph; TensorFlow itself is
+    not installable here) timed on this box's host cores on a bounded sample of the same workload."""
+    from oracle import lrcn_oracle as O
+    rng = np.random.default_rng(2)
+    p = O.init_params(rng, num_classes, "fc6", 256, 1, (227, 227, 3))
+    frames = np.random.default_rng(0).integers(0, 256, (clips * fpc, 227, 227, 3), dtype=np.uint8)
+    x = frames.astype(np.float32) - MEAN_BGR
+    lab = np.random.default_rng(1).integers(0, num_classes, clips)
+    onehot = O.labels_to_one_hot([[l] for l in lab], num_classes)
+    t0 = time.time()
+    O.lrcn_train_step(p, x, onehot, fpc, lr=1e-3, clip_norm=10.0, dtype=np.float32, chunk=16)
+    dt = time.time() - t0
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count()
+    return {"value": clips / dt, "unit": "clips/s", "cores": cores, "kind": "port",
+            "sample": "%d clips x %d frames 227x227, one train step (fwd+bwd+clip+SGD), numpy fp32 oracle, %.1f s"
+                      % (clips, fpc, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--clips-per-gpu", type=int, default=64)
+    ap.add_argument("--global-batch", type=int, default=0, help="strong scaling: split this many clips over the ranks")
+    ap.add_argument("--fpc", type=int, default=16)
+    ap.add_argument("--classes", type=int, default=101)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-clips", type=int, default=2)
+    ap.add_argument("--dropout", type=float, default=0.0)
+    args = ap.parse_args()
+
+    from vltf_amd import dp as dpmod
+    from vltf_amd.engine import LRCNEngine, NetConfig, init_params
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    rank, world, local = dpmod.init_from_env()
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
+    dev = "cuda:%d" % local
+    torch.cuda.set_device(local)
+
+    scaling = "weak"
+    clips = args.clips_per_gpu
+    if args.global_batch:
+        scaling = "strong"
+        lo, hi = dpmod.shard_range(args.global_batch, rank, world)
+        clips = hi - lo
+    gar = dpmod.GradAllReduce() if world > 1 else None
+    cfg = NetConfig(image_shape=(227, 227, 3), num_classes=args.classes, fpc=args.fpc, frame_encoding_layer="fc6",
+                    classifier="lstm", lstm_hidden=256, lstm_layers=1, fusion="avg", dropout_keep_prob=args.dropout)
+    eng = LRCNEngine(cfg, max_clips=clips, device=dev, dp=gar)
+    eng.load_params(init_params(cfg, seed=2))          # reference initialisers; same seed on every rank
+    if gar is not None:
+        gar.broadcast_params(eng.w)
+    n = clips * args.fpc
+    frames = torch.from_numpy(np.random.default_rng(rank).integers(0, 256, (n, 227, 227, 3), dtype=np.uint8)).to(dev)
+    lab = np.random.default_rng(1000 + rank).integers(0, args.classes, clips)
+    onehot = torch.zeros((clips, args.classes), dtype=torch.int32)
+    onehot[torch.arange(clips), torch.from_numpy(lab)] = 1
+    onehot = onehot.to(dev)
+
+    def step():
+        eng.train_step_u8(frames, onehot, lr=1e-3, clip_norm=10.0, mean_bgr=MEAN_BGR, fetch=False)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    eng.set_probe([l + p for l in CONV_MACS for p in (".fwd", ".dgrad", ".wgrad")])
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    times = eng.probe_times_ms()
+    eng.set_probe(None)
+    out = eng.train_step_u8(frames, onehot, lr=1e-3, clip_norm=10.0, mean_bgr=MEAN_BGR, fetch=True)   # sanity, untimed
+
+    total_clips = clips * world if scaling == "weak" else args.global_batch
+    if gar is not None:
+        tc = gar.sum_scalars(torch.tensor([float(clips)], device=dev))
+        total_clips = int(tc.item())
+    if rank != 0:
+        return
+
+    # ---- roofline of the dominant kernel symbol, from the live HIP-event brackets --------------------
+    per = {}
+    for label, ms in times:
+        per.setdefault(label, []).append(ms)
+    avg = {k: sum(v) / len(v) for k, v in per.items()}
+    dom_flop = sum(2.0 * CONV_MACS[l.split(".")[0]] * n for l in DOMINANT) / len(DOMINANT)      # per launch
+    dom_ms = sum(avg[l] for l in DOMINANT) / len(DOMINANT)                                       # per launch
+    achieved = dom_flop / (dom_ms * 1e-3) / 1e12
+    stack_flop = sum(2.0 * CONV_MACS[l.split(".")[0]] * n for l in avg)
+    stack_ms = sum(avg.values())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = total_clips * args.steps / elapsed
+    rec = {
+        "metric": "clips/sec (16-frame 227x227) LRCN train step", "value": round(value, 2), "unit": "clips/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "LRCN AlexNet(fc6)+LSTM(256) %d-frame 227x227x3 clips, %d classes, UCF-101-shaped synthetic, "
+                               "full train step" % (args.fpc, args.classes),
+                   "global_batch": total_clips, "clips_per_gpu": clips, "frames_per_clip": args.fpc,
+                   "parallelism": "dp%d" % world, "optimizer": "sgd+clip_by_global_norm(10)", "init": "reference (sigma 0.05)"},
+        "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                     "kernel": DOMINANT_SYMBOL, "launches": list(DOMINANT),
+                     "flop_per_launch": dom_flop, "ms_per_launch": round(dom_ms, 4),
+                     "conv_stack": {"tflops": round(stack_flop / (stack_ms * 1e-3) / 1e12, 2),
+                                    "frac": round(stack_flop / (stack_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                                    "ms_per_step": round(stack_ms, 3),
+                                    "per_launch_ms": {k: round(v, 3) for k, v in sorted(avg.items())}},
+                     "step_frac_of_mfma_roofline": round(value / world * CLIP_TRAIN_FLOP / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)
+                     if args.fpc == 16 else None},
+        "check": {"loss": round(out["loss"], 4), "grad_norm": round(out["grad_norm"], 3)},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        rec["cpu_baseline"] = cpu_baseline(args.cpu_clips, args.fpc, args.classes)
+    print(json.dumps(rec))
+
+
+if __name__ == "__main__":
+    main()

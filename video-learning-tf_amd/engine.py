@@ -234,8 +234,31 @@ class LRCNEngine:
             self.dlogits = buf(*self.logits.shape)
         self.stats = torch.zeros(2, device=dev)
         self.ss = torch.zeros(1, device=dev)
-        self.zero_i32 = torch.zeros(N, dtype=torch.int32, device=dev)
+        self.probe, self.probe_events = None, []
         self.mean_dev = torch.zeros(3, device=dev)
+
+    # ---- live kernel timing (bench.py roofline): HIP events around labelled launches -------------
+    def set_probe(self, labels):
+        """labels: iterable of '<layer>.<fwd|dgrad|wgrad>' whose launches get bracketed by events
+        recorded on the launch stream.  None disables."""
+        self.probe = set(labels) if labels else None
+        self.probe_events = []
+
+    def _run(self, label, fn, *args, **kw):
+        if self.probe is not None and label in self.probe:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn(*args, **kw)
+            e1.record()
+            self.probe_events.append((label, e0, e1))
+        else:
+            fn(*args, **kw)
+
+    def probe_times_ms(self):
+        torch.cuda.synchronize(self.dev)
+        out = [(l, a.elapsed_time(b)) for l, a, b in self.probe_events]
+        self.probe_events = []
+        return out
 
     # ---- parameters ----------------------------------------------------------------------------
     def load_params(self, params: dict):
@@ -292,7 +315,7 @@ class LRCNEngine:
         x = self.x0[:n]
         for L in self.layers:
             name = L["name"]
-            L["conv"].fwd(x, P["dcnn/%sW" % name], P["dcnn/%sb" % name], L["y"][:n], relu=True)
+            self._run(name + ".fwd", L["conv"].fwd, x, P["dcnn/%sW" % name], P["dcnn/%sb" % name], L["y"][:n], relu=True)
             x = L["y"][:n]
             if L["lrn"]:
                 ops.lrn_fwd(x, L["l"][:n], **LRN)
@@ -440,15 +463,15 @@ class LRCNEngine:
             elif L["pool"]:
                 ops.maxpool_bwd(L["dp"][:n], L["arg"][:n], dy, relu_mask=L["y"][:n], hwc=L["hwc"])
             # else: dy was written (ReluGrad fused) by the next layer's dgrad epilogue
-            conv.wgrad(x_in, dy, G["dcnn/%sW" % name], self.ws)
+            self._run(name + ".wgrad", conv.wgrad, x_in, dy, G["dcnn/%sW" % name], self.ws)
             ops.bias_grad_nchw(dy, G["dcnn/%sb" % name], sw)
             if li > 0:
                 prev = self.layers[li - 1]
                 conv.wt_transpose(P["dcnn/%sW" % name], self.wt)
                 if prev["pool"]:
-                    conv.dgrad(dy, self.wt, prev["dp"][:n])                       # into the pool output gradient
+                    self._run(name + ".dgrad", conv.dgrad, dy, self.wt, prev["dp"][:n])     # into the pool output gradient
                 else:
-                    conv.dgrad(dy, self.wt, prev["dy"][:n], relu_mask=prev["y"][:n])
+                    self._run(name + ".dgrad", conv.dgrad, dy, self.wt, prev["dy"][:n], relu_mask=prev["y"][:n])
         if self.dp is not None:
             self.dp.reduce_async(self.g, *self.buckets[1])
 
