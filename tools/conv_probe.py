@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Runs one AlexNet conv layer's fwd / dgrad / wgrad kernels in isolation (for rocprofv3 / timing).
+usage: conv_probe.py <conv1..conv5> <fwd|dgrad|wgrad> [frames] [iters]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from vltf_amd import ops
+
+GEOM = {  # cin, h, w, cout, k, stride, groups
+    "conv1": (3, 227, 227, 96, 11, 4, 1), "conv2": (96, 28, 28, 256, 5, 1, 2), "conv3": (256, 13, 13, 384, 3, 1, 1),
+    "conv4": (384, 13, 13, 384, 3, 1, 2), "conv5": (384, 13, 13, 256, 3, 1, 2)}
+MACS = {"conv1": 113221152, "conv2": 240844800, "conv3": 149520384, "conv4": 112140288, "conv5": 74760192}
+
+
+def main():
+    layer, what = sys.argv[1], sys.argv[2]
+    n = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
+    iters = int(sys.argv[4]) if len(sys.argv) > 4 else 10
+    cin, h, w, cout, k, s, g = GEOM[layer]
+    conv = ops.Conv(cin, h, w, cout, k, k, s, g)
+    dev = "cuda:0"
+    x = torch.randn(n, cin, h, w, device=dev)
+    wt = torch.randn(k, k, cin // g, cout, device=dev) * 0.05
+    b = torch.zeros(cout, device=dev)
+    y = torch.empty(n, cout, conv.oh, conv.ow, device=dev)
+    dy = torch.randn(n, cout, conv.oh, conv.ow, device=dev)
+    dx = torch.empty_like(x)
+    dw = torch.empty_like(wt)
+    wtt = torch.empty(wt.numel(), device=dev)
+    ws = torch.empty(max(conv.wgrad_ws_bytes(n) // 4, 1), device=dev)
+    if what == "dgrad":
+        conv.wt_transpose(wt, wtt)
+
+    def run():
+        if what == "fwd":
+            conv.fwd(x, wt, b, y, relu=True)
+        elif what == "dgrad":
+            conv.dgrad(dy, wtt, dx)
+        else:
+            conv.wgrad(x, dy, dw, ws)
+
+    run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    print("%s.%s n=%d: %.3f ms  %.1f TFLOP/s" % (layer, what, n, dt * 1e3, 2 * MACS[layer] * n / dt / 1e12))
+
+
+if __name__ == "__main__":
+    main()

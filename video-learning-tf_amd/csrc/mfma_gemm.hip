@@ -60,6 +60,7 @@ struct DenseKX {
         R = P.R;
         x0 = x0_;
     }
+    __device__ __forceinline__ void prefetch(int) {}
     __device__ __forceinline__ void load(int rt, float (&v)[NLD]) const {
 #pragma unroll
         for (int j = 0; j < NLD; ++j) {
@@ -99,6 +100,7 @@ struct DenseXK {
         R = P.R;
         x0 = x0_;
     }
+    __device__ __forceinline__ void prefetch(int) {}
     __device__ __forceinline__ void load(int rt, float (&v)[NLD]) const {
 #pragma unroll
         for (int j = 0; j < NLD; ++j) {
@@ -129,19 +131,37 @@ struct ConvGeom {
     FastDiv dOHW, dOW;
     int64_t img_stride;  // elements between images (Cin_total * H * W)
     int64_t grp_stride;  // elements between groups (Cin_g * H * W)
+    int64_t total;       // elements in x (n * Cin_total * H * W); < 2^30 so byte offsets fit 32 bits
 };
 
-// im2col gather, reduction index r = im2col row (wave-uniform per load -> scalar table reads),
-// x = output pixel across lanes (coalesced along ow).
+// Buffer-resource gather: every im2col element is fetched with a raw buffer load whose per-lane byte
+// offset is either the real offset or OOB_OFF; the hardware range check returns 0 for the latter, so
+// padding taps and tile tails cost no branch and no select.  Offsets are biased by (pt*W + pl)
+// elements so they are never negative (the resource base points that far before x).
+static constexpr uint32_t OOB_OFF = 0xFFFFFFF0u;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, int64_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)(uint32_t)bytes, 0x00020000);
+}
+__device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0));
+}
+
+// im2col gather, reduction index r = im2col row, x = output pixel across lanes (coalesced along ow).
+// A wave owns NLD consecutive rows of the tile, so its table entries are one contiguous, aligned
+// block read with a single wide scalar load -- fetched one tile ahead of use.
 template <int BX, int BR>
 struct ConvGather {
     using L = LdsKX<BX, BR>;
-    static constexpr int NLD = BX * BR / NT;
+    static constexpr int NLD = BX * BR / NT;   // rows per wave
     static_assert(BX % 64 == 0, "pixel tile must be a multiple of the wave size");
+    static_assert(NLD * (NT / BX) == BR, "rows must split evenly over the wave groups");
     using Params = ConvGeom;
-    const float* base;
-    const int2* ktab;
-    int ih0, iw0, H, W;
+    __amdgpu_buffer_rsrc_t rsrc;
+    const int2* tab;     // this wave's first row of the current tile
+    int2 ent[NLD];       // entries of the tile about to be loaded (prefetched)
+    uint32_t voff;       // biased byte offset of (n, ih0, iw0)
+    int ih0, iw0, H, W, row0;
     bool vm;
     __device__ __forceinline__ void init(const Params& P, int x0, int zg) {
         const int m = x0 + threadIdx.x % BX;
@@ -155,25 +175,31 @@ struct ConvGather {
         iw0 = (int)ow * P.stride - P.pl;
         H = P.H;
         W = P.W;
-        ktab = P.ktab;
-        base = P.x + (int64_t)n * P.img_stride + (int64_t)zg * P.grp_stride + (int64_t)ih0 * P.W + iw0;
+        const int bias = P.pt * P.W + P.pl;
+        const int ih0_real = ih0;
+        rsrc = make_rsrc(P.x + (int64_t)zg * P.grp_stride - bias, (P.total - (int64_t)zg * P.grp_stride + bias) * 4);
+        voff = (uint32_t)((int64_t)n * P.img_stride + (int64_t)ih0_real * P.W + iw0 + bias) * 4u;
+        if (!vm) ih0 = 1 << 28;   // a pixel past the end fails every row test below: no separate predicate
+        row0 = __builtin_amdgcn_readfirstlane((int)threadIdx.x / BX) * NLD;
+        tab = P.ktab + row0;
     }
-    __device__ __forceinline__ void load(int rt, float (&v)[NLD]) const {
+    __device__ __forceinline__ void prefetch(int rt) {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) ent[j] = tab[rt * BR + j];
+    }
+    __device__ __forceinline__ void load(int rt, float (&v)[NLD]) {
 #pragma unroll
         for (int j = 0; j < NLD; ++j) {
-            const int kl = __builtin_amdgcn_readfirstlane((int)(threadIdx.x + NT * j) / BX);
-            const int2 e = ktab[rt * BR + kl];
-            const int ih = ih0 + (e.y >> 16), iw = iw0 + (e.y & 0xffff);
-            const bool ok = vm && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
-            v[j] = ok ? base[e.x] : 0.f;
+            const int ih = ih0 + (ent[j].y >> 16), iw = iw0 + (ent[j].y & 0xffff);
+            const bool ok = ((unsigned)ih < (unsigned)H) & ((unsigned)iw < (unsigned)W);
+            v[j] = buf_load(rsrc, ok ? voff + (uint32_t)ent[j].x * 4u : OOB_OFF);
         }
+        prefetch(rt + 1);   // the table is padded by a whole tile, reading one past the end is safe
     }
     __device__ __forceinline__ void store(float* lds, const float (&v)[NLD]) const {
+        const int xl = threadIdx.x % BX;
 #pragma unroll
-        for (int j = 0; j < NLD; ++j) {
-            const int e = threadIdx.x + NT * j;
-            lds[L::idx(e % BX, e / BX)] = v[j];
-        }
+        for (int j = 0; j < NLD; ++j) lds[L::idx(xl, row0 + j)] = v[j];
     }
 };
 
@@ -184,19 +210,21 @@ struct WgradGather {
     using L = LdsXK<BX, BR>;
     static constexpr int NLD = BX * BR / NT;
     using Params = ConvGeom;
-    const float* xin;
-    int off[NLD], khkw[NLD];
-    int H, W, M, OHW, OW, stride, pt, pl;
+    __amdgpu_buffer_rsrc_t rsrc;
+    uint32_t off[NLD];   // byte offsets (ci*H + kh)*W + kw
+    int khkw[NLD];
+    int H, W, M, OHW, OW, stride, pt, pl, bias;
     FastDiv dOHW, dOW;
     int64_t img_stride;
     __device__ __forceinline__ void init(const Params& P, int x0, int zg) {
 #pragma unroll
         for (int j = 0; j < NLD; ++j) {
             const int2 e = P.ktab[x0 + (int)(threadIdx.x + NT * j) / BR];
-            off[j] = e.x;
+            off[j] = (uint32_t)e.x * 4u;
             khkw[j] = e.y;
         }
-        xin = P.x + (int64_t)zg * P.grp_stride;
+        bias = P.pt * P.W + P.pl;
+        rsrc = make_rsrc(P.x + (int64_t)zg * P.grp_stride - bias, (P.total - (int64_t)zg * P.grp_stride + bias) * 4);
         H = P.H; W = P.W; M = P.M; OHW = P.OHW; OW = P.OW;
         stride = P.stride; pt = P.pt; pl = P.pl;
         dOHW = P.dOHW; dOW = P.dOW;
@@ -210,15 +238,17 @@ struct WgradGather {
         const uint32_t p = mm - n * OHW;
         const uint32_t oh = fd_div(p, dOW);
         const uint32_t ow = p - oh * OW;
-        const int ih0 = (int)oh * stride - pt, iw0 = (int)ow * stride - pl;
-        const float* base = xin + (int64_t)n * img_stride + (int64_t)ih0 * W + iw0;
+        const int ih0r = (int)oh * stride - pt, iw0 = (int)ow * stride - pl;
+        const uint32_t voff = (uint32_t)((int64_t)n * img_stride + (int64_t)ih0r * W + iw0 + bias) * 4u;
+        const int ih0 = vm ? ih0r : (1 << 28);
 #pragma unroll
         for (int j = 0; j < NLD; ++j) {
             const int ih = ih0 + (khkw[j] >> 16), iw = iw0 + (khkw[j] & 0xffff);
-            const bool ok = vm && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
-            v[j] = ok ? base[off[j]] : 0.f;
+            const bool ok = ((unsigned)ih < (unsigned)H) & ((unsigned)iw < (unsigned)W);
+            v[j] = buf_load(rsrc, ok ? voff + off[j] : OOB_OFF);
         }
     }
+    __device__ __forceinline__ void prefetch(int) {}
     __device__ __forceinline__ void store(float* lds, const float (&v)[NLD]) const {
 #pragma unroll
         for (int j = 0; j < NLD; ++j) {
@@ -238,16 +268,26 @@ struct DyRows {
         const float* dy;
         int M, OHW, Cog, Cout_total;
         FastDiv dOHW;
+        int64_t total;   // elements in dy
     };
-    const float* dy;
-    int M, OHW, Cog, x0;
+    __amdgpu_buffer_rsrc_t rsrc;
+    uint32_t co_off[NLD];   // byte offset of the row's channel plane
+    bool co_ok[NLD];        // channel inside the group
+    int M, OHW;
     int64_t img_stride;
     FastDiv dOHW;
-    __device__ __forceinline__ void init(const Params& P, int x0_, int zg) {
-        dy = P.dy + (int64_t)zg * P.Cog * P.OHW;
-        M = P.M; OHW = P.OHW; Cog = P.Cog; x0 = x0_;
+    __device__ __forceinline__ void init(const Params& P, int x0, int zg) {
+        const int64_t goff = (int64_t)zg * P.Cog * P.OHW;
+        rsrc = make_rsrc(P.dy + goff, (P.total - goff) * 4);
+        M = P.M; OHW = P.OHW;
         img_stride = (int64_t)P.Cout_total * P.OHW;
         dOHW = P.dOHW;
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int co = x0 + (int)(threadIdx.x + NT * j) / BR;
+            co_ok[j] = co < P.Cog;
+            co_off[j] = (uint32_t)co * (uint32_t)P.OHW * 4u;
+        }
     }
     __device__ __forceinline__ void load(int rt, float (&v)[NLD]) const {
         const int m = rt * BR + threadIdx.x % BR;
@@ -255,13 +295,11 @@ struct DyRows {
         const uint32_t mm = vm ? m : 0;
         const uint32_t n = fd_div(mm, dOHW);
         const uint32_t p = mm - n * OHW;
-        const float* base = dy + (int64_t)n * img_stride + p;
+        const uint32_t voff = (uint32_t)((int64_t)n * img_stride + p) * 4u;
 #pragma unroll
-        for (int j = 0; j < NLD; ++j) {
-            const int co = x0 + (int)(threadIdx.x + NT * j) / BR;
-            v[j] = (vm && co < Cog) ? base[(int64_t)co * OHW] : 0.f;
-        }
+        for (int j = 0; j < NLD; ++j) v[j] = buf_load(rsrc, (vm & co_ok[j]) ? voff + co_off[j] : OOB_OFF);
     }
+    __device__ __forceinline__ void prefetch(int) {}
     __device__ __forceinline__ void store(float* lds, const float (&v)[NLD]) const {
 #pragma unroll
         for (int j = 0; j < NLD; ++j) {
@@ -387,6 +425,8 @@ __global__ __launch_bounds__(NT) void mfma_contract(const typename LA::Params pa
 
     float ra[LA::NLD], rb[LB::NLD];
     if (rt0 < rt1) {
+        la.prefetch(rt0);
+        lb.prefetch(rt0);
         la.load(rt0, ra);
         lb.load(rt0, rb);
         la.store(lds, ra);
@@ -563,6 +603,8 @@ extern "C" int vl_conv_fwd(const vl_conv_desc* d, const float* x, const float* w
     g.dOHW = make_fastdiv(g.OHW); g.dOW = make_fastdiv(g.OW);
     g.img_stride = (int64_t)d->cin * d->h * d->w;
     g.grp_stride = (int64_t)d->cig * d->h * d->w;
+    g.total = g.img_stride * n;
+    VL_CHECK(g.total < (1ll << 30) - (1 << 20), "vl_conv_fwd: input of %lld elements exceeds the 4 GiB buffer-offset range", (long long)g.total);
     // HWIO weights are the [K][Cout_total] GEMM operand as they stand; group g = column block g*cog.
     return dispatch_conv(g, w, d->cout, d->cog, d->cog, d->cout, bias, nullptr, relu, y, (hipStream_t)stream);
 }
@@ -604,6 +646,8 @@ extern "C" int vl_conv_dgrad(const vl_conv_desc* d, const float* dy, const float
     g.dOHW = make_fastdiv(g.OHW); g.dOW = make_fastdiv(g.OW);
     g.img_stride = (int64_t)d->cout * d->oh * d->ow;
     g.grp_stride = (int64_t)d->cog * d->oh * d->ow;
+    g.total = g.img_stride * n;
+    VL_CHECK(g.total < (1ll << 30) - (1 << 20), "vl_conv_dgrad: dy of %lld elements exceeds the 4 GiB buffer-offset range", (long long)g.total);
     return dispatch_conv(g, wt, d->cin, d->cig, d->cig, d->cin, nullptr, relu_mask, 0, dx, (hipStream_t)stream);
 }
 
@@ -629,7 +673,7 @@ static int launch_wgrad(const vl_conv_desc* d, const ConvGeom& g, const float* d
     constexpr int BM = 128, BR = 32;
     using LA = WgradGather<BM, BR>;
     using LB = DyRows<BN, BR>;
-    typename LB::Params pb{dy, g.M, g.OHW, d->cog, d->cout, g.dOHW};
+    typename LB::Params pb{dy, g.M, g.OHW, d->cog, d->cout, g.dOHW, (int64_t)d->cout * g.M};
     const int64_t slab = (int64_t)d->K * d->cout;
     // slab z: [K][Cout_total], group g = column block
     EpiRowMajor::Params pe{splits > 1 ? ws : dw, d->cout, d->K, d->cog, nullptr, nullptr, 0, d->cog, splits > 1 ? slab : 0};
@@ -661,6 +705,9 @@ extern "C" int vl_conv_wgrad(const vl_conv_desc* d, const float* x, const float*
     g.dOHW = make_fastdiv(g.OHW); g.dOW = make_fastdiv(g.OW);
     g.img_stride = (int64_t)d->cin * d->h * d->w;
     g.grp_stride = (int64_t)d->cig * d->h * d->w;
+    g.total = g.img_stride * n;
+    VL_CHECK(g.total < (1ll << 30) - (1 << 20) && (int64_t)n * d->cout * d->oh * d->ow < (1ll << 30),
+             "vl_conv_wgrad: operand exceeds the 4 GiB buffer-offset range");
     if (d->cog % 128 == 0) return launch_wgrad<128, 2, 2>(d, g, dy, dw, (float*)ws, splits, (hipStream_t)stream);
     return launch_wgrad<96, 4, 1>(d, g, dy, dw, (float*)ws, splits, (hipStream_t)stream);
 }
