@@ -39,15 +39,16 @@ int vl_device_count(void);
 
 /* ---- input preparation: Dataset.process_image (dataset_.py:481-501) on device ------------------
  * src: uint8 [n][raw_h][raw_w][3] HWC, BGR (the TFRecord 'image_raw' bytes, dataset_.py:125-126).
- * dst: fp32  [n][3][out_h][out_w] NCHW.  crop_y/crop_x: int32[n] top-left crop offsets
+ * dst: fp32  [n][3][out_h + 2*dst_halo][out_w + 2*dst_halo] NCHW; only the interior is written (the halo
+ * must have been zeroed once: it is conv1's SAME padding, see vl_conv_set_halo).  crop_y/crop_x: int32[n] top-left crop offsets
  * (center: floor((raw-want)/2), dataset_.py:572-573); mirror: uint8[n] flips the W axis
  * (dataset_.py:497-499); mean_bgr: float[3] subtracted per channel (dataset_.py:521-530), may be NULL.
  * crop_y, crop_x, mirror may be NULL (= 0). */
 int vl_input_prep_u8(const uint8_t* src, float* dst, int n, int raw_h, int raw_w, int out_h, int out_w,
                      const int32_t* crop_y, const int32_t* crop_x, const uint8_t* mirror,
-                     const float* mean_bgr, vl_stream_t stream);
-/* The reference's own feed format: fp32 NHWC placeholder (models/model.py:54) -> NCHW. */
-int vl_nhwc_to_nchw(const float* src, float* dst, int n, int h, int w, int c, vl_stream_t stream);
+                     const float* mean_bgr, int dst_halo, vl_stream_t stream);
+/* The reference's own feed format: fp32 NHWC placeholder (models/model.py:54) -> NCHW (+halo). */
+int vl_nhwc_to_nchw(const float* src, float* dst, int n, int h, int w, int c, int dst_halo, vl_stream_t stream);
 int vl_nchw_to_nhwc(const float* src, float* dst, int n, int c, int h, int w, vl_stream_t stream);
 
 /* ---- convolution: dcnn.conv (alexnet.py:15-31) = tf.nn.conv2d 'SAME' per group + bias_add ------
@@ -55,6 +56,16 @@ int vl_nchw_to_nhwc(const float* src, float* dst, int n, int c, int h, int w, vl
 int vl_conv_create(vl_conv_desc** out, int cin, int h, int w, int cout, int kh, int kw, int stride, int groups);
 void vl_conv_destroy(vl_conv_desc* d);
 int vl_conv_out_hw(const vl_conv_desc* d, int* oh, int* ow);
+/* Padded ("halo") activation layout.  A tensor with halo p is stored [n][c][H + 2p][W + 2p] with p zero
+ * pixels on every side of each plane; only interiors are ever written.  When the gathered operand's halo
+ * covers the SAME padding, the im2col gather needs no bounds test at all (every tap is in-bounds and the
+ * padding taps read the zeros), which removes all vector-ALU address work from the kernel's steady state.
+ *   x_halo : layout of x (vl_conv_fwd / vl_conv_wgrad input; also of vl_conv_dgrad's relu_mask)
+ *   y_halo : layout of y written by vl_conv_fwd
+ *   dy_halo: layout of dy read by vl_conv_dgrad / vl_conv_wgrad
+ *   dx_halo: layout of dx written by vl_conv_dgrad
+ * Default 0 everywhere (dense NCHW; bounds-tested gather).  Rebuilds the index tables (setup time only). */
+int vl_conv_set_halo(vl_conv_desc* d, int x_halo, int y_halo, int dy_halo, int dx_halo);
 /* y[n][cout][oh][ow] = conv(x[n][cin][h][w], w_hwio) + bias, optional fused ReLU (alexnet.py:77). */
 int vl_conv_fwd(const vl_conv_desc* d, const float* x, const float* w_hwio, const float* bias, float* y,
                 int n, int relu, vl_stream_t stream);
@@ -78,9 +89,10 @@ int vl_bias_grad_nchw(const float* dy, float* db, float* ws, int n, int c, int h
 int vl_lrn_fwd(const float* x, float* y, int n, int c, int hw, int radius, float alpha, float beta, float bias,
                vl_stream_t stream);
 /* dx for the above; relu_fused != 0 additionally applies the ReluGrad of the layer that produced
- * x (x is a ReLU output, alexnet.py:77): dx = x > 0 ? dx : 0. */
+ * x (x is a ReLU output, alexnet.py:77): dx = x > 0 ? dx : 0.  x and dy are dense; dx may carry a halo
+ * (plane width w, hw = h*w): it is the dy of the conv that produced x. */
 int vl_lrn_bwd(const float* x, const float* dy, float* dx, int n, int c, int hw, int radius, float alpha,
-               float beta, float bias, int relu_fused, vl_stream_t stream);
+               float beta, float bias, int relu_fused, int w, int dx_halo, vl_stream_t stream);
 
 /* ---- tf.nn.max_pool k x k, stride s, VALID (alexnet.py:91-98,132-139,204-211) ------------------
  * x NCHW [n][c][h][w]; y element (n,c,oh,ow) is stored at y[n*ys_n + c*ys_c + oh*ys_h + ow*ys_w]
@@ -89,10 +101,10 @@ int vl_lrn_bwd(const float* x, const float* dy, float* dx, int n, int c, int hw,
  * first maximum in scan order (TF-CPU MaxPoolGrad target). */
 int vl_maxpool_fwd(const float* x, float* y, uint8_t* argmax, int n, int c, int h, int w, int k, int s,
                    int64_t ys_n, int64_t ys_c, int64_t ys_h, int64_t ys_w, vl_stream_t stream);
-/* dx NCHW (fully written).  relu_mask (the pool input, NCHW) optional: fused ReluGrad. */
+/* dx NCHW with dx_halo (interior fully written).  relu_mask (the pool input, dense NCHW) optional: fused ReluGrad. */
 int vl_maxpool_bwd(const float* dy, const uint8_t* argmax, float* dx, const float* relu_mask, int n, int c,
                    int h, int w, int k, int s, int64_t ys_n, int64_t ys_c, int64_t ys_h, int64_t ys_w,
-                   vl_stream_t stream);
+                   int dx_halo, vl_stream_t stream);
 
 /* ---- dense GEMM on fp32 MFMA: tf.nn.relu_layer / xw_plus_b / matmul gradients ------------------
  * C[m][n] = sum_k opA(m,k) * opB(k,n) (+ bias[n]) (ReLU) ; then C = relu_mask>0 ? C : 0 if given.

@@ -93,8 +93,19 @@ CONV_CASES = [
 ]
 
 
+def pad_nchw(a_nchw, halo):
+    return np.pad(a_nchw, ((0, 0), (0, 0), (halo, halo), (halo, halo)))
+
+
+def interior(t, halo):
+    return t if halo == 0 else t[:, :, halo:-halo, halo:-halo]
+
+
+@pytest.mark.parametrize("padded", [False, True])
 @pytest.mark.parametrize("n,h,w,cin,cout,k,s,g", CONV_CASES)
-def test_conv_fwd_bwd(ops, n, h, w, cin, cout, k, s, g):
+def test_conv_fwd_bwd(ops, padded, n, h, w, cin, cout, k, s, g):
+    """padded=False: dense NCHW, bounds-tested gather.  padded=True: every tensor carries a zero halo
+    (x/dy: the SAME padding -> test-free gather; y/dx: an arbitrary halo of 1) as the engine lays them out."""
     rng = np.random.default_rng(h * 100 + cin)
     x = rng.standard_normal((n, h, w, cin)).astype(np.float32)
     wt = (rng.standard_normal((k, k, cin // g, cout)) / math.sqrt(k * k * cin / g)).astype(np.float32)
@@ -103,33 +114,43 @@ def test_conv_fwd_bwd(ops, n, h, w, cin, cout, k, s, g):
     oh, _, _ = O.same_pad(h, k, s)
     ow, _, _ = O.same_pad(w, k, s)
     assert (conv.oh, conv.ow) == (oh, ow)
-    xd, wd, bd = dev(nchw(x)), dev(wt), dev(b)
-    y = torch.empty((n, cout, oh, ow), device=DEV)
+    xh = conv.same_pad() if padded else 0
+    yh = 1 if padded else 0
+    dyh = (k - 1) if padded else 0          # >= K-1-pad on every side
+    dxh = 2 if padded else 0
+    conv.set_halo(xh, yh, dyh, dxh)
+    xd, wd, bd = dev(pad_nchw(nchw(x), xh)), dev(wt), dev(b)
+    y = torch.zeros((n, cout, oh + 2 * yh, ow + 2 * yh), device=DEV)
     conv.fwd(xd, wd, bd, y, relu=False)
     z = O.grouped_conv(x, wt, b, s, g)
-    close(nhwc(host(y)), z, msg="conv fwd")
+    close(nhwc(host(interior(y, yh))), z, msg="conv fwd")
+    if yh:
+        yy = host(y)
+        assert np.all(yy[:, :, 0, :] == 0) and np.all(yy[:, :, :, -1] == 0)      # halo untouched
     conv.fwd(xd, wd, bd, y, relu=True)
-    close(nhwc(host(y)), np.maximum(z, 0), msg="conv fwd+relu")
+    close(nhwc(host(interior(y, yh))), np.maximum(z, 0), msg="conv fwd+relu")
 
     dy = rng.standard_normal(z.shape).astype(np.float32)
     dxo, dwo, dbo = O.grouped_conv_grad(x, wt, dy, s, g, need_dx=(s == 1))
-    dyd = dev(nchw(dy))
+    dyd = dev(pad_nchw(nchw(dy), dyh))
     dw = torch.empty_like(wd)
     ws = torch.empty(max(conv.wgrad_ws_bytes(n) // 4, 1), device=DEV)
     conv.wgrad(xd, dyd, dw, ws)
     close(host(dw), dwo, msg="conv wgrad")
     db = torch.empty(cout, device=DEV)
-    ops.bias_grad_nchw(dyd, db, torch.empty(64 * cout, device=DEV))
+    ops.bias_grad_nchw(dyd, db, torch.empty(64 * cout, device=DEV))       # halo zeros add nothing
     close(host(db), dbo, msg="bias grad")
     if s == 1:
         wtt = torch.empty(wd.numel(), device=DEV)
         conv.wt_transpose(wd, wtt)
-        dx = torch.empty_like(xd)
+        dx = torch.zeros((n, cin, h + 2 * dxh, w + 2 * dxh), device=DEV)
         conv.dgrad(dyd, wtt, dx)
-        close(nhwc(host(dx)), dxo, msg="conv dgrad")
+        close(nhwc(host(interior(dx, dxh))), dxo, msg="conv dgrad")
         mask = rng.standard_normal(x.shape).astype(np.float32)
-        conv.dgrad(dyd, wtt, dx, relu_mask=dev(nchw(mask)))
-        close(nhwc(host(dx)), dxo * (mask > 0), msg="conv dgrad+mask")
+        conv.dgrad(dyd, wtt, dx, relu_mask=dev(pad_nchw(nchw(mask), xh)))
+        close(nhwc(host(interior(dx, dxh))), dxo * (mask > 0), msg="conv dgrad+mask")
+        if dxh:
+            assert np.all(host(dx)[:, :, :dxh, :] == 0)
     else:
         with pytest.raises(Exception):
             conv.dgrad(dyd, wd, torch.empty_like(xd))
@@ -152,6 +173,10 @@ def test_lrn(ops, n, h, w, c):
     close(nhwc(host(dx)), g, rtol=1e-5, atol_rel=1e-6, msg="lrn bwd")
     ops.lrn_bwd(xd, dev(nchw(dy)), dx, relu_fused=True)
     close(nhwc(host(dx)), g * (x > 0), rtol=1e-5, atol_rel=1e-6, msg="lrn bwd + relu grad")
+    dxp = torch.zeros((n, c, h + 4, w + 4), device=DEV)
+    ops.lrn_bwd(xd, dev(nchw(dy)), dxp, dx_halo=2)
+    close(nhwc(host(dxp[:, :, 2:-2, 2:-2])), g, rtol=1e-5, atol_rel=1e-6, msg="lrn bwd into a haloed dx")
+    assert float(dxp[:, :, :2].abs().max()) == 0 and float(dxp[:, :, :, -2:].abs().max()) == 0
 
 
 @pytest.mark.parametrize("hwc", [False, True])
@@ -177,6 +202,18 @@ def test_maxpool(ops, hwc, n, h, w, c):
     close(nhwc(host(dx)), want, rtol=1e-6, atol_rel=1e-7)
     ops.maxpool_bwd(dyd, ad, dx, relu_mask=xd, hwc=hwc)
     close(nhwc(host(dx)), want * (x > 0), rtol=1e-6, atol_rel=1e-7)
+    if not hwc:     # haloed pool output (feeds a conv) and haloed dx (is a conv's dy)
+        yp = torch.zeros((n, c, oh + 4, ow + 4), device=DEV)
+        ap = torch.zeros(yp.shape, dtype=torch.uint8, device=DEV)
+        ops.maxpool_fwd(xd, yp, ap, y_halo=2)
+        np.testing.assert_array_equal(nhwc(host(yp[:, :, 2:-2, 2:-2])), y)
+        assert float(yp[:, :, :2].abs().max()) == 0
+        dyp = torch.zeros_like(yp)
+        dyp[:, :, 2:-2, 2:-2] = dev(nchw(dy))
+        dxp = torch.zeros((n, c, h + 2, w + 2), device=DEV)
+        ops.maxpool_bwd(dyp, ap, dxp, dy_halo=2, dx_halo=1)
+        close(nhwc(host(dxp[:, :, 1:-1, 1:-1])), want, rtol=1e-6, atol_rel=1e-7)
+        assert float(dxp[:, :, 0].abs().max()) == 0
 
 
 def test_colsum(ops):
@@ -202,11 +239,18 @@ def test_input_prep(ops):
     np.testing.assert_array_equal(nhwc(host(dst)), want)          # bit exact: u8 -> f32 minus f32
     ops.input_prep_u8(dev(src, torch.uint8)[:, :oh, :ow].contiguous(), dst)
     np.testing.assert_array_equal(nhwc(host(dst)), src[:, :oh, :ow].astype(np.float32))
+    dsth = torch.zeros((n, 3, oh + 8, ow + 8), device=DEV)
+    ops.input_prep_u8(dev(src, torch.uint8), dsth, dev(cy, torch.int32), dev(cx, torch.int32), dev(mir, torch.uint8), dev(mean), halo=4)
+    np.testing.assert_array_equal(nhwc(host(dsth[:, :, 4:-4, 4:-4])), want)
+    assert float(dsth[:, :, :4].abs().max()) == 0 and float(dsth[:, :, :, -4:].abs().max()) == 0
     # layout converters
     x = rng.standard_normal((2, 5, 7, 3)).astype(np.float32)
     t = torch.empty((2, 3, 5, 7), device=DEV)
     ops.nhwc_to_nchw(dev(x), t)
     np.testing.assert_array_equal(host(t), nchw(x))
+    th = torch.zeros((2, 3, 9, 11), device=DEV)
+    ops.nhwc_to_nchw(dev(x), th, halo=2)
+    np.testing.assert_array_equal(host(th[:, :, 2:-2, 2:-2]), nchw(x))
     back = torch.empty((2, 5, 7, 3), device=DEV)
     ops.nchw_to_nhwc(t, back)
     np.testing.assert_array_equal(host(back), x)

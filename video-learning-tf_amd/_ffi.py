@@ -14,12 +14,13 @@ SIGNATURES = {
     "vl_last_error": (C.c_char_p, []),
     "vl_version": (i32, []),
     "vl_device_count": (i32, []),
-    "vl_input_prep_u8": (i32, [p, p, i32, i32, i32, i32, i32, p, p, p, p, p]),
-    "vl_nhwc_to_nchw": (i32, [p, p, i32, i32, i32, i32, p]),
+    "vl_input_prep_u8": (i32, [p, p, i32, i32, i32, i32, i32, p, p, p, p, i32, p]),
+    "vl_nhwc_to_nchw": (i32, [p, p, i32, i32, i32, i32, i32, p]),
     "vl_nchw_to_nhwc": (i32, [p, p, i32, i32, i32, i32, p]),
     "vl_conv_create": (i32, [C.POINTER(p), i32, i32, i32, i32, i32, i32, i32, i32]),
     "vl_conv_destroy": (None, [p]),
     "vl_conv_out_hw": (i32, [p, C.POINTER(i32), C.POINTER(i32)]),
+    "vl_conv_set_halo": (i32, [p, i32, i32, i32, i32]),
     "vl_conv_fwd": (i32, [p, p, p, p, p, i32, i32, p]),
     "vl_conv_wt_transpose": (i32, [p, p, p, p]),
     "vl_conv_dgrad": (i32, [p, p, p, p, p, i32, p]),
@@ -27,9 +28,9 @@ SIGNATURES = {
     "vl_conv_wgrad": (i32, [p, p, p, p, p, sz, i32, p]),
     "vl_bias_grad_nchw": (i32, [p, p, p, i32, i32, i32, p]),
     "vl_lrn_fwd": (i32, [p, p, i32, i32, i32, i32, f32, f32, f32, p]),
-    "vl_lrn_bwd": (i32, [p, p, p, i32, i32, i32, i32, f32, f32, f32, i32, p]),
+    "vl_lrn_bwd": (i32, [p, p, p, i32, i32, i32, i32, f32, f32, f32, i32, i32, i32, p]),
     "vl_maxpool_fwd": (i32, [p, p, p, i32, i32, i32, i32, i32, i32, i64, i64, i64, i64, p]),
-    "vl_maxpool_bwd": (i32, [p, p, p, p, i32, i32, i32, i32, i32, i32, i64, i64, i64, i64, p]),
+    "vl_maxpool_bwd": (i32, [p, p, p, p, i32, i32, i32, i32, i32, i32, i64, i64, i64, i64, i32, p]),
     "vl_gemm": (i32, [i32, i32, i32, i32, i32, p, i64, p, i64, p, i64, p, i32, p, p, sz, p]),
     "vl_colsum": (i32, [p, i64, p, p, i32, i32, p]),
     "vl_lstm_step_fwd": (i32, [p, p, p, p, p, p, i32, i32, i32, i32, f32, p]),

@@ -2,13 +2,24 @@
 //
 // One kernel template, D[i][j] = sum_r A(i, r) * B(r, j), computed with v_mfma_f32_32x32x2_f32
 // (exact fp32, 64 FLOP/clk/SIMD).  256 threads = 4 wavefronts per workgroup; each wave owns a
-// (BM/WM) x (BN/WN) block of 32x32 accumulator tiles.  Operand tiles are staged
-// HBM/L2 -> registers -> LDS (double buffered, next tile's loads issued before the MFMAs of the
-// current one, written to LDS after them: one barrier per r-tile).  What differs between the
-// uses is only the *loader* (how element (x, r) of an operand is found in memory) and the epilogue:
+// (BM/WM) x (BN/WN) block of 32x32 accumulator tiles.
 //
-//   conv fwd / dgrad : A = HWIO weights [r=(kh,kw,ci)][i=co]        (DenseKX)
-//                      B = implicit im2col gather [r][j=pixel]      (ConvGather), NCHW input
+// Measured on MI355X (tools/ubench/mfma_issue.hip): the fp32 MFMA sustains 156 TFLOP/s, LDS reads are
+// almost free beside it, but EVERY other vector-ALU instruction of a co-resident wave costs ~3-4 of
+// the MFMA's 64 issue cycles (+4 v_add per MFMA: 130 TF, +8: 112 TF) at any occupancy.  The steady
+// state of this kernel therefore contains (almost) no VALU address arithmetic:
+//   * global -> register staging uses raw buffer loads whose per-lane byte offset is a per-thread
+//     CONSTANT and whose per-tile part is a scalar (soffset, or a buffer resource rebuilt per tile
+//     with scalar ops); out-of-range lanes get an offset past num_records and read 0 in hardware;
+//   * im2col taps need no bounds tests when activations carry a zero halo (padded layout);
+//   * LDS is addressed with per-thread constant bases + immediates: the double buffer is unrolled
+//     by two so that buffer offsets are compile-time;
+//   * operand tiles live in LDS as [x][BR+2]: a lane's reduction elements are adjacent, so one
+//     ds_read_b64 feeds two MFMA steps (the reduction order is permuted identically for A and B),
+//     and both the b64 fragment reads and the b32 staging writes are bank-conflict free.
+//
+//   conv fwd / dgrad : A = HWIO weights [r=(kh,kw,ci)][i=co]               (DenseKX)
+//                      B = implicit im2col gather [r][j=pixel], NCHW input  (ConvGather)
 //                      epilogue writes NCHW (+bias, ReLU | ReluGrad mask)
 //   conv wgrad       : A = implicit im2col gather [i=(kh,kw,ci)][r=pixel]   (WgradGather)
 //                      B = dy [j=co][r=pixel]                               (DyRows)
@@ -18,154 +29,166 @@
 // MFMA operand maps (cdna_hip_programming.md section 3): lane l holds A[i = l&31][r = l>>5] and
 // B[r = l>>5][j = l&31]; D register q of lane l is D[i = (q&3) + 8*(q>>2) + 4*(l>>5)][j = l&31].
 // j is therefore the coalesced (lane) dimension of every store.
+#include <stdlib.h>
+
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 static constexpr int NT = 256;  // threads per workgroup
 
-// ---- LDS tile layouts -------------------------------------------------------------------------
-// KX: [r][x], x contiguous.  Fragment reads walk x across lanes 0..31 -> conflict free.
-template <int BX, int BR>
-struct LdsKX {
-    static constexpr int SIZE = BX * BR;
-    static __device__ __forceinline__ int idx(int x, int r) { return r * BX + x; }
-};
-// XK: [x][r] with an odd row stride so that fragment reads (x across lanes) are conflict free.
-template <int BX, int BR>
-struct LdsXK {
-    static constexpr int SIZE = BX * (BR + 1);
-    static __device__ __forceinline__ int idx(int x, int r) { return x * (BR + 1) + r; }
-};
-
-// ---- loaders ----------------------------------------------------------------------------------
-// Dense operand stored [r][x] (x contiguous in memory).
-template <int BX, int BR>
-struct DenseKX {
-    using L = LdsKX<BX, BR>;
-    static constexpr int NLD = BX * BR / NT;
-    static_assert(BX * BR % NT == 0, "tile must divide over 256 threads");
-    struct Params {
-        const float* p;
-        int64_t ld;
-        int X, R;
-        int64_t zg_stride;
-    };
-    const float* base;
-    int64_t ld;
-    int X, R, x0;
-    __device__ __forceinline__ void init(const Params& P, int x0_, int zg) {
-        base = P.p + (int64_t)zg * P.zg_stride;
-        ld = P.ld;
-        X = P.X;
-        R = P.R;
-        x0 = x0_;
-    }
-    __device__ __forceinline__ void prefetch(int) {}
-    __device__ __forceinline__ void load(int rt, float (&v)[NLD]) const {
-#pragma unroll
-        for (int j = 0; j < NLD; ++j) {
-            const int e = threadIdx.x + NT * j;
-            const int r = rt * BR + e / BX, x = x0 + e % BX;
-            v[j] = (r < R && x < X) ? base[(int64_t)r * ld + x] : 0.f;
-        }
-    }
-    __device__ __forceinline__ void store(float* lds, const float (&v)[NLD]) const {
-#pragma unroll
-        for (int j = 0; j < NLD; ++j) {
-            const int e = threadIdx.x + NT * j;
-            lds[L::idx(e % BX, e / BX)] = v[j];
-        }
-    }
-};
-
-// Dense operand stored [x][r] (r contiguous in memory).
-template <int BX, int BR>
-struct DenseXK {
-    using L = LdsXK<BX, BR>;
-    static constexpr int NLD = BX * BR / NT;
-    static_assert(BX * BR % NT == 0, "tile must divide over 256 threads");
-    struct Params {
-        const float* p;
-        int64_t ld;
-        int X, R;
-        int64_t zg_stride;
-    };
-    const float* base;
-    int64_t ld;
-    int X, R, x0;
-    __device__ __forceinline__ void init(const Params& P, int x0_, int zg) {
-        base = P.p + (int64_t)zg * P.zg_stride;
-        ld = P.ld;
-        X = P.X;
-        R = P.R;
-        x0 = x0_;
-    }
-    __device__ __forceinline__ void prefetch(int) {}
-    __device__ __forceinline__ void load(int rt, float (&v)[NLD]) const {
-#pragma unroll
-        for (int j = 0; j < NLD; ++j) {
-            const int e = threadIdx.x + NT * j;
-            const int r = rt * BR + e % BR, x = x0 + e / BR;
-            v[j] = (r < R && x < X) ? base[(int64_t)x * ld + r] : 0.f;
-        }
-    }
-    __device__ __forceinline__ void store(float* lds, const float (&v)[NLD]) const {
-#pragma unroll
-        for (int j = 0; j < NLD; ++j) {
-            const int e = threadIdx.x + NT * j;
-            lds[L::idx(e / BR, e % BR)] = v[j];
-        }
-    }
-};
-
-// Geometry shared by the im2col loaders.  ktab[k] = {offset (ci*H + kh)*W + kw, kh << 16 | kw};
-// entries past the real K carry kh = 0x4000 so that the bounds test fails (zero fill).
-struct ConvGeom {
-    const float* x;
-    const int2* ktab;
-    int K;              // im2col rows per group
-    int M;              // n * OH * OW pixels
-    int H, W;           // input plane
-    int stride, pt, pl;
-    int OHW, OW;
-    FastDiv dOHW, dOW;
-    int64_t img_stride;  // elements between images (Cin_total * H * W)
-    int64_t grp_stride;  // elements between groups (Cin_g * H * W)
-    int64_t total;       // elements in x (n * Cin_total * H * W); < 2^30 so byte offsets fit 32 bits
-};
-
-// Buffer-resource gather: every im2col element is fetched with a raw buffer load whose per-lane byte
-// offset is either the real offset or OOB_OFF; the hardware range check returns 0 for the latter, so
-// padding taps and tile tails cost no branch and no select.  Offsets are biased by (pt*W + pl)
-// elements so they are never negative (the resource base points that far before x).
-static constexpr uint32_t OOB_OFF = 0xFFFFFFF0u;
+// Byte offset that fails the buffer range check of every resource we build (num_records < 0xE0000000);
+// adding any per-element offset < 2^28 to it still fails and does not wrap.
+static constexpr uint32_t OOB_OFF = 0xF0000000u;
+static constexpr int64_t MAX_BUF_BYTES = 0xE0000000ll;
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, int64_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)(uint32_t)bytes, 0x00020000);
 }
-__device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0));
+__device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, uint32_t voff, int soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, soff, 0));
 }
 
-// im2col gather, reduction index r = im2col row, x = output pixel across lanes (coalesced along ow).
-// A wave owns NLD consecutive rows of the tile, so its table entries are one contiguous, aligned
-// block read with a single wide scalar load -- fetched one tile ahead of use.
+// LDS operand tile: [x][BR + 2] floats (x = non-reduction index, r = reduction index within the tile)
 template <int BX, int BR>
+struct LdsTile {
+    static constexpr int STR = BR + 2;
+    static constexpr int SIZE = BX * STR;
+};
+
+// ---- loaders ----------------------------------------------------------------------------------
+// Interface: init(P, x0, zg); prefetch(rt); load(rt, v[NLD]); store(tile_base, v[NLD]).
+
+// Dense operand stored [r][x] (x contiguous in memory); lanes walk x.
+template <int BX, int BR>
+struct DenseKX {
+    using L = LdsTile<BX, BR>;
+    static constexpr int NLD = BX * BR / NT;
+    static_assert(BX * BR % NT == 0, "tile must divide over 256 threads");
+    struct Params {
+        const float* p;
+        int64_t ld;
+        int X, R;
+        int64_t zg_stride;
+    };
+    const float* base;
+    int64_t step;            // elements per reduction tile
+    int64_t total;           // elements from base to the end of row R-1 (rows are ld apart)
+    uint32_t voff[NLD];
+    int loff[NLD];
+    __device__ __forceinline__ void init(const Params& P, int x0, int zg) {
+        base = P.p + (int64_t)zg * P.zg_stride;
+        step = (int64_t)BR * P.ld;
+        total = (int64_t)P.R * P.ld;
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int e = threadIdx.x + NT * j;
+            const int xl = e % BX, rl = e / BX;
+            voff[j] = (x0 + xl < P.X) ? (uint32_t)(((int64_t)rl * P.ld + x0 + xl) * 4) : OOB_OFF;
+            loff[j] = xl * L::STR + rl;
+        }
+    }
+    __device__ __forceinline__ void prefetch(int) {}
+    __device__ __forceinline__ void load(int rt, float (&v)[NLD]) const {
+        // resource rebuilt per tile with scalar ops: rows past R fail the range check and read 0
+        const int64_t done = (int64_t)rt * step;
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(base + done, (total - done) * 4);
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) v[j] = buf_load(rs, voff[j], 0);
+    }
+    __device__ __forceinline__ void store(float* tile, const float (&v)[NLD]) const {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) tile[loff[j]] = v[j];
+    }
+};
+
+// Dense operand stored [x][r] (r contiguous in memory); lanes walk r.
+template <int BX, int BR>
+struct DenseXK {
+    using L = LdsTile<BX, BR>;
+    static constexpr int NLD = BX * BR / NT;
+    static_assert(BX * BR % NT == 0, "tile must divide over 256 threads");
+    struct Params {
+        const float* p;
+        int64_t ld;
+        int X, R;
+        int64_t zg_stride;
+    };
+    const float* base;
+    int64_t total;
+    int R, rl;
+    uint32_t voff[NLD];
+    int loff[NLD];
+    __device__ __forceinline__ void init(const Params& P, int x0, int zg) {
+        base = P.p + (int64_t)zg * P.zg_stride;
+        total = (int64_t)(P.X - 1) * P.ld + P.R;   // last valid element + 1
+        R = P.R;
+        rl = threadIdx.x % BR;
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int xl = (int)(threadIdx.x + NT * j) / BR;
+            voff[j] = (x0 + xl < P.X) ? (uint32_t)(((int64_t)(x0 + xl) * P.ld + rl) * 4) : OOB_OFF;
+            loff[j] = xl * L::STR + rl;
+        }
+    }
+    __device__ __forceinline__ void prefetch(int) {}
+    __device__ __forceinline__ void load(int rt, float (&v)[NLD]) const {
+        const int r0 = rt * BR;
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(base + r0, (total - r0) * 4);
+        if (r0 + BR <= R) {   // uniform: whole tile inside the reduction range
+#pragma unroll
+            for (int j = 0; j < NLD; ++j) v[j] = buf_load(rs, voff[j], 0);
+        } else {              // last partial tile: columns past R belong to the next row, mask them
+            const bool ok = r0 + rl < R;
+#pragma unroll
+            for (int j = 0; j < NLD; ++j) v[j] = buf_load(rs, ok ? voff[j] : OOB_OFF, 0);
+        }
+    }
+    __device__ __forceinline__ void store(float* tile, const float (&v)[NLD]) const {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) tile[loff[j]] = v[j];
+    }
+};
+
+// Geometry shared by the im2col loaders.  The gathered tensor is NCHW with a zero halo of `halo`
+// pixels on every side of each plane (physical plane (H + 2 halo) x (W + 2 halo)).
+//   padded mode  (halo >= SAME padding): ktab[k] = byte offset (ci*Pp + kh*Wp + kw)*4, no tests.
+//   checked mode (halo too small, e.g. 0): ktab2[k] = {that offset, kh << 16 | kw}; taps outside the
+//                 logical plane are replaced by OOB_OFF with two compares per element.
+struct ConvGeom {
+    const float* x;
+    const int* ktab;     // padded mode
+    const int2* ktab2;   // checked mode
+    int K;               // im2col rows per group
+    int M;               // n * OH * OW output pixels
+    int H, W;            // logical input plane
+    int halo, Wp;        // physical row pitch
+    int stride, pt, pl;
+    int OHW, OW;
+    FastDiv dOHW, dOW;
+    int64_t img_stride;  // elements between images   (Cin_total * Pp)
+    int64_t grp_stride;  // elements between groups   (Cin_g * Pp)
+    int64_t total;       // elements in x
+};
+
+// im2col gather for forward / dgrad: x = output pixel across lanes (coalesced along ow), r = im2col
+// row.  A wave owns NLD consecutive rows of the tile: its table entries are one aligned block read
+// with one wide scalar load, fetched a tile ahead, and used as the load's scalar offset.
+template <int BX, int BR, bool PADDED>
 struct ConvGather {
-    using L = LdsKX<BX, BR>;
+    using L = LdsTile<BX, BR>;
     static constexpr int NLD = BX * BR / NT;   // rows per wave
     static_assert(BX % 64 == 0, "pixel tile must be a multiple of the wave size");
     static_assert(NLD * (NT / BX) == BR, "rows must split evenly over the wave groups");
     using Params = ConvGeom;
     __amdgpu_buffer_rsrc_t rsrc;
-    const int2* tab;     // this wave's first row of the current tile
-    int2 ent[NLD];       // entries of the tile about to be loaded (prefetched)
-    uint32_t voff;       // biased byte offset of (n, ih0, iw0)
-    int ih0, iw0, H, W, row0;
-    bool vm;
+    const int* tab;
+    const int2* tab2;
+    int ent[NLD], ent_hw[NLD];
+    uint32_t voff;
+    int ih0, iw0, H, W, lbase;
     __device__ __forceinline__ void init(const Params& P, int x0, int zg) {
         const int m = x0 + threadIdx.x % BX;
-        vm = m < P.M;
+        const bool vm = m < P.M;
         const uint32_t mm = vm ? m : 0;
         const uint32_t n = fd_div(mm, P.dOHW);
         const uint32_t p = mm - n * P.OHW;
@@ -175,61 +198,83 @@ struct ConvGather {
         iw0 = (int)ow * P.stride - P.pl;
         H = P.H;
         W = P.W;
-        const int bias = P.pt * P.W + P.pl;
-        const int ih0_real = ih0;
+        // checked mode may point up to (pt, pl) before the plane origin: bias the base so offsets stay >= 0
+        const int bias = PADDED ? 0 : P.pt * P.Wp + P.pl;
         rsrc = make_rsrc(P.x + (int64_t)zg * P.grp_stride - bias, (P.total - (int64_t)zg * P.grp_stride + bias) * 4);
-        voff = (uint32_t)((int64_t)n * P.img_stride + (int64_t)ih0_real * P.W + iw0 + bias) * 4u;
-        if (!vm) ih0 = 1 << 28;   // a pixel past the end fails every row test below: no separate predicate
-        row0 = __builtin_amdgcn_readfirstlane((int)threadIdx.x / BX) * NLD;
+        const int64_t o = (int64_t)n * P.img_stride + (int64_t)(ih0 + P.halo) * P.Wp + (iw0 + P.halo) + bias;
+        voff = vm ? (uint32_t)o * 4u : OOB_OFF;
+        if (!vm) ih0 = 1 << 28;   // checked mode: every row test fails
+        const int row0 = __builtin_amdgcn_readfirstlane((int)threadIdx.x / BX) * NLD;
         tab = P.ktab + row0;
+        tab2 = P.ktab2 + row0;
+        lbase = (threadIdx.x % BX) * L::STR + row0;
     }
     __device__ __forceinline__ void prefetch(int rt) {
 #pragma unroll
-        for (int j = 0; j < NLD; ++j) ent[j] = tab[rt * BR + j];
+        for (int j = 0; j < NLD; ++j) {
+            if (PADDED) {
+                ent[j] = tab[rt * BR + j];
+            } else {
+                const int2 e = tab2[rt * BR + j];
+                ent[j] = e.x;
+                ent_hw[j] = e.y;
+            }
+        }
     }
     __device__ __forceinline__ void load(int rt, float (&v)[NLD]) {
 #pragma unroll
         for (int j = 0; j < NLD; ++j) {
-            const int ih = ih0 + (ent[j].y >> 16), iw = iw0 + (ent[j].y & 0xffff);
-            const bool ok = ((unsigned)ih < (unsigned)H) & ((unsigned)iw < (unsigned)W);
-            v[j] = buf_load(rsrc, ok ? voff + (uint32_t)ent[j].x * 4u : OOB_OFF);
+            if (PADDED) {
+                v[j] = buf_load(rsrc, voff, ent[j]);
+            } else {
+                const int ih = ih0 + (ent_hw[j] >> 16), iw = iw0 + (ent_hw[j] & 0xffff);
+                const bool ok = ((unsigned)ih < (unsigned)H) & ((unsigned)iw < (unsigned)W);
+                v[j] = buf_load(rsrc, ok ? voff : OOB_OFF, ent[j]);
+            }
         }
-        prefetch(rt + 1);   // the table is padded by a whole tile, reading one past the end is safe
+        prefetch(rt + 1);   // tables are padded by more than a tile: reading one past the end is safe
     }
-    __device__ __forceinline__ void store(float* lds, const float (&v)[NLD]) const {
-        const int xl = threadIdx.x % BX;
+    __device__ __forceinline__ void store(float* tile, const float (&v)[NLD]) const {
 #pragma unroll
-        for (int j = 0; j < NLD; ++j) lds[L::idx(xl, row0 + j)] = v[j];
+        for (int j = 0; j < NLD; ++j) tile[lbase + j] = v[j];
     }
 };
 
 // im2col gather for wgrad: x = im2col row (fixed per thread: table entries live in registers),
 // reduction index r = output pixel across lanes.
-template <int BX, int BR>
+template <int BX, int BR, bool PADDED>
 struct WgradGather {
-    using L = LdsXK<BX, BR>;
+    using L = LdsTile<BX, BR>;
     static constexpr int NLD = BX * BR / NT;
     using Params = ConvGeom;
     __amdgpu_buffer_rsrc_t rsrc;
-    uint32_t off[NLD];   // byte offsets (ci*H + kh)*W + kw
+    uint32_t off[NLD];
     int khkw[NLD];
-    int H, W, M, OHW, OW, stride, pt, pl, bias;
+    int loff[NLD];
+    int H, W, M, OHW, OW, stride, pt, pl, bias, halo, Wp;
     FastDiv dOHW, dOW;
     int64_t img_stride;
     __device__ __forceinline__ void init(const Params& P, int x0, int zg) {
 #pragma unroll
         for (int j = 0; j < NLD; ++j) {
-            const int2 e = P.ktab[x0 + (int)(threadIdx.x + NT * j) / BR];
-            off[j] = (uint32_t)e.x * 4u;
-            khkw[j] = e.y;
+            const int xl = (int)(threadIdx.x + NT * j) / BR;
+            if (PADDED) {
+                off[j] = (uint32_t)P.ktab[x0 + xl];
+            } else {
+                const int2 e = P.ktab2[x0 + xl];
+                off[j] = (uint32_t)e.x;
+                khkw[j] = e.y;
+            }
+            loff[j] = xl * L::STR + threadIdx.x % BR;
         }
-        bias = P.pt * P.W + P.pl;
+        bias = PADDED ? 0 : P.pt * P.Wp + P.pl;
         rsrc = make_rsrc(P.x + (int64_t)zg * P.grp_stride - bias, (P.total - (int64_t)zg * P.grp_stride + bias) * 4);
         H = P.H; W = P.W; M = P.M; OHW = P.OHW; OW = P.OW;
-        stride = P.stride; pt = P.pt; pl = P.pl;
+        stride = P.stride; pt = P.pt; pl = P.pl; halo = P.halo; Wp = P.Wp;
         dOHW = P.dOHW; dOW = P.dOW;
         img_stride = P.img_stride;
     }
+    __device__ __forceinline__ void prefetch(int) {}
     __device__ __forceinline__ void load(int rt, float (&v)[NLD]) const {
         const int m = rt * BR + threadIdx.x % BR;
         const bool vm = m < M;
@@ -239,73 +284,85 @@ struct WgradGather {
         const uint32_t oh = fd_div(p, dOW);
         const uint32_t ow = p - oh * OW;
         const int ih0r = (int)oh * stride - pt, iw0 = (int)ow * stride - pl;
-        const uint32_t voff = (uint32_t)((int64_t)n * img_stride + (int64_t)ih0r * W + iw0 + bias) * 4u;
-        const int ih0 = vm ? ih0r : (1 << 28);
+        const uint32_t vo = (uint32_t)((int64_t)n * img_stride + (int64_t)(ih0r + halo) * Wp + (iw0 + halo) + bias) * 4u;
+        const uint32_t voff = vm ? vo : OOB_OFF;
+        if (PADDED) {
 #pragma unroll
-        for (int j = 0; j < NLD; ++j) {
-            const int ih = ih0 + (khkw[j] >> 16), iw = iw0 + (khkw[j] & 0xffff);
-            const bool ok = ((unsigned)ih < (unsigned)H) & ((unsigned)iw < (unsigned)W);
-            v[j] = buf_load(rsrc, ok ? voff + off[j] : OOB_OFF);
+            for (int j = 0; j < NLD; ++j) v[j] = buf_load(rsrc, voff + off[j], 0);
+        } else {
+            const int ih0 = vm ? ih0r : (1 << 28);
+#pragma unroll
+            for (int j = 0; j < NLD; ++j) {
+                const int ih = ih0 + (khkw[j] >> 16), iw = iw0 + (khkw[j] & 0xffff);
+                const bool ok = ((unsigned)ih < (unsigned)H) & ((unsigned)iw < (unsigned)W);
+                v[j] = buf_load(rsrc, ok ? voff + off[j] : OOB_OFF, 0);
+            }
         }
     }
-    __device__ __forceinline__ void prefetch(int) {}
-    __device__ __forceinline__ void store(float* lds, const float (&v)[NLD]) const {
+    __device__ __forceinline__ void store(float* tile, const float (&v)[NLD]) const {
 #pragma unroll
-        for (int j = 0; j < NLD; ++j) {
-            const int e = threadIdx.x + NT * j;
-            lds[L::idx(e / BR, e % BR)] = v[j];
-        }
+        for (int j = 0; j < NLD; ++j) tile[loff[j]] = v[j];
     }
 };
 
 // dy rows for wgrad: x = output channel (within the group), r = output pixel across lanes.
-// dy is NCHW [n][Cout_total][OHW].
+// dy is NCHW [n][Cout_total][OH + 2 halo][OW + 2 halo].
 template <int BX, int BR>
 struct DyRows {
-    using L = LdsXK<BX, BR>;
+    using L = LdsTile<BX, BR>;
     static constexpr int NLD = BX * BR / NT;
     struct Params {
         const float* dy;
-        int M, OHW, Cog, Cout_total;
-        FastDiv dOHW;
+        int M, OHW, OW, Cog, Cout_total, halo, OWp;
+        FastDiv dOHW, dOW;
+        int64_t plane;   // (OH + 2 halo) * OWp
         int64_t total;   // elements in dy
     };
     __amdgpu_buffer_rsrc_t rsrc;
-    uint32_t co_off[NLD];   // byte offset of the row's channel plane
-    bool co_ok[NLD];        // channel inside the group
-    int M, OHW;
+    uint32_t co_off[NLD];
+    bool co_ok[NLD];
+    int loff[NLD];
+    bool all_ok;
+    int M, OHW, OW, halo, OWp;
     int64_t img_stride;
-    FastDiv dOHW;
+    FastDiv dOHW, dOW;
     __device__ __forceinline__ void init(const Params& P, int x0, int zg) {
-        const int64_t goff = (int64_t)zg * P.Cog * P.OHW;
+        const int64_t goff = (int64_t)zg * P.Cog * P.plane;
         rsrc = make_rsrc(P.dy + goff, (P.total - goff) * 4);
-        M = P.M; OHW = P.OHW;
-        img_stride = (int64_t)P.Cout_total * P.OHW;
-        dOHW = P.dOHW;
+        M = P.M; OHW = P.OHW; OW = P.OW; halo = P.halo; OWp = P.OWp;
+        img_stride = (int64_t)P.Cout_total * P.plane;
+        dOHW = P.dOHW; dOW = P.dOW;
+        all_ok = x0 + BX <= P.Cog;   // uniform
 #pragma unroll
         for (int j = 0; j < NLD; ++j) {
-            const int co = x0 + (int)(threadIdx.x + NT * j) / BR;
-            co_ok[j] = co < P.Cog;
-            co_off[j] = (uint32_t)co * (uint32_t)P.OHW * 4u;
+            const int xl = (int)(threadIdx.x + NT * j) / BR;
+            co_ok[j] = x0 + xl < P.Cog;
+            co_off[j] = (uint32_t)((int64_t)(x0 + xl) * P.plane * 4);
+            loff[j] = xl * L::STR + threadIdx.x % BR;
         }
     }
+    __device__ __forceinline__ void prefetch(int) {}
     __device__ __forceinline__ void load(int rt, float (&v)[NLD]) const {
         const int m = rt * BR + threadIdx.x % BR;
         const bool vm = m < M;
         const uint32_t mm = vm ? m : 0;
         const uint32_t n = fd_div(mm, dOHW);
         const uint32_t p = mm - n * OHW;
-        const uint32_t voff = (uint32_t)((int64_t)n * img_stride + p) * 4u;
+        const uint32_t oh = fd_div(p, dOW);
+        const uint32_t ow = p - oh * OW;
+        const uint32_t vo = (uint32_t)((int64_t)n * img_stride + (int64_t)(oh + halo) * OWp + ow + halo) * 4u;
+        const uint32_t voff = vm ? vo : OOB_OFF;
+        if (all_ok) {
 #pragma unroll
-        for (int j = 0; j < NLD; ++j) v[j] = buf_load(rsrc, (vm & co_ok[j]) ? voff + co_off[j] : OOB_OFF);
-    }
-    __device__ __forceinline__ void prefetch(int) {}
-    __device__ __forceinline__ void store(float* lds, const float (&v)[NLD]) const {
+            for (int j = 0; j < NLD; ++j) v[j] = buf_load(rsrc, voff + co_off[j], 0);
+        } else {
 #pragma unroll
-        for (int j = 0; j < NLD; ++j) {
-            const int e = threadIdx.x + NT * j;
-            lds[L::idx(e / BR, e % BR)] = v[j];
+            for (int j = 0; j < NLD; ++j) v[j] = buf_load(rsrc, co_ok[j] ? voff + co_off[j] : OOB_OFF, 0);
         }
+    }
+    __device__ __forceinline__ void store(float* tile, const float (&v)[NLD]) const {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) tile[loff[j]] = v[j];
     }
 };
 
@@ -349,15 +406,19 @@ struct EpiRowMajor {
     }
 };
 
-// NCHW conv output: i = output channel within the group, j = output pixel.
+// NCHW conv output with halo: i = output channel within the group, j = output pixel.
 struct EpiConvNCHW {
     struct Params {
         float* y;
         const float* bias;  // [Cout_total] or null
-        const float* mask;  // NCHW like y or null
+        const float* mask;  // NCHW (its own halo) or null
         int relu;
-        int Cog, Cout_total, OHW, M;
-        FastDiv dOHW;
+        int Cog, Cout_total, OHW, OW, M;
+        FastDiv dOHW, dOW;
+        int y_halo, y_wp;
+        int64_t y_plane;
+        int m_halo, m_wp;
+        int64_t m_plane;
     };
     template <int TM, int TN>
     static __device__ __forceinline__ void apply(const Params& P, int zg, int zs, int i0, int j0, f32x16 (&acc)[TM][TN]) {
@@ -368,7 +429,11 @@ struct EpiConvNCHW {
             if (m >= P.M) continue;
             const uint32_t n = fd_div((uint32_t)m, P.dOHW);
             const uint32_t p = m - n * P.OHW;
-            const int64_t base = ((int64_t)n * P.Cout_total + (int64_t)zg * P.Cog) * P.OHW + p;
+            const uint32_t oh = fd_div(p, P.dOW);
+            const uint32_t ow = p - oh * P.OW;
+            const int64_t c0 = (int64_t)n * P.Cout_total + (int64_t)zg * P.Cog;
+            const int64_t ybase = c0 * P.y_plane + (int64_t)(oh + P.y_halo) * P.y_wp + ow + P.y_halo;
+            const int64_t mbase = c0 * P.m_plane + (int64_t)(oh + P.m_halo) * P.m_wp + ow + P.m_halo;
 #pragma unroll
             for (int ti = 0; ti < TM; ++ti) {
 #pragma unroll
@@ -378,9 +443,8 @@ struct EpiConvNCHW {
                         float v = acc[ti][tj][q];
                         if (P.bias) v += P.bias[zg * P.Cog + co];
                         if (P.relu) v = fmaxf(v, 0.f);
-                        const int64_t o = base + (int64_t)co * P.OHW;
-                        if (P.mask) v = P.mask[o] > 0.f ? v : 0.f;
-                        P.y[o] = v;
+                        if (P.mask) v = P.mask[mbase + (int64_t)co * P.m_plane] > 0.f ? v : 0.f;
+                        P.y[ybase + (int64_t)co * P.y_plane] = v;
                     }
                 }
             }
@@ -395,10 +459,12 @@ __global__ __launch_bounds__(NT) void mfma_contract(const typename LA::Params pa
                                                     const typename EP::Params pe, int tiles_i, int rtiles,
                                                     int rt_per_split) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
+    static_assert(BR % 4 == 0, "two MFMA steps per 8-byte fragment read");
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     static_assert(TM * WM * 32 == BM && TN * WN * 32 == BN, "tile shape");
-    constexpr int SA = LA::L::SIZE, SB = LB::L::SIZE;
-    __shared__ float lds[2 * (SA + SB)];
+    constexpr int STR = BR + 2;
+    constexpr int SA = BM * STR, SB = BN * STR;
+    __shared__ __attribute__((aligned(16))) float lds[2 * (SA + SB)];
 
     const int ti_blk = blockIdx.x % tiles_i, tj_blk = blockIdx.x / tiles_i;
     const int zg = blockIdx.y, zs = blockIdx.z;
@@ -420,6 +486,30 @@ __global__ __launch_bounds__(NT) void mfma_contract(const typename LA::Params pa
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
 
+    // Fragment addresses: lane half h = lane>>5 consumes, at MFMA step s, the tile's reduction element
+    // 4*(s>>1) + 2*h + (s&1) (the same permutation for A and B), i.e. 8 consecutive bytes per step pair.
+    const float* fa = lds + (wi0 + (lane & 31)) * STR + 2 * (lane >> 5);
+    const float* fb = lds + SA + (wj0 + (lane & 31)) * STR + 2 * (lane >> 5);
+
+    auto compute = [&](const int cur) {   // cur is a literal at both call sites
+#pragma unroll
+        for (int t = 0; t < BR / 4; ++t) {
+            float2 af[TM], bf[TN];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) af[a] = *reinterpret_cast<const float2*>(fa + cur * (SA + SB) + a * 32 * STR + 4 * t);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) bf[b] = *reinterpret_cast<const float2*>(fb + cur * (SA + SB) + b * 32 * STR + 4 * t);
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].x, bf[b].x, acc[a][b], 0, 0, 0);
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].y, bf[b].y, acc[a][b], 0, 0, 0);
+        }
+    };
+
     const int rt0 = zs * rt_per_split;
     const int rt1 = min(rtiles, rt0 + rt_per_split);
 
@@ -433,36 +523,36 @@ __global__ __launch_bounds__(NT) void mfma_contract(const typename LA::Params pa
         lb.store(lds + SA, rb);
     }
     __syncthreads();
-    for (int rt = rt0; rt < rt1; ++rt) {
-        const int cur = (rt - rt0) & 1;
-        const float* A = lds + cur * (SA + SB);
-        const float* B = A + SA;
-        const bool more = rt + 1 < rt1;
+    // Tile rt0 + i lives in LDS buffer i & 1.  The loop is unrolled by two so that every LDS address is a
+    // per-thread constant plus an immediate; an odd trailing tile is computed after the loop.
+    const int ntiles = rt1 - rt0;
+    int rt = rt0;
+    for (int i = 0; i + 1 < ntiles; i += 2, rt += 2) {
+        // sched_barrier pins the phases: issue the next tile's loads FIRST (a whole tile of MFMAs hides
+        // their latency), then the MFMAs, then the LDS stores; hipcc otherwise sinks the loads to their use.
+        la.load(rt + 1, ra);
+        lb.load(rt + 1, rb);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(0);
+        __builtin_amdgcn_sched_barrier(0);
+        la.store(lds + (SA + SB), ra);
+        lb.store(lds + (SA + SB) + SA, rb);
+        __syncthreads();
+        const bool more = i + 2 < ntiles;
         if (more) {
-            la.load(rt + 1, ra);
-            lb.load(rt + 1, rb);
+            la.load(rt + 2, ra);
+            lb.load(rt + 2, rb);
         }
-#pragma unroll
-        for (int kk = 0; kk < BR / 2; ++kk) {
-            const int r = 2 * kk + (lane >> 5);
-            float af[TM], bf[TN];
-#pragma unroll
-            for (int a = 0; a < TM; ++a) af[a] = A[LA::L::idx(wi0 + 32 * a + (lane & 31), r)];
-#pragma unroll
-            for (int b = 0; b < TN; ++b) bf[b] = B[LB::L::idx(wj0 + 32 * b + (lane & 31), r)];
-#pragma unroll
-            for (int a = 0; a < TM; ++a)
-#pragma unroll
-                for (int b = 0; b < TN; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
-        }
+        __builtin_amdgcn_sched_barrier(0);
+        compute(1);
+        __builtin_amdgcn_sched_barrier(0);
         if (more) {
-            float* An = lds + (cur ^ 1) * (SA + SB);
-            la.store(An, ra);
-            lb.store(An + SA, rb);
+            la.store(lds, ra);
+            lb.store(lds + SA, rb);
         }
         __syncthreads();
     }
+    if (ntiles & 1) compute(0);
     EP::template apply<TM, TN>(pe, zg, zs, i0 + wi0, j0 + wj0, acc);
 }
 
@@ -489,42 +579,76 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ ws, float* __restr
 // ---- convolution descriptor -------------------------------------------------------------------
 struct vl_conv_desc {
     int cin, h, w, cout, kh, kw, stride, groups;
-    int oh, ow, pt, pl;
+    int oh, ow, pt, pl, pb, pr;   // SAME padding before / after
     int cig, cog;
-    int K;           // kh*kw*cig
-    int Kd;          // kh*kw*cog (dgrad reduction length)
-    int2* ktab_fwd;  // device, padded
-    int2* ktab_bwd;  // device, padded (stride 1 only), over dy planes
-    int ktab_len_fwd, ktab_len_bwd;
+    int K;    // kh*kw*cig
+    int Kd;   // kh*kw*cog (dgrad reduction length)
+    int x_halo, y_halo, dy_halo, dx_halo;
+    int2* ktab2_fwd;  // checked-mode tables (device), halo-aware offsets
+    int2* ktab2_bwd;
+    int* ktab_fwd;    // padded-mode tables
+    int* ktab_bwd;
+    int fwd_padded, bwd_padded;
 };
 
-static void tf_same_pad(int in, int k, int s, int* out, int* before) {
+static void tf_same_pad(int in, int k, int s, int* out, int* before, int* after) {
     *out = (in + s - 1) / s;
     int total = (*out - 1) * s + k - in;
     if (total < 0) total = 0;
     *before = total / 2;
+    *after = total - *before;
 }
 
-static int build_ktab(int2** dev, int* len, int kh, int kw, int cg, int H, int W) {
+// tables over planes of physical size (H + 2 halo) x (W + 2 halo); rows ordered (kh, kw, c) like HWIO
+static int build_ktabs(int** dev1, int2** dev2, int kh, int kw, int cg, int H, int W, int halo) {
     const int K = kh * kw * cg;
-    const int pad = ((K + 127) / 128) * 128 + 128;
-    int2* host = (int2*)malloc(sizeof(int2) * pad);
-    if (!host) return 1;
+    const int pad = ((K + 127) / 128) * 128 + 256;
+    const int Wp = W + 2 * halo;
+    const int64_t Pp = (int64_t)(H + 2 * halo) * Wp;
+    int* h1 = (int*)malloc(sizeof(int) * pad);
+    int2* h2 = (int2*)malloc(sizeof(int2) * pad);
+    if (!h1 || !h2) {
+        free(h1);
+        free(h2);
+        return 1;
+    }
     for (int k = 0; k < pad; ++k) {
         if (k < K) {
-            const int c = k % cg, kx = (k / cg) % kw, ky = k / (cg * kw);  // HWIO row order (kh, kw, ci)
-            host[k].x = (c * H + ky) * W + kx;
-            host[k].y = (ky << 16) | kx;
+            const int c = k % cg, kx = (k / cg) % kw, ky = k / (cg * kw);
+            const int64_t off = ((int64_t)c * Pp + (int64_t)ky * Wp + kx) * 4;
+            h1[k] = (int)off;
+            h2[k].x = (int)off;
+            h2[k].y = (ky << 16) | kx;
         } else {
-            host[k].x = 0;
-            host[k].y = 0x4000 << 16;
+            h1[k] = 0;               // padded mode: a valid address; the weight row is zero (range check)
+            h2[k].x = 0;
+            h2[k].y = 0x4000 << 16;  // checked mode: fails the row test
         }
     }
-    hipError_t e = hipMalloc((void**)dev, sizeof(int2) * pad);
-    if (e == hipSuccess) e = hipMemcpy(*dev, host, sizeof(int2) * pad, hipMemcpyHostToDevice);
-    free(host);
-    *len = pad;
+    if (*dev1) (void)hipFree(*dev1);
+    if (*dev2) (void)hipFree(*dev2);
+    *dev1 = nullptr;
+    *dev2 = nullptr;
+    hipError_t e = hipMalloc((void**)dev1, sizeof(int) * pad);
+    if (e == hipSuccess) e = hipMalloc((void**)dev2, sizeof(int2) * pad);
+    if (e == hipSuccess) e = hipMemcpy(*dev1, h1, sizeof(int) * pad, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(*dev2, h2, sizeof(int2) * pad, hipMemcpyHostToDevice);
+    free(h1);
+    free(h2);
     return e == hipSuccess ? 0 : 2;
+}
+
+static int rebuild_tables(vl_conv_desc* d) {
+    int rc = build_ktabs(&d->ktab_fwd, &d->ktab2_fwd, d->kh, d->kw, d->cig, d->h, d->w, d->x_halo);
+    d->fwd_padded = d->x_halo >= d->pt && d->x_halo >= d->pb && d->x_halo >= d->pl && d->x_halo >= d->pr;
+    if (rc == 0 && d->stride == 1) {
+        rc = build_ktabs(&d->ktab_bwd, &d->ktab2_bwd, d->kh, d->kw, d->cog, d->oh, d->ow, d->dy_halo);
+        // dgrad pads dy by K-1-pad before and by the forward pad-before after
+        const int need = (d->kh - 1 - d->pt > d->pt ? d->kh - 1 - d->pt : d->pt);
+        const int needw = (d->kw - 1 - d->pl > d->pl ? d->kw - 1 - d->pl : d->pl);
+        d->bwd_padded = d->dy_halo >= need && d->dy_halo >= needw;
+    }
+    return rc;
 }
 
 extern "C" int vl_conv_create(vl_conv_desc** out, int cin, int h, int w, int cout, int kh, int kw, int stride, int groups) {
@@ -535,15 +659,13 @@ extern "C" int vl_conv_create(vl_conv_desc** out, int cin, int h, int w, int cou
     vl_conv_desc* d = (vl_conv_desc*)calloc(1, sizeof(vl_conv_desc));
     VL_CHECK(d, "vl_conv_create: out of host memory");
     d->cin = cin; d->h = h; d->w = w; d->cout = cout; d->kh = kh; d->kw = kw; d->stride = stride; d->groups = groups;
-    tf_same_pad(h, kh, stride, &d->oh, &d->pt);
-    tf_same_pad(w, kw, stride, &d->ow, &d->pl);
+    tf_same_pad(h, kh, stride, &d->oh, &d->pt, &d->pb);
+    tf_same_pad(w, kw, stride, &d->ow, &d->pl, &d->pr);
     d->cig = cin / groups;
     d->cog = cout / groups;
     d->K = kh * kw * d->cig;
     d->Kd = kh * kw * d->cog;
-    int rc = build_ktab(&d->ktab_fwd, &d->ktab_len_fwd, kh, kw, d->cig, h, w);
-    if (rc == 0 && stride == 1) rc = build_ktab(&d->ktab_bwd, &d->ktab_len_bwd, kh, kw, d->cog, d->oh, d->ow);
-    if (rc) {
+    if (rebuild_tables(d)) {
         vl_conv_destroy(d);
         vl_set_error("vl_conv_create: device table allocation failed");
         return 2;
@@ -552,10 +674,21 @@ extern "C" int vl_conv_create(vl_conv_desc** out, int cin, int h, int w, int cou
     return 0;
 }
 
+extern "C" int vl_conv_set_halo(vl_conv_desc* d, int x_halo, int y_halo, int dy_halo, int dx_halo) {
+    VL_CHECK(d, "vl_conv_set_halo: null descriptor");
+    VL_CHECK(x_halo >= 0 && y_halo >= 0 && dy_halo >= 0 && dx_halo >= 0 && x_halo < 64 && y_halo < 64 && dy_halo < 64 && dx_halo < 64,
+             "vl_conv_set_halo: bad halo");
+    d->x_halo = x_halo; d->y_halo = y_halo; d->dy_halo = dy_halo; d->dx_halo = dx_halo;
+    VL_CHECK(rebuild_tables(d) == 0, "vl_conv_set_halo: device table allocation failed");
+    return 0;
+}
+
 extern "C" void vl_conv_destroy(vl_conv_desc* d) {
     if (!d) return;
     if (d->ktab_fwd) (void)hipFree(d->ktab_fwd);
     if (d->ktab_bwd) (void)hipFree(d->ktab_bwd);
+    if (d->ktab2_fwd) (void)hipFree(d->ktab2_fwd);
+    if (d->ktab2_bwd) (void)hipFree(d->ktab2_bwd);
     free(d);
 }
 
@@ -567,30 +700,56 @@ extern "C" int vl_conv_out_hw(const vl_conv_desc* d, int* oh, int* ow) {
 }
 
 // ---- conv forward / dgrad launch ---------------------------------------------------------------
-template <int BM, int WM, int WN>
+struct ConvOut {
+    float* y;
+    const float* bias;
+    const float* mask;
+    int relu;
+    int y_halo, m_halo, OH, OW;
+};
+
+template <int BM, int WM, int WN, bool PADDED>
 static int launch_conv(const ConvGeom& g, const float* w, int64_t w_ld, int w_grp_stride, int Cog, int Cout_total,
-                       const float* bias, const float* mask, int relu, float* y, hipStream_t s) {
+                       const ConvOut& o, hipStream_t s) {
     constexpr int BN = 128, BR = 16;
     using LA = DenseKX<BM, BR>;
-    using LB = ConvGather<BN, BR>;
+    using LB = ConvGather<BN, BR, PADDED>;
     typename LA::Params pa{w, w_ld, Cog, g.K, (int64_t)w_grp_stride};
-    EpiConvNCHW::Params pe{y, bias, mask, relu, Cog, Cout_total, g.OHW, g.M, g.dOHW};
+    EpiConvNCHW::Params pe;
+    pe.y = o.y; pe.bias = o.bias; pe.mask = o.mask; pe.relu = o.relu;
+    pe.Cog = Cog; pe.Cout_total = Cout_total; pe.OHW = g.OHW; pe.OW = g.OW; pe.M = g.M;
+    pe.dOHW = g.dOHW; pe.dOW = g.dOW;
+    pe.y_halo = o.y_halo; pe.y_wp = o.OW + 2 * o.y_halo; pe.y_plane = (int64_t)(o.OH + 2 * o.y_halo) * pe.y_wp;
+    pe.m_halo = o.m_halo; pe.m_wp = o.OW + 2 * o.m_halo; pe.m_plane = (int64_t)(o.OH + 2 * o.m_halo) * pe.m_wp;
     const int tiles_i = ceil_div(Cog, BM), tiles_j = ceil_div(g.M, BN);
     const int rtiles = ceil_div(g.K, BR);
     dim3 grid(tiles_i * tiles_j, (unsigned)(Cout_total / Cog), 1);
-    hipLaunchKernelGGL((mfma_contract<BM, BN, BR, WM, WN, LA, LB, EpiConvNCHW>), grid, dim3(NT), 0, s, pa, g, pe, tiles_i,
-                       rtiles, rtiles);
+    hipLaunchKernelGGL((mfma_contract<BM, BN, BR, WM, WN, LA, LB, EpiConvNCHW>), grid, dim3(NT), 0, s, pa, g, pe, tiles_i, rtiles,
+                       rtiles);
     VL_LAUNCH_CHECK();
     return 0;
 }
 
+template <bool PADDED>
 static int dispatch_conv(const ConvGeom& g, const float* w, int64_t w_ld, int w_grp_stride, int Cog, int Cout_total,
-                         const float* bias, const float* mask, int relu, float* y, hipStream_t s) {
+                         const ConvOut& o, hipStream_t s) {
     // output-channel tile: 128 when it divides well, else 96 (conv1: 96, conv4: 192) or 64 (conv2 dgrad: 48)
     const int w128 = ceil_div(Cog, 128) * 128, w96 = ceil_div(Cog, 96) * 96, w64 = ceil_div(Cog, 64) * 64;
-    if (w128 <= w96 && w128 <= w64) return launch_conv<128, 2, 2>(g, w, w_ld, w_grp_stride, Cog, Cout_total, bias, mask, relu, y, s);
-    if (w96 <= w64) return launch_conv<96, 1, 4>(g, w, w_ld, w_grp_stride, Cog, Cout_total, bias, mask, relu, y, s);
-    return launch_conv<64, 1, 4>(g, w, w_ld, w_grp_stride, Cog, Cout_total, bias, mask, relu, y, s);
+    if (w128 <= w96 && w128 <= w64) return launch_conv<128, 2, 2, PADDED>(g, w, w_ld, w_grp_stride, Cog, Cout_total, o, s);
+    if (w96 <= w64) return launch_conv<96, 1, 4, PADDED>(g, w, w_ld, w_grp_stride, Cog, Cout_total, o, s);
+    return launch_conv<64, 1, 4, PADDED>(g, w, w_ld, w_grp_stride, Cog, Cout_total, o, s);
+}
+
+static void fill_geom(ConvGeom& g, const float* x, int n, int cin_total, int cig, int H, int W, int halo, int OH, int OW,
+                      int stride, int pt, int pl, int K, const int* tab, const int2* tab2) {
+    g.x = x; g.ktab = tab; g.ktab2 = tab2; g.K = K; g.M = n * OH * OW; g.H = H; g.W = W;
+    g.halo = halo; g.Wp = W + 2 * halo;
+    g.stride = stride; g.pt = pt; g.pl = pl; g.OHW = OH * OW; g.OW = OW;
+    g.dOHW = make_fastdiv(g.OHW); g.dOW = make_fastdiv(g.OW);
+    const int64_t Pp = (int64_t)(H + 2 * halo) * g.Wp;
+    g.img_stride = (int64_t)cin_total * Pp;
+    g.grp_stride = (int64_t)cig * Pp;
+    g.total = g.img_stride * n;
 }
 
 extern "C" int vl_conv_fwd(const vl_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int n,
@@ -598,15 +757,12 @@ extern "C" int vl_conv_fwd(const vl_conv_desc* d, const float* x, const float* w
     VL_CHECK(d && x && w && y, "vl_conv_fwd: null argument");
     VL_CHECK(n > 0 && (int64_t)n * d->oh * d->ow < (1ll << 31), "vl_conv_fwd: bad batch %d", n);
     ConvGeom g;
-    g.x = x; g.ktab = d->ktab_fwd; g.K = d->K; g.M = n * d->oh * d->ow; g.H = d->h; g.W = d->w;
-    g.stride = d->stride; g.pt = d->pt; g.pl = d->pl; g.OHW = d->oh * d->ow; g.OW = d->ow;
-    g.dOHW = make_fastdiv(g.OHW); g.dOW = make_fastdiv(g.OW);
-    g.img_stride = (int64_t)d->cin * d->h * d->w;
-    g.grp_stride = (int64_t)d->cig * d->h * d->w;
-    g.total = g.img_stride * n;
-    VL_CHECK(g.total < (1ll << 30) - (1 << 20), "vl_conv_fwd: input of %lld elements exceeds the 4 GiB buffer-offset range", (long long)g.total);
+    fill_geom(g, x, n, d->cin, d->cig, d->h, d->w, d->x_halo, d->oh, d->ow, d->stride, d->pt, d->pl, d->K, d->ktab_fwd, d->ktab2_fwd);
+    VL_CHECK(g.total * 4 < MAX_BUF_BYTES, "vl_conv_fwd: input of %lld elements exceeds the buffer-offset range", (long long)g.total);
+    ConvOut o{y, bias, nullptr, relu, d->y_halo, 0, d->oh, d->ow};
     // HWIO weights are the [K][Cout_total] GEMM operand as they stand; group g = column block g*cog.
-    return dispatch_conv(g, w, d->cout, d->cog, d->cog, d->cout, bias, nullptr, relu, y, (hipStream_t)stream);
+    if (d->fwd_padded) return dispatch_conv<true>(g, w, d->cout, d->cog, d->cog, d->cout, o, (hipStream_t)stream);
+    return dispatch_conv<false>(g, w, d->cout, d->cog, d->cog, d->cout, o, (hipStream_t)stream);
 }
 
 __global__ void conv_wt_transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, int KH, int KW, int cig,
@@ -641,14 +797,12 @@ extern "C" int vl_conv_dgrad(const vl_conv_desc* d, const float* dy, const float
     VL_CHECK(n > 0 && (int64_t)n * d->h * d->w < (1ll << 31), "vl_conv_dgrad: bad batch %d", n);
     // dx = conv(dy, wt) with pad' = K-1-pad: the same kernel with the roles of the channel sets swapped.
     ConvGeom g;
-    g.x = dy; g.ktab = d->ktab_bwd; g.K = d->Kd; g.M = n * d->h * d->w; g.H = d->oh; g.W = d->ow;
-    g.stride = 1; g.pt = d->kh - 1 - d->pt; g.pl = d->kw - 1 - d->pl; g.OHW = d->h * d->w; g.OW = d->w;
-    g.dOHW = make_fastdiv(g.OHW); g.dOW = make_fastdiv(g.OW);
-    g.img_stride = (int64_t)d->cout * d->oh * d->ow;
-    g.grp_stride = (int64_t)d->cog * d->oh * d->ow;
-    g.total = g.img_stride * n;
-    VL_CHECK(g.total < (1ll << 30) - (1 << 20), "vl_conv_dgrad: dy of %lld elements exceeds the 4 GiB buffer-offset range", (long long)g.total);
-    return dispatch_conv(g, wt, d->cin, d->cig, d->cig, d->cin, nullptr, relu_mask, 0, dx, (hipStream_t)stream);
+    fill_geom(g, dy, n, d->cout, d->cog, d->oh, d->ow, d->dy_halo, d->h, d->w, 1, d->kh - 1 - d->pt, d->kw - 1 - d->pl, d->Kd,
+              d->ktab_bwd, d->ktab2_bwd);
+    VL_CHECK(g.total * 4 < MAX_BUF_BYTES, "vl_conv_dgrad: dy of %lld elements exceeds the buffer-offset range", (long long)g.total);
+    ConvOut o{dx, nullptr, relu_mask, 0, d->dx_halo, d->x_halo, d->h, d->w};
+    if (d->bwd_padded) return dispatch_conv<true>(g, wt, d->cin, d->cig, d->cig, d->cin, o, (hipStream_t)stream);
+    return dispatch_conv<false>(g, wt, d->cin, d->cig, d->cig, d->cin, o, (hipStream_t)stream);
 }
 
 // ---- conv wgrad -------------------------------------------------------------------------------
@@ -667,13 +821,17 @@ extern "C" size_t vl_conv_wgrad_ws_bytes(const vl_conv_desc* d, int n) {
     return (size_t)wgrad_splits(d, n) * d->K * d->cout * sizeof(float);
 }
 
-template <int BN, int WM, int WN>
+template <int BN, int WM, int WN, bool PADDED>
 static int launch_wgrad(const vl_conv_desc* d, const ConvGeom& g, const float* dy, float* dw, float* ws, int splits,
                         hipStream_t s) {
     constexpr int BM = 128, BR = 32;
-    using LA = WgradGather<BM, BR>;
+    using LA = WgradGather<BM, BR, PADDED>;
     using LB = DyRows<BN, BR>;
-    typename LB::Params pb{dy, g.M, g.OHW, d->cog, d->cout, g.dOHW, (int64_t)d->cout * g.M};
+    typename LB::Params pb;
+    pb.dy = dy; pb.M = g.M; pb.OHW = g.OHW; pb.OW = g.OW; pb.Cog = d->cog; pb.Cout_total = d->cout; pb.halo = d->dy_halo;
+    pb.OWp = d->ow + 2 * d->dy_halo; pb.dOHW = g.dOHW; pb.dOW = g.dOW;
+    pb.plane = (int64_t)(d->oh + 2 * d->dy_halo) * pb.OWp;
+    pb.total = (int64_t)d->cout * pb.plane * (g.M / g.OHW);
     const int64_t slab = (int64_t)d->K * d->cout;
     // slab z: [K][Cout_total], group g = column block
     EpiRowMajor::Params pe{splits > 1 ? ws : dw, d->cout, d->K, d->cog, nullptr, nullptr, 0, d->cog, splits > 1 ? slab : 0};
@@ -700,16 +858,16 @@ extern "C" int vl_conv_wgrad(const vl_conv_desc* d, const float* x, const float*
     VL_CHECK(splits == 1 || (ws && ws_bytes >= vl_conv_wgrad_ws_bytes(d, n)), "vl_conv_wgrad: workspace too small (%zu < %zu)",
              ws_bytes, vl_conv_wgrad_ws_bytes(d, n));
     ConvGeom g;
-    g.x = x; g.ktab = d->ktab_fwd; g.K = d->K; g.M = n * d->oh * d->ow; g.H = d->h; g.W = d->w;
-    g.stride = d->stride; g.pt = d->pt; g.pl = d->pl; g.OHW = d->oh * d->ow; g.OW = d->ow;
-    g.dOHW = make_fastdiv(g.OHW); g.dOW = make_fastdiv(g.OW);
-    g.img_stride = (int64_t)d->cin * d->h * d->w;
-    g.grp_stride = (int64_t)d->cig * d->h * d->w;
-    g.total = g.img_stride * n;
-    VL_CHECK(g.total < (1ll << 30) - (1 << 20) && (int64_t)n * d->cout * d->oh * d->ow < (1ll << 30),
-             "vl_conv_wgrad: operand exceeds the 4 GiB buffer-offset range");
-    if (d->cog % 128 == 0) return launch_wgrad<128, 2, 2>(d, g, dy, dw, (float*)ws, splits, (hipStream_t)stream);
-    return launch_wgrad<96, 4, 1>(d, g, dy, dw, (float*)ws, splits, (hipStream_t)stream);
+    fill_geom(g, x, n, d->cin, d->cig, d->h, d->w, d->x_halo, d->oh, d->ow, d->stride, d->pt, d->pl, d->K, d->ktab_fwd, d->ktab2_fwd);
+    const int64_t dy_total = (int64_t)n * d->cout * (d->oh + 2 * d->dy_halo) * (d->ow + 2 * d->dy_halo);
+    VL_CHECK(g.total * 4 < MAX_BUF_BYTES && dy_total * 4 < MAX_BUF_BYTES, "vl_conv_wgrad: operand exceeds the buffer-offset range");
+    hipStream_t s = (hipStream_t)stream;
+    if (d->cog % 128 == 0) {
+        if (d->fwd_padded) return launch_wgrad<128, 2, 2, true>(d, g, dy, dw, (float*)ws, splits, s);
+        return launch_wgrad<128, 2, 2, false>(d, g, dy, dw, (float*)ws, splits, s);
+    }
+    if (d->fwd_padded) return launch_wgrad<96, 4, 1, true>(d, g, dy, dw, (float*)ws, splits, s);
+    return launch_wgrad<96, 4, 1, false>(d, g, dy, dw, (float*)ws, splits, s);
 }
 
 // ---- dense GEMM -------------------------------------------------------------------------------
@@ -756,6 +914,9 @@ extern "C" int vl_gemm(int transa, int transb, int m, int n, int k, const float*
     VL_CHECK(a && b && c, "vl_gemm: null argument");
     VL_CHECK(m > 0 && n > 0 && k > 0, "vl_gemm: bad shape %d x %d x %d", m, n, k);
     VL_CHECK(lda >= (transa ? m : k) && ldb >= (transb ? k : n) && ldc >= n, "vl_gemm: leading dimension too small");
+    const int64_t ea = transa ? (int64_t)(k - 1) * lda + m : (int64_t)(m - 1) * lda + k;
+    const int64_t eb = transb ? (int64_t)(n - 1) * ldb + k : (int64_t)(k - 1) * ldb + n;
+    VL_CHECK(ea * 4 < MAX_BUF_BYTES && eb * 4 < MAX_BUF_BYTES, "vl_gemm: operand exceeds the buffer-offset range");
     const int bm = m <= 64 ? 64 : 128;
     const int tiles = ceil_div(m, bm) * ceil_div(n, 128);
     // split the reduction when the output alone cannot fill 256 CUs and a workspace was provided

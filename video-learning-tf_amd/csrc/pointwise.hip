@@ -13,8 +13,10 @@ static inline int grid_for(int64_t work, int threads, int cap) {
 // ---- input prep (dataset_.py:481-501) ---------------------------------------------------------
 __global__ void input_prep_u8_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst, int n, int rh, int rw, int oh,
                                      int ow, const int32_t* __restrict__ cy, const int32_t* __restrict__ cx,
-                                     const uint8_t* __restrict__ mir, const float* __restrict__ mean) {
+                                     const uint8_t* __restrict__ mir, const float* __restrict__ mean, int halo) {
     const int64_t plane = (int64_t)oh * ow, total = plane * n;
+    const int wp = ow + 2 * halo;
+    const int64_t pp = (int64_t)(oh + 2 * halo) * wp;
     const float m0 = mean ? mean[0] : 0.f, m1 = mean ? mean[1] : 0.f, m2 = mean ? mean[2] : 0.f;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int img = (int)(e / plane);
@@ -23,21 +25,21 @@ __global__ void input_prep_u8_kernel(const uint8_t* __restrict__ src, float* __r
         const int sy = y + (cy ? cy[img] : 0);
         const int sx = ((mir && mir[img]) ? ow - 1 - x : x) + (cx ? cx[img] : 0);
         const uint8_t* s = src + (((int64_t)img * rh + sy) * rw + sx) * 3;
-        float* d = dst + (int64_t)img * 3 * plane + p;
+        float* d = dst + (int64_t)img * 3 * pp + (int64_t)(y + halo) * wp + x + halo;
         d[0] = (float)s[0] - m0;
-        d[plane] = (float)s[1] - m1;
-        d[2 * plane] = (float)s[2] - m2;
+        d[pp] = (float)s[1] - m1;
+        d[2 * pp] = (float)s[2] - m2;
     }
 }
 
 extern "C" int vl_input_prep_u8(const uint8_t* src, float* dst, int n, int raw_h, int raw_w, int out_h, int out_w,
                                 const int32_t* crop_y, const int32_t* crop_x, const uint8_t* mirror, const float* mean_bgr,
-                                vl_stream_t stream) {
-    VL_CHECK(src && dst, "vl_input_prep_u8: null argument");
+                                int dst_halo, vl_stream_t stream) {
+    VL_CHECK(src && dst && dst_halo >= 0, "vl_input_prep_u8: bad argument");
     VL_CHECK(n > 0 && out_h > 0 && out_w > 0 && out_h <= raw_h && out_w <= raw_w, "vl_input_prep_u8: bad shape");
     const int64_t total = (int64_t)n * out_h * out_w;
     hipLaunchKernelGGL(input_prep_u8_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, (hipStream_t)stream, src, dst, n,
-                       raw_h, raw_w, out_h, out_w, crop_y, crop_x, mirror, mean_bgr);
+                       raw_h, raw_w, out_h, out_w, crop_y, crop_x, mirror, mean_bgr, dst_halo);
     VL_LAUNCH_CHECK();
     return 0;
 }
@@ -54,11 +56,24 @@ __global__ void permute3_kernel(const float* __restrict__ src, float* __restrict
     }
 }
 
-extern "C" int vl_nhwc_to_nchw(const float* src, float* dst, int n, int h, int w, int c, vl_stream_t stream) {
-    VL_CHECK(src && dst && n > 0 && h > 0 && w > 0 && c > 0, "vl_nhwc_to_nchw: bad argument");
-    const int64_t hw = (int64_t)h * w;
-    hipLaunchKernelGGL(permute3_kernel, dim3(grid_for(n * hw * c, 256, 8192)), dim3(256), 0, (hipStream_t)stream, src, dst,
-                       (int64_t)n, c, (int)hw, hw * c, (int64_t)1, (int64_t)c);
+__global__ void nhwc_to_nchw_halo_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, int h, int w, int c,
+                                         int halo) {
+    const int64_t total = (int64_t)n * c * h * w;
+    const int wp = w + 2 * halo;
+    const int64_t pp = (int64_t)(h + 2 * halo) * wp;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(e % w);
+        const int y = (int)((e / w) % h);
+        const int ch = (int)((e / ((int64_t)w * h)) % c);
+        const int64_t img = e / ((int64_t)w * h * c);
+        dst[(img * c + ch) * pp + (int64_t)(y + halo) * wp + x + halo] = src[((img * h + y) * w + x) * c + ch];
+    }
+}
+
+extern "C" int vl_nhwc_to_nchw(const float* src, float* dst, int n, int h, int w, int c, int dst_halo, vl_stream_t stream) {
+    VL_CHECK(src && dst && n > 0 && h > 0 && w > 0 && c > 0 && dst_halo >= 0, "vl_nhwc_to_nchw: bad argument");
+    hipLaunchKernelGGL(nhwc_to_nchw_halo_kernel, dim3(grid_for((int64_t)n * h * w * c, 256, 8192)), dim3(256), 0, (hipStream_t)stream,
+                       src, dst, n, h, w, c, dst_halo);
     VL_LAUNCH_CHECK();
     return 0;
 }
@@ -113,7 +128,7 @@ __global__ void lrn_fwd_kernel(const float* __restrict__ x, float* __restrict__ 
 
 template <int CH, int R>
 __global__ void lrn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, int n, int C,
-                               int HW, float alpha, float beta, float bias, int relu_fused) {
+                               int HW, float alpha, float beta, float bias, int relu_fused, int W, int halo) {
     const int64_t pos = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (pos >= (int64_t)n * HW) return;
     const int img = (int)(pos / HW);
@@ -128,6 +143,11 @@ __global__ void lrn_bwd_kernel(const float* __restrict__ x, const float* __restr
         const int c = c0 - 2 * R + i;
         xv[i] = (c >= 0 && c < C) ? xp[(int64_t)c * HW] : 0.f;
     }
+    // dx may carry a halo: plane pitch (H + 2 halo)(W + 2 halo), interior origin at (halo, halo)
+    const int py = p / W, px = p - py * W;
+    const int wp = W + 2 * halo;
+    const int64_t dpp = (int64_t)(HW / W + 2 * halo) * wp;
+    float* dxp = dx + (int64_t)img * C * dpp + (int64_t)(py + halo) * wp + px + halo;
     float t[CH + 2 * R];  // dy_c * x_c * s_c^(-beta-1) for c0-R .. c0+CH+R-1
     float u[CH];          // s_c^-beta for the owned channels
 #pragma unroll
@@ -151,7 +171,7 @@ __global__ void lrn_bwd_kernel(const float* __restrict__ x, const float* __restr
             const float xc = xv[i + 2 * R];
             float r = u[i] - 2.f * alpha * beta * xc * a;
             if (relu_fused) r = xc > 0.f ? r : 0.f;
-            dx[off + (int64_t)(c0 + i) * HW] = r;
+            dxp[(int64_t)(c0 + i) * dpp] = r;
         }
     }
 }
@@ -168,13 +188,14 @@ extern "C" int vl_lrn_fwd(const float* x, float* y, int n, int c, int hw, int ra
 }
 
 extern "C" int vl_lrn_bwd(const float* x, const float* dy, float* dx, int n, int c, int hw, int radius, float alpha, float beta,
-                          float bias, int relu_fused, vl_stream_t stream) {
+                          float bias, int relu_fused, int w, int dx_halo, vl_stream_t stream) {
     VL_CHECK(x && dy && dx && n > 0 && c > 0 && hw > 0, "vl_lrn_bwd: bad argument");
+    VL_CHECK(w > 0 && hw % w == 0 && dx_halo >= 0, "vl_lrn_bwd: plane width %d does not divide hw %d", w, hw);
     VL_CHECK(radius == 2, "vl_lrn_bwd: only depth_radius 2 is built (alexnet.py:81); got %d", radius);
     constexpr int CH = 16;
     dim3 grid(ceil_div((int64_t)n * hw, 256), ceil_div(c, CH));
     hipLaunchKernelGGL((lrn_bwd_kernel<CH, 2>), grid, dim3(256), 0, (hipStream_t)stream, x, dy, dx, n, c, hw, alpha, beta, bias,
-                       relu_fused);
+                       relu_fused, w, dx_halo);
     VL_LAUNCH_CHECK();
     return 0;
 }
@@ -208,8 +229,10 @@ __global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restric
 
 __global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ arg, float* __restrict__ dx,
                                    const float* __restrict__ mask, int n, int C, int H, int W, int OH, int OW, int k, int s,
-                                   int64_t ysn, int64_t ysc, int64_t ysh, int64_t ysw) {
+                                   int64_t ysn, int64_t ysc, int64_t ysh, int64_t ysw, int halo) {
     const int64_t total = (int64_t)n * C * H * W;
+    const int wp = W + 2 * halo;
+    const int64_t pp = (int64_t)(H + 2 * halo) * wp;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int iw = (int)(e % W);
         const int ih = (int)((e / W) % H);
@@ -229,7 +252,7 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* 
                     if ((int)arg[o] == (ih - oh * s) * k + (iw - ow * s)) acc += dy[o];
                 }
         }
-        dx[e] = acc;
+        dx[((int64_t)img * C + c) * pp + (int64_t)(ih + halo) * wp + iw + halo] = acc;
     }
 }
 
@@ -245,12 +268,13 @@ extern "C" int vl_maxpool_fwd(const float* x, float* y, uint8_t* argmax, int n, 
 }
 
 extern "C" int vl_maxpool_bwd(const float* dy, const uint8_t* argmax, float* dx, const float* relu_mask, int n, int c, int h,
-                              int w, int k, int s, int64_t ys_n, int64_t ys_c, int64_t ys_h, int64_t ys_w, vl_stream_t stream) {
-    VL_CHECK(dy && argmax && dx && n > 0 && c > 0 && k > 0 && s > 0 && h >= k && w >= k, "vl_maxpool_bwd: bad argument");
+                              int w, int k, int s, int64_t ys_n, int64_t ys_c, int64_t ys_h, int64_t ys_w, int dx_halo,
+                              vl_stream_t stream) {
+    VL_CHECK(dy && argmax && dx && n > 0 && c > 0 && k > 0 && s > 0 && h >= k && w >= k && dx_halo >= 0, "vl_maxpool_bwd: bad argument");
     const int oh = (h - k) / s + 1, ow = (w - k) / s + 1;
     const int64_t total = (int64_t)n * c * h * w;
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total, 256, 16384)), dim3(256), 0, (hipStream_t)stream, dy, argmax, dx,
-                       relu_mask, n, c, h, w, oh, ow, k, s, ys_n, ys_c, ys_h, ys_w);
+                       relu_mask, n, c, h, w, oh, ow, k, s, ys_n, ys_c, ys_h, ys_w, dx_halo);
     VL_LAUNCH_CHECK();
     return 0;
 }

@@ -152,38 +152,64 @@ class LRCNEngine:
         if cfg.optimizer == "adam" and training:
             self.adam_m, self.adam_v = torch.zeros(total, device=dev), torch.zeros(total, device=dev)
 
-        # ---- conv stack plan
+        # ---- conv stack plan.  Tensors a conv gathers from (its x, and the dy its dgrad reads) are stored
+        # with a zero halo equal to the conv's SAME padding, so the im2col gather is test-free (vltf.h).
+        def zbuf(n_, c_, h_, w_, halo, dtype=torch.float32):
+            return torch.zeros((n_, c_, h_ + 2 * halo, w_ + 2 * halo), dtype=dtype, device=dev)
+
         h, w, c = cfg.image_shape
-        self.x0 = buf(N, c, h, w)
+        convs = []
+        for name, kh, kw, co, s, g, lrn, pool in CONV_LAYERS:
+            conv = ops.Conv(c, h, w, co, kh, kw, s, g)
+            convs.append(conv)
+            h, w, c = conv.oh, conv.ow, co
+            if pool:
+                h, w = ops.pool_out(h), ops.pool_out(w)
+        pads = [cv.same_pad() for cv in convs]
+        h, w, c = cfg.image_shape
+        self.x0_halo = pads[0]
+        self.x0 = zbuf(N, c, h, w, self.x0_halo)
         self.layers = []
         max_w = 0
         ws_bytes = 4
-        for name, kh, kw, co, s, g, lrn, pool in CONV_LAYERS:
-            conv = ops.Conv(c, h, w, co, kh, kw, s, g)
+        for li, (name, kh, kw, co, s, g, lrn, pool) in enumerate(CONV_LAYERS):
+            conv = convs[li]
+            nxt = pads[li + 1] if li + 1 < len(convs) else 0
             L = dict(name=name, conv=conv, lrn=lrn, pool=pool, cin=c, h=h, w=w)
-            L["y"] = buf(N, co, conv.oh, conv.ow)
+            L["x_halo"] = pads[li]
+            L["y_halo"] = 0 if (lrn or pool) else nxt            # y feeds the next conv directly (conv3, conv4)
+            L["dy_halo"] = pads[li] if li > 0 else 0             # dy is gathered by this layer's dgrad (not conv1)
+            L["y"] = zbuf(N, co, conv.oh, conv.ow, L["y_halo"])
             if training:
-                L["dy"] = buf(N, co, conv.oh, conv.ow)
-                ws_bytes = max(ws_bytes, conv.wgrad_ws_bytes(N))
-            out = L["y"]
+                L["dy"] = zbuf(N, co, conv.oh, conv.ow, L["dy_halo"])
+            out, out_halo = L["y"], L["y_halo"]
             h, w, c = conv.oh, conv.ow, co
             if lrn:
                 L["l"] = buf(N, c, h, w)
-                out = L["l"]
+                out, out_halo = L["l"], 0
                 if training:
                     L["dl"] = buf(N, c, h, w)
             if pool:
                 ph, pw = ops.pool_out(h), ops.pool_out(w)
                 L["hwc"] = name == "conv5"       # pool5 writes the (h, w, c)-flat order fc6 reads (alexnet.py:228)
-                L["p"] = buf(N, ph, pw, c) if L["hwc"] else buf(N, c, ph, pw)
-                L["arg"] = buf(*L["p"].shape, dtype=torch.uint8)
+                L["p_halo"] = 0 if L["hwc"] else nxt
+                L["p"] = buf(N, ph, pw, c) if L["hwc"] else zbuf(N, c, ph, pw, L["p_halo"])
+                L["arg"] = torch.zeros(L["p"].shape, dtype=torch.uint8, device=dev)
                 if training:
-                    L["dp"] = buf(*L["p"].shape)
-                out = L["p"]
+                    L["dp"] = buf(N, ph, pw, c) if L["hwc"] else zbuf(N, c, ph, pw, L["p_halo"])   # same layout as p / arg
+                out, out_halo = L["p"], L["p_halo"]
                 h, w = ph, pw
-            L["out"] = out
+            L["out"], L["out_halo"] = out, out_halo
             max_w = max(max_w, kh * kw * (conv.cin // g) * co)
             self.layers.append(L)
+        for li, L in enumerate(self.layers):
+            prev = self.layers[li - 1] if li > 0 else None
+            dx_halo = 0
+            if prev is not None:                                 # dgrad writes into the previous layer's dp (pool) or dy
+                dx_halo = prev["p_halo"] if prev["pool"] else prev["dy_halo"]
+            L["conv"].set_halo(L["x_halo"], L["y_halo"], L["dy_halo"], dx_halo)
+            if training:
+                ws_bytes = max(ws_bytes, L["conv"].wgrad_ws_bytes(N))
         self.flat_dim = h * w * c
         self.f6 = buf(N, FC_DIM)
         self.f7 = buf(N, FC_DIM) if cfg.frame_encoding_layer != "fc6" else None
@@ -299,14 +325,14 @@ class LRCNEngine:
         if mean_bgr is not None:
             self.mean_dev.copy_(torch.as_tensor(np.asarray(mean_bgr, np.float32)), non_blocking=True)
             mean = self.mean_dev
-        ops.input_prep_u8(frames_u8, self.x0[:n], crop_y, crop_x, mirror, mean)
+        ops.input_prep_u8(frames_u8, self.x0[:n], crop_y, crop_x, mirror, mean, halo=self.x0_halo)
         return n, b
 
     def feed_f32_nhwc(self, frames):
         """The reference's placeholder format: float32 NHWC, already cropped / mean-subtracted (model.py:54)."""
         n = frames.shape[0]
         b = self._check_frames(n)
-        ops.nhwc_to_nchw(frames, self.x0[:n])
+        ops.nhwc_to_nchw(frames, self.x0[:n], halo=self.x0_halo)
         return n, b
 
     # ---- forward -------------------------------------------------------------------------------
@@ -321,7 +347,7 @@ class LRCNEngine:
                 ops.lrn_fwd(x, L["l"][:n], **LRN)
                 x = L["l"][:n]
             if L["pool"]:
-                ops.maxpool_fwd(x, L["p"][:n], L["arg"][:n], hwc=L["hwc"])
+                ops.maxpool_fwd(x, L["p"][:n], L["arg"][:n], hwc=L["hwc"], y_halo=L["p_halo"])
                 x = L["p"][:n]
         ops.gemm(x, P["dcnn/fc6W"], self.f6, n, FC_DIM, self.flat_dim, bias=P["dcnn/fc6b"], relu=True, ws=self.ws)
         if self.f7 is not None:
@@ -458,10 +484,10 @@ class LRCNEngine:
             x_in = self.layers[li - 1]["out"][:n] if li > 0 else self.x0[:n]
             dy = L["dy"][:n]
             if L["pool"] and L["lrn"]:
-                ops.maxpool_bwd(L["dp"][:n], L["arg"][:n], L["dl"][:n], hwc=L["hwc"])
-                ops.lrn_bwd(L["y"][:n], L["dl"][:n], dy, relu_fused=True, **LRN)
+                self._pool_bwd(L, n, L["dl"][:n], None, 0)
+                ops.lrn_bwd(L["y"][:n], L["dl"][:n], dy, relu_fused=True, dx_halo=L["dy_halo"], **LRN)
             elif L["pool"]:
-                ops.maxpool_bwd(L["dp"][:n], L["arg"][:n], dy, relu_mask=L["y"][:n], hwc=L["hwc"])
+                self._pool_bwd(L, n, dy, L["y"][:n], L["dy_halo"])
             # else: dy was written (ReluGrad fused) by the next layer's dgrad epilogue
             self._run(name + ".wgrad", conv.wgrad, x_in, dy, G["dcnn/%sW" % name], self.ws)
             ops.bias_grad_nchw(dy, G["dcnn/%sb" % name], sw)
@@ -474,6 +500,9 @@ class LRCNEngine:
                     self._run(name + ".dgrad", conv.dgrad, dy, self.wt, prev["dy"][:n], relu_mask=prev["y"][:n])
         if self.dp is not None:
             self.dp.reduce_async(self.g, *self.buckets[1])
+
+    def _pool_bwd(self, L, n, dx, relu_mask, dx_halo):
+        ops.maxpool_bwd(L["dp"][:n], L["arg"][:n], dx, relu_mask=relu_mask, hwc=L["hwc"], dy_halo=L["p_halo"], dx_halo=dx_halo)
 
     def _relu_mask_inplace(self, d, y, count):
         # rare path (classifier fc + early fusion): mask through the lrn-free identity of maxpool_bwd is not

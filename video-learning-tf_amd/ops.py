@@ -32,8 +32,8 @@ def _dense(*ts):
 
 
 # ---- input ---------------------------------------------------------------------------------------
-def input_prep_u8(src, dst, crop_y=None, crop_x=None, mirror=None, mean_bgr=None):
-    """src uint8 [n, raw_h, raw_w, 3] (HWC, BGR) -> dst f32 [n, 3, out_h, out_w] (dataset_.py:481-501)."""
+def input_prep_u8(src, dst, crop_y=None, crop_x=None, mirror=None, mean_bgr=None, halo=0):
+    """src uint8 [n, raw_h, raw_w, 3] (HWC, BGR) -> dst f32 [n, 3, out_h + 2 halo, out_w + 2 halo] (dataset_.py:481-501)."""
     if src.dtype != torch.uint8 or not src.is_cuda:
         raise _ffi.VltfError("input_prep_u8: src must be a device uint8 tensor")
     _f32(dst, mean_bgr)
@@ -41,14 +41,16 @@ def input_prep_u8(src, dst, crop_y=None, crop_x=None, mirror=None, mean_bgr=None
     n, rh, rw, c = src.shape
     if c != 3 or dst.shape[0] != n or dst.shape[1] != 3:
         raise _ffi.VltfError("input_prep_u8: shape mismatch %s -> %s" % (tuple(src.shape), tuple(dst.shape)))
-    _ffi.call("vl_input_prep_u8", _p(src), _p(dst), n, rh, rw, dst.shape[2], dst.shape[3], _p(crop_y), _p(crop_x),
-              _p(mirror), _p(mean_bgr), stream())
+    _ffi.call("vl_input_prep_u8", _p(src), _p(dst), n, rh, rw, dst.shape[2] - 2 * halo, dst.shape[3] - 2 * halo, _p(crop_y),
+              _p(crop_x), _p(mirror), _p(mean_bgr), halo, stream())
 
 
-def nhwc_to_nchw(src, dst):
+def nhwc_to_nchw(src, dst, halo=0):
     _f32(src, dst); _dense(src, dst)
     n, h, w, c = src.shape
-    _ffi.call("vl_nhwc_to_nchw", _p(src), _p(dst), n, h, w, c, stream())
+    if tuple(dst.shape) != (n, c, h + 2 * halo, w + 2 * halo):
+        raise _ffi.VltfError("nhwc_to_nchw: shape mismatch %s -> %s (halo %d)" % (tuple(src.shape), tuple(dst.shape), halo))
+    _ffi.call("vl_nhwc_to_nchw", _p(src), _p(dst), n, h, w, c, halo, stream())
 
 
 def nchw_to_nhwc(src, dst):
@@ -70,6 +72,23 @@ class Conv:
         _ffi.check(_ffi.lib().vl_conv_out_hw(self._d, C.byref(oh), C.byref(ow)), "vl_conv_out_hw")
         self.oh, self.ow = oh.value, ow.value
         self.w_shape = (kh, kw, cin // groups, cout)
+        self.x_halo = self.y_halo = self.dy_halo = self.dx_halo = 0
+
+    def same_pad(self):
+        """Largest SAME padding on any side (TF rule): the halo that makes the gather test-free."""
+        def one(n, k, s):
+            out = -(-n // s)
+            tot = max((out - 1) * s + k - n, 0)
+            return tot - tot // 2
+        return max(one(self.h, self.kh, self.stride), one(self.w, self.kw, self.stride))
+
+    def set_halo(self, x_halo=0, y_halo=0, dy_halo=0, dx_halo=0):
+        """Declare the zero-halo layouts of x / y / dy / dx (include/vltf.h: vl_conv_set_halo)."""
+        _ffi.call("vl_conv_set_halo", self._d, x_halo, y_halo, dy_halo, dx_halo)
+        self.x_halo, self.y_halo, self.dy_halo, self.dx_halo = x_halo, y_halo, dy_halo, dx_halo
+
+    def _shape(self, n, c, h, w, halo):
+        return (n, c, h + 2 * halo, w + 2 * halo)
 
     def __del__(self):
         try:
@@ -82,8 +101,10 @@ class Conv:
     def fwd(self, x, w, bias, y, relu=True):
         _f32(x, w, bias, y); _dense(x, w, bias, y)
         n = x.shape[0]
-        if tuple(x.shape[1:]) != (self.cin, self.h, self.w) or tuple(y.shape) != (n, self.cout, self.oh, self.ow):
-            raise _ffi.VltfError("conv.fwd: shape mismatch x=%s y=%s" % (tuple(x.shape), tuple(y.shape)))
+        if tuple(x.shape) != self._shape(n, self.cin, self.h, self.w, self.x_halo) or \
+                tuple(y.shape) != self._shape(n, self.cout, self.oh, self.ow, self.y_halo):
+            raise _ffi.VltfError("conv.fwd: shape mismatch x=%s y=%s (halos %d, %d)" % (tuple(x.shape), tuple(y.shape),
+                                                                                        self.x_halo, self.y_halo))
         _ffi.call("vl_conv_fwd", self._d, _p(x), _p(w), _p(bias), _p(y), n, int(relu), stream())
 
     def wt_transpose(self, w, wt):
@@ -92,6 +113,11 @@ class Conv:
 
     def dgrad(self, dy, wt, dx, relu_mask=None):
         _f32(dy, wt, dx, relu_mask); _dense(dy, wt, dx, relu_mask)
+        n = dy.shape[0]
+        if tuple(dy.shape) != self._shape(n, self.cout, self.oh, self.ow, self.dy_halo) or \
+                tuple(dx.shape) != self._shape(n, self.cin, self.h, self.w, self.dx_halo) or \
+                (relu_mask is not None and tuple(relu_mask.shape) != self._shape(n, self.cin, self.h, self.w, self.x_halo)):
+            raise _ffi.VltfError("conv.dgrad: shape mismatch dy=%s dx=%s" % (tuple(dy.shape), tuple(dx.shape)))
         _ffi.call("vl_conv_dgrad", self._d, _p(dy), _p(wt), _p(dx), _p(relu_mask), dy.shape[0], stream())
 
     def wgrad_ws_bytes(self, n):
@@ -99,6 +125,10 @@ class Conv:
 
     def wgrad(self, x, dy, dw, ws):
         _f32(x, dy, dw); _dense(x, dy, dw, ws)
+        n = x.shape[0]
+        if tuple(x.shape) != self._shape(n, self.cin, self.h, self.w, self.x_halo) or \
+                tuple(dy.shape) != self._shape(n, self.cout, self.oh, self.ow, self.dy_halo):
+            raise _ffi.VltfError("conv.wgrad: shape mismatch x=%s dy=%s" % (tuple(x.shape), tuple(dy.shape)))
         nbytes = 0 if ws is None else ws.numel() * ws.element_size()
         _ffi.call("vl_conv_wgrad", self._d, _p(x), _p(dy), _p(dw), _p(ws), nbytes, x.shape[0], stream())
 
@@ -119,35 +149,44 @@ def lrn_fwd(x, y, radius=2, alpha=2e-5, beta=0.75, bias=1.0):
     _ffi.call("vl_lrn_fwd", _p(x), _p(y), n, c, x.numel() // (n * c), radius, alpha, beta, bias, stream())
 
 
-def lrn_bwd(x, dy, dx, radius=2, alpha=2e-5, beta=0.75, bias=1.0, relu_fused=False):
+def lrn_bwd(x, dy, dx, radius=2, alpha=2e-5, beta=0.75, bias=1.0, relu_fused=False, dx_halo=0):
     _f32(x, dy, dx); _dense(x, dy, dx)
-    n, c = x.shape[0], x.shape[1]
-    _ffi.call("vl_lrn_bwd", _p(x), _p(dy), _p(dx), n, c, x.numel() // (n * c), radius, alpha, beta, bias, int(relu_fused),
-              stream())
+    n, c, h, w = x.shape
+    if tuple(dx.shape) != (n, c, h + 2 * dx_halo, w + 2 * dx_halo):
+        raise _ffi.VltfError("lrn_bwd: dx shape %s does not match x %s with halo %d" % (tuple(dx.shape), tuple(x.shape), dx_halo))
+    _ffi.call("vl_lrn_bwd", _p(x), _p(dy), _p(dx), n, c, h * w, radius, alpha, beta, bias, int(relu_fused), w, dx_halo, stream())
 
 
 def pool_out(h, k=3, s=2):
     return (h - k) // s + 1
 
 
-def _pool_strides(c, oh, ow, hwc):
-    # NCHW, or the (h, w, c)-flat order fc6 expects (alexnet.py:228)
-    return (oh * ow * c, 1, ow * c, c) if hwc else (c * oh * ow, oh * ow, ow, 1)
+def _pool_layout(c, oh, ow, hwc, halo):
+    """(element offset of the interior origin, strides n/c/h/w) of a pool output: NCHW with halo, or the
+    (h, w, c)-flat order fc6 expects (alexnet.py:228)."""
+    if hwc:
+        return 0, (oh * ow * c, 1, ow * c, c)
+    wp = ow + 2 * halo
+    pp = (oh + 2 * halo) * wp
+    return halo * wp + halo, (c * pp, pp, wp, 1)
 
 
-def maxpool_fwd(x, y, argmax, k=3, s=2, hwc=False):
+def maxpool_fwd(x, y, argmax, k=3, s=2, hwc=False, y_halo=0):
     _f32(x, y); _dense(x, y, argmax)
     n, c, h, w = x.shape
-    st = _pool_strides(c, pool_out(h, k, s), pool_out(w, k, s), hwc)
-    _ffi.call("vl_maxpool_fwd", _p(x), _p(y), _p(argmax), n, c, h, w, k, s, st[0], st[1], st[2], st[3], stream())
+    o, st = _pool_layout(c, pool_out(h, k, s), pool_out(w, k, s), hwc, y_halo)
+    _ffi.call("vl_maxpool_fwd", _p(x), _p(y) + 4 * o, None if argmax is None else _p(argmax) + o, n, c, h, w, k, s, st[0], st[1],
+              st[2], st[3], stream())
 
 
-def maxpool_bwd(dy, argmax, dx, relu_mask=None, k=3, s=2, hwc=False):
+def maxpool_bwd(dy, argmax, dx, relu_mask=None, k=3, s=2, hwc=False, dy_halo=0, dx_halo=0):
+    """dy / argmax have the pool OUTPUT layout (halo dy_halo); dx is NCHW with dx_halo."""
     _f32(dy, dx, relu_mask); _dense(dy, dx, argmax, relu_mask)
-    n, c, h, w = dx.shape
-    st = _pool_strides(c, pool_out(h, k, s), pool_out(w, k, s), hwc)
-    _ffi.call("vl_maxpool_bwd", _p(dy), _p(argmax), _p(dx), _p(relu_mask), n, c, h, w, k, s, st[0], st[1], st[2], st[3],
-              stream())
+    n, c = dx.shape[0], dx.shape[1]
+    h, w = dx.shape[2] - 2 * dx_halo, dx.shape[3] - 2 * dx_halo
+    o, st = _pool_layout(c, pool_out(h, k, s), pool_out(w, k, s), hwc, dy_halo)
+    _ffi.call("vl_maxpool_bwd", _p(dy) + 4 * o, _p(argmax) + o, _p(dx), _p(relu_mask), n, c, h, w, k, s, st[0], st[1], st[2], st[3],
+              dx_halo, stream())
 
 
 # ---- dense ---------------------------------------------------------------------------------------
