@@ -94,6 +94,14 @@ int vl_lrn_fwd(const float* x, float* y, int n, int c, int hw, int radius, float
 int vl_lrn_bwd(const float* x, const float* dy, float* dx, int n, int c, int hw, int radius, float alpha,
                float beta, float bias, int relu_fused, int w, int dx_halo, vl_stream_t stream);
 
+/* Fused backward of [LRN -> max_pool 3x3/2 VALID] (alexnet.py:79-98,120-139): dx = LRN'(x) applied to the
+ * pooled gradient routed through argmax, + optional ReluGrad of x; the gradient wrt the LRN output is never
+ * written.  x dense NCHW [n][c][h][w] (the LRN input); dp / argmax: pool-output layout NCHW with p_halo;
+ * dx: NCHW with dx_halo. */
+int vl_pool_lrn_bwd(const float* x, const float* dp, const uint8_t* argmax, float* dx, int n, int c, int h, int w,
+                    int p_halo, int radius, float alpha, float beta, float bias, int relu_fused, int dx_halo,
+                    vl_stream_t stream);
+
 /* ---- tf.nn.max_pool k x k, stride s, VALID (alexnet.py:91-98,132-139,204-211) ------------------
  * x NCHW [n][c][h][w]; y element (n,c,oh,ow) is stored at y[n*ys_n + c*ys_c + oh*ys_h + ow*ys_w]
  * (NCHW: ys = {c*oh*ow, oh*ow, ow, 1}; (h,w,c)-flat for fc6, alexnet.py:228: {oh*ow*c, 1, ow*c, c}).

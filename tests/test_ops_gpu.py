@@ -216,6 +216,28 @@ def test_maxpool(ops, hwc, n, h, w, c):
         assert float(dxp[:, :, 0].abs().max()) == 0
 
 
+@pytest.mark.parametrize("n,h,w,c,ph,dh", [(2, 9, 11, 7, 0, 0), (2, 13, 13, 40, 1, 2), (1, 57, 57, 20, 2, 0), (3, 28, 28, 33, 1, 2)])
+def test_pool_lrn_bwd_fused(ops, n, h, w, c, ph, dh):
+    """Fused kernel == maxpool_bwd followed by lrn_bwd(+ReluGrad) of the oracle."""
+    rng = np.random.default_rng(h * c)
+    x = np.maximum(rng.standard_normal((n, h, w, c)) * 30, 0).astype(np.float32)
+    l, _ = O.lrn(x)
+    y, arg = O.max_pool_valid(l)
+    oh, ow = y.shape[1], y.shape[2]
+    dy = rng.standard_normal(y.shape).astype(np.float32)
+    dl = O.max_pool_valid_grad(x.shape, arg, dy.astype(np.float64))
+    want = O.lrn_grad(x, dl) * (x > 0)
+    dp = torch.zeros((n, c, oh + 2 * ph, ow + 2 * ph), device=DEV)
+    ap = torch.zeros(dp.shape, dtype=torch.uint8, device=DEV)
+    interior(dp, ph).copy_(dev(nchw(dy)))
+    interior(ap, ph).copy_(dev(nchw(arg), torch.uint8))
+    dx = torch.zeros((n, c, h + 2 * dh, w + 2 * dh), device=DEV)
+    ops.pool_lrn_bwd(dev(nchw(x)), dp, ap, dx, p_halo=ph, dx_halo=dh)
+    close(nhwc(host(interior(dx, dh))), want, rtol=1e-5, atol_rel=1e-6)
+    if dh:
+        assert float(dx[:, :, :dh].abs().max()) == 0
+
+
 def test_colsum(ops):
     rng = np.random.default_rng(0)
     a = rng.standard_normal((100, 300)).astype(np.float32)

@@ -552,7 +552,7 @@ __global__ __launch_bounds__(NT) void mfma_contract(const typename LA::Params pa
         }
         __syncthreads();
     }
-    if (ntiles & 1) compute(0);
+    if (ntiles > 0 && (ntiles & 1)) compute(0);   // ntiles <= 0 for a trailing, empty reduction split
     EP::template apply<TM, TN>(pe, zg, zs, i0 + wi0, j0 + wj0, acc);
 }
 

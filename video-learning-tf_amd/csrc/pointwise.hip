@@ -176,6 +176,97 @@ __global__ void lrn_bwd_kernel(const float* __restrict__ x, const float* __restr
     }
 }
 
+// Fused max-pool(3x3/2 VALID) backward + LRN backward (+ReluGrad): the gradient wrt the LRN output is
+// never materialised.  One thread = one (image, pixel) column x CH channels.  The <= 4 pooling windows
+// that contain the pixel are the same for every channel, so they are decoded once; per channel the
+// routed gradient is a <= 4-term gather from the (tiny, cache resident) pooled gradient + arg-max maps.
+template <int CH, int R>
+__global__ void pool_lrn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dp, const uint8_t* __restrict__ arg,
+                                    float* __restrict__ dx, int n, int C, int H, int W, int OH, int OW, int64_t ps_n, int64_t ps_c,
+                                    int ps_h, float alpha, float beta, float bias, int relu_fused, int halo) {
+    const int HW = H * W;
+    const int64_t pos = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos >= (int64_t)n * HW) return;
+    const int img = (int)(pos / HW);
+    const int p = (int)(pos - (int64_t)img * HW);
+    const int py = p / W, px = p - py * W;
+    const int c0 = blockIdx.y * CH;
+    // windows (k = 3, s = 2) covering (py, px): row candidates (py>>1, local py&1) and, for even py, (py/2-1, local 2)
+    int woff[4], wloc[4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int oh = (py >> 1) - a, lr = (py & 1) + 2 * a;
+        const bool rok = oh >= 0 && oh < OH && lr <= 2;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int ow = (px >> 1) - b, lc = (px & 1) + 2 * b;
+            const bool ok = rok && ow >= 0 && ow < OW && lc <= 2;
+            woff[a * 2 + b] = ok ? oh * ps_h + ow : -1;
+            wloc[a * 2 + b] = lr * 3 + lc;
+        }
+    }
+    const float* xp = x + (int64_t)img * C * HW + p;
+    const float* dpp = dp + (int64_t)img * ps_n;
+    const uint8_t* ap = arg + (int64_t)img * ps_n;
+    float xv[CH + 4 * R];
+#pragma unroll
+    for (int i = 0; i < CH + 4 * R; ++i) {
+        const int c = c0 - 2 * R + i;
+        xv[i] = (c >= 0 && c < C) ? xp[(int64_t)c * HW] : 0.f;
+    }
+    float t[CH + 2 * R], u[CH];
+#pragma unroll
+    for (int i = 0; i < CH + 2 * R; ++i) {
+        const int c = c0 - R + i;
+        float g = 0.f;
+        if (c >= 0 && c < C) {
+            const int64_t cb = (int64_t)c * ps_c;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (woff[q] >= 0 && (int)ap[cb + woff[q]] == wloc[q]) g += dpp[cb + woff[q]];
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int d = 0; d <= 2 * R; ++d) s += xv[i + d] * xv[i + d];
+        const float sc = bias + alpha * s;
+        const float pw = pow_neg(sc, beta);
+        t[i] = g * xv[i + R] * pw / sc;
+        if (i >= R && i < CH + R) u[i - R] = g * pw;
+    }
+    const int wp = W + 2 * halo;
+    const int64_t dplane = (int64_t)(H + 2 * halo) * wp;
+    float* dxp = dx + (int64_t)img * C * dplane + (int64_t)(py + halo) * wp + px + halo;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        if (c0 + i < C) {
+            float a = 0.f;
+#pragma unroll
+            for (int d = 0; d <= 2 * R; ++d) a += t[i + d];
+            const float xc = xv[i + 2 * R];
+            float r = u[i] - 2.f * alpha * beta * xc * a;
+            if (relu_fused) r = xc > 0.f ? r : 0.f;
+            dxp[(int64_t)(c0 + i) * dplane] = r;
+        }
+    }
+}
+
+extern "C" int vl_pool_lrn_bwd(const float* x, const float* dp, const uint8_t* argmax, float* dx, int n, int c, int h, int w,
+                               int p_halo, int radius, float alpha, float beta, float bias, int relu_fused, int dx_halo,
+                               vl_stream_t stream) {
+    VL_CHECK(x && dp && argmax && dx && n > 0 && c > 0 && h >= 3 && w >= 3 && p_halo >= 0 && dx_halo >= 0, "vl_pool_lrn_bwd: bad argument");
+    VL_CHECK(radius == 2, "vl_pool_lrn_bwd: only depth_radius 2 is built (alexnet.py:81); got %d", radius);
+    const int oh = (h - 3) / 2 + 1, ow = (w - 3) / 2 + 1;
+    const int owp = ow + 2 * p_halo;
+    const int64_t pplane = (int64_t)(oh + 2 * p_halo) * owp;
+    const int64_t origin = (int64_t)p_halo * owp + p_halo;
+    constexpr int CH = 16;
+    dim3 grid(ceil_div((int64_t)n * h * w, 256), ceil_div(c, CH));
+    hipLaunchKernelGGL((pool_lrn_bwd_kernel<CH, 2>), grid, dim3(256), 0, (hipStream_t)stream, x, dp + origin, argmax + origin, dx, n,
+                       c, h, w, oh, ow, (int64_t)c * pplane, pplane, owp, alpha, beta, bias, relu_fused, dx_halo);
+    VL_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int vl_lrn_fwd(const float* x, float* y, int n, int c, int hw, int radius, float alpha, float beta, float bias,
                           vl_stream_t stream) {
     VL_CHECK(x && y && n > 0 && c > 0 && hw > 0, "vl_lrn_fwd: bad argument");

@@ -187,8 +187,6 @@ class LRCNEngine:
             if lrn:
                 L["l"] = buf(N, c, h, w)
                 out, out_halo = L["l"], 0
-                if training:
-                    L["dl"] = buf(N, c, h, w)
             if pool:
                 ph, pw = ops.pool_out(h), ops.pool_out(w)
                 L["hwc"] = name == "conv5"       # pool5 writes the (h, w, c)-flat order fc6 reads (alexnet.py:228)
@@ -484,8 +482,9 @@ class LRCNEngine:
             x_in = self.layers[li - 1]["out"][:n] if li > 0 else self.x0[:n]
             dy = L["dy"][:n]
             if L["pool"] and L["lrn"]:
-                self._pool_bwd(L, n, L["dl"][:n], None, 0)
-                ops.lrn_bwd(L["y"][:n], L["dl"][:n], dy, relu_fused=True, dx_halo=L["dy_halo"], **LRN)
+                # pool -> LRN -> ReLU backward in one pass: d(lrn out) is never written
+                ops.pool_lrn_bwd(L["y"][:n], L["dp"][:n], L["arg"][:n], dy, p_halo=L["p_halo"], dx_halo=L["dy_halo"],
+                                 relu_fused=True, **LRN)
             elif L["pool"]:
                 self._pool_bwd(L, n, dy, L["y"][:n], L["dy_halo"])
             # else: dy was written (ReluGrad fused) by the next layer's dgrad epilogue

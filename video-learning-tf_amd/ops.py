@@ -189,6 +189,18 @@ def maxpool_bwd(dy, argmax, dx, relu_mask=None, k=3, s=2, hwc=False, dy_halo=0, 
               dx_halo, stream())
 
 
+def pool_lrn_bwd(x, dp, argmax, dx, p_halo=0, dx_halo=0, radius=2, alpha=2e-5, beta=0.75, bias=1.0, relu_fused=True):
+    """Fused maxpool(3,2) backward + LRN backward (+ReluGrad); dp/argmax have the pool-output layout (p_halo)."""
+    _f32(x, dp, dx); _dense(x, dp, argmax, dx)
+    n, c, h, w = x.shape
+    oh, ow = pool_out(h), pool_out(w)
+    if tuple(dp.shape) != (n, c, oh + 2 * p_halo, ow + 2 * p_halo) or tuple(argmax.shape) != tuple(dp.shape) or \
+            tuple(dx.shape) != (n, c, h + 2 * dx_halo, w + 2 * dx_halo):
+        raise _ffi.VltfError("pool_lrn_bwd: shape mismatch x=%s dp=%s dx=%s" % (tuple(x.shape), tuple(dp.shape), tuple(dx.shape)))
+    _ffi.call("vl_pool_lrn_bwd", _p(x), _p(dp), _p(argmax), _p(dx), n, c, h, w, p_halo, radius, alpha, beta, bias, int(relu_fused),
+              dx_halo, stream())
+
+
 # ---- dense ---------------------------------------------------------------------------------------
 def gemm(a, b, c, m, n, k, transa=False, transb=False, lda=None, ldb=None, ldc=None, bias=None, relu=False,
          relu_mask=None, ws=None):
