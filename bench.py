@@ -31,7 +31,7 @@ PEAK_FP32_MFMA_TFLOPS = 157.3              # MI355X_MICROARCH.md: v_mfma_f32_32x
 # launches that share the single-kernel symbol mfma_contract<128,128,16,2,2,DenseKX,ConvGather,EpiConvNCHW>
 # (output-channel tile 128: conv2/3/5 forward and conv3 dgrad, whose output channel count is 256)
 DOMINANT = ("conv2.fwd", "conv3.fwd", "conv5.fwd", "conv3.dgrad")
-DOMINANT_SYMBOL = "mfma_contract<128,128,16,2,2,DenseKX<128,16>,ConvGather<128,16>,EpiConvNCHW>"
+DOMINANT_SYMBOL = "mfma_contract<128, 128, 16, 2, 2, DenseKX<128, 16>, ConvGather<128, 16, true>, EpiConvNCHW>"
 MEAN_BGR = np.array([99.197148, 105.293620, 109.503945], np.float32)
 
 
@@ -48,10 +48,14 @@ def cpu_baseline(clips, fpc, num_classes):
     t0 = time.time()
     O.lrcn_train_step(p, x, onehot, fpc, lr=1e-3, clip_norm=10.0, dtype=np.float32, chunk=16)
     dt = time.time() - t0
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count()
+    cores = None
+    try:   # threads the BLAS behind numpy actually used
+        from threadpoolctl import threadpool_info
+        cores = max([int(i.get("num_threads", 1)) for i in threadpool_info()] or [1])
+    except Exception:
+        pass
+    if not cores:
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
     return {"value": clips / dt, "unit": "clips/s", "cores": cores, "kind": "port",
             "sample": "%d clips x %d frames 227x227, one train step (fwd+bwd+clip+SGD), numpy fp32 oracle, %.1f s"
                       % (clips, fpc, dt)}
@@ -67,7 +71,7 @@ def main():
     ap.add_argument("--fpc", type=int, default=16)
     ap.add_argument("--classes", type=int, default=101)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-clips", type=int, default=2)
+    ap.add_argument("--cpu-clips", type=int, default=8)
     ap.add_argument("--dropout", type=float, default=0.0)
     args = ap.parse_args()
 
