@@ -53,3 +53,21 @@ def test_missing_library_fails_loudly(monkeypatch, built):
     monkeypatch.setattr(built, "LIB_PATH", "/nonexistent/libvltf_hip.so")
     with pytest.raises(built.VltfError):
         built.lib()
+
+
+def test_host_library_exports_header_symbols():
+    from vltf_amd import _hostio
+    if not os.path.exists(_hostio.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    src = open(os.path.join(ROOT, "include", "vltf_host.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = sorted(set(re.findall(r"\b(vlh_[a-z0-9_]+)\s*\(", src)))
+    assert names == sorted(_hostio.SIGNATURES)
+    lib = ctypes.CDLL(_hostio.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), n
+    for name, (_, args) in _hostio.SIGNATURES.items():
+        m = re.search(r"\b%s\s*\(([^;]*?)\)\s*;" % name, src, flags=re.S)
+        body = m.group(1).strip()
+        assert (0 if body in ("", "void") else body.count(",") + 1) == len(args), name

@@ -1,0 +1,153 @@
+"""The input format, byte for byte: CRC-32C known answers, TFRecord framing, the tf.train.Example codec
+(cross-checked against google.protobuf with the same schema built at run time), the .size sidecar and the
+native batch reader (libvltf_host.so) against the pure-Python restatement."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from vltf_amd import _hostio, tfrecord as T
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    if not os.path.exists(_hostio.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+
+
+def test_crc32c_known_answers():
+    # RFC 3720 B.4 vectors
+    assert T.crc32c(b"123456789") == 0xE3069283
+    assert T.crc32c(bytes(32)) == 0x8A9136AA
+    assert T.crc32c(bytes([0xFF] * 32)) == 0x62A8AB43
+    assert T.crc32c(bytes(range(32))) == 0x46DD794E
+    for data in (b"", b"a", b"123456789", bytes(range(256)) * 37 + b"xyz"):
+        assert _hostio.lib().vlh_crc32c(data, len(data)) == T.crc32c(data)
+        assert _hostio.masked_crc32c(data) == T.masked_crc32c(data)
+    c = T.crc32c(b"123456789")
+    assert T.masked_crc32c(b"123456789") == (((c >> 15) | (c << 17)) + 0xA282EAD8) & 0xFFFFFFFF
+
+
+def example_classes():
+    """tf.train.Example / Features / Feature / *List rebuilt with descriptor_pb2 (tensorflow/core/example/*.proto)."""
+    from google.protobuf import descriptor_pb2, descriptor_pool, message_factory
+    fd = descriptor_pb2.FileDescriptorProto(name="vltf_test_example.proto", package="vltf_test", syntax="proto3")
+    F = descriptor_pb2.FieldDescriptorProto
+
+    def msg(name, fields):
+        m = fd.message_type.add(name=name)
+        for fname, num, ftype, label, tname in fields:
+            f = m.field.add(name=fname, number=num, type=ftype, label=label)
+            if tname:
+                f.type_name = tname
+        return m
+    msg("BytesList", [("value", 1, F.TYPE_BYTES, F.LABEL_REPEATED, None)])
+    msg("FloatList", [("value", 1, F.TYPE_FLOAT, F.LABEL_REPEATED, None)])
+    msg("Int64List", [("value", 1, F.TYPE_INT64, F.LABEL_REPEATED, None)])
+    feat = msg("Feature", [("bytes_list", 1, F.TYPE_MESSAGE, F.LABEL_OPTIONAL, ".vltf_test.BytesList"),
+                           ("float_list", 2, F.TYPE_MESSAGE, F.LABEL_OPTIONAL, ".vltf_test.FloatList"),
+                           ("int64_list", 3, F.TYPE_MESSAGE, F.LABEL_OPTIONAL, ".vltf_test.Int64List")])
+    feats = msg("Features", [("feature", 1, F.TYPE_MESSAGE, F.LABEL_REPEATED, ".vltf_test.Features.FeatureEntry")])
+    entry = feats.nested_type.add(name="FeatureEntry")
+    entry.options.map_entry = True
+    entry.field.add(name="key", number=1, type=F.TYPE_STRING, label=F.LABEL_OPTIONAL)
+    entry.field.add(name="value", number=2, type=F.TYPE_MESSAGE, label=F.LABEL_OPTIONAL, type_name=".vltf_test.Feature")
+    msg("Example", [("features", 1, F.TYPE_MESSAGE, F.LABEL_OPTIONAL, ".vltf_test.Features")])
+    pool = descriptor_pool.DescriptorPool()
+    pool.Add(fd)
+    return message_factory.GetMessageClass(pool.FindMessageTypeByName("vltf_test.Example"))
+
+
+def test_example_codec_against_protobuf():
+    Example = example_classes()
+    rng = np.random.default_rng(0)
+    frame = rng.integers(0, 256, (6, 7, 3), dtype=np.uint8)
+    ours = T.frame_example(frame, [5, 2])
+    ex = Example()
+    ex.ParseFromString(ours)                                    # protobuf accepts our bytes
+    f = ex.features.feature
+    assert f["height"].int64_list.value[0] == 6 and f["width"].int64_list.value[0] == 7 and f["depth"].int64_list.value[0] == 3
+    assert list(f["label"].int64_list.value) == [5, 2] and f["image_raw"].bytes_list.value[0] == frame.tobytes()
+    ref = Example()                                            # and we accept protobuf's bytes
+    ref.features.feature["height"].int64_list.value.append(6)
+    ref.features.feature["width"].int64_list.value.append(7)
+    ref.features.feature["depth"].int64_list.value.append(3)
+    ref.features.feature["label"].int64_list.value.extend([5, 2])
+    ref.features.feature["image_raw"].bytes_list.value.append(frame.tobytes())
+    ref.features.feature["score"].float_list.value.extend([0.5, -2.0])
+    img, lab = T.parse_frame_example(ref.SerializeToString())
+    assert np.array_equal(img, frame) and lab == [5, 2]
+    assert T.decode_example(ref.SerializeToString())["score"] == [0.5, -2.0]
+    assert T.decode_example(T.encode_example({"neg": [-3, 1 << 40]}))["neg"] == [-3, 1 << 40]
+
+
+def write_frames(path, frames, labels):
+    with T.TFRecordWriter(path) as w:
+        for fr, lab in zip(frames, labels):
+            w.write(T.frame_example(fr, lab))
+
+
+def test_framing_roundtrip_and_native_reader(tmp_path):
+    rng = np.random.default_rng(1)
+    frames = rng.integers(0, 256, (7, 12, 10, 3), dtype=np.uint8)
+    labels = [[i % 4] for i in range(7)]
+    labels[3] = [3, 9, 1]
+    path = str(tmp_path / "a.tfrecord")
+    write_frames(path, frames, labels)
+    raw = open(path, "rb").read()
+    n, = struct.unpack("<Q", raw[:8])
+    assert struct.unpack("<I", raw[8:12])[0] == T.masked_crc32c(raw[:8])
+    assert struct.unpack("<I", raw[12 + n:16 + n])[0] == T.masked_crc32c(raw[12:12 + n])
+    got = [T.parse_frame_example(p) for p in T.tf_record_iterator(path)]
+    assert len(got) == 7 and all(np.array_equal(g[0], f) for g, f in zip(got, frames)) and [g[1] for g in got] == labels
+    imgs, labs, off = _hostio.read_frames(path, 0, 4, (12, 10, 3))
+    assert np.array_equal(imgs, frames[:4]) and labs == labels[:4]
+    imgs2, labs2, off2 = _hostio.read_frames(path, off, 3, (12, 10, 3))
+    assert np.array_equal(imgs2, frames[4:]) and labs2 == labels[4:] and off2 == len(raw)
+    assert _hostio.skip_records(path, 0, 4) == off
+    it = T.tf_record_iterator(path)
+    it.skip(4)
+    assert np.array_equal(T.parse_frame_example(next(it))[0], frames[4])
+    with pytest.raises(EOFError) as e:                          # ragged: fewer records than asked
+        _hostio.read_frames(path, off, 5, (12, 10, 3))
+    assert e.value.records_read == 3
+    with pytest.raises(_hostio.HostIOError):                     # wrong geometry
+        _hostio.read_frames(path, 0, 1, (12, 11, 3))
+    empty = str(tmp_path / "empty.tfrecord")
+    open(empty, "wb").close()
+    assert list(T.tf_record_iterator(empty)) == []
+    with pytest.raises(EOFError):
+        _hostio.read_frames(empty, 0, 1, (12, 10, 3))
+
+
+def test_corruption_is_detected(tmp_path):
+    frames = np.zeros((2, 4, 4, 3), np.uint8)
+    path = str(tmp_path / "c.tfrecord")
+    write_frames(path, frames, [[0], [1]])
+    raw = bytearray(open(path, "rb").read())
+    n, = struct.unpack("<Q", raw[:8])
+    raw[12 + n // 2] ^= 0x10                                    # flip a bit inside record 0's image bytes
+    bad = str(tmp_path / "bad.tfrecord")
+    open(bad, "wb").write(raw)
+    with pytest.raises(IOError):
+        list(T.tf_record_iterator(bad))
+    with pytest.raises(_hostio.HostIOError):
+        _hostio.read_frames(bad, 0, 2, (4, 4, 3))
+    imgs, _, _ = _hostio.read_frames(bad, 0, 2, (4, 4, 3), verify_crc=False)      # like TF with CRC checks off
+    assert imgs.shape == (2, 4, 4, 3)
+
+
+def test_size_file(tmp_path):
+    p = str(tmp_path / "x.size")
+    T.write_size_file(p, 5, "video", [2, 2, 3, 3, 3], 16, 1)
+    assert open(p).read() == "items\t5\ntype\tvideo\ncpi\t[(2, 2), (3, 3)]\nfpc\t16\nlabelcount\t1\n"     # serialize.py:138-151
+    d = T.read_size_file(p)
+    assert d == {"items": 5, "type": "video", "cpv": [2, 2, 3, 3, 3], "fpc": 16, "labelcount": 1}
+    T.write_size_file(p, 3, "image", None, None, 2)
+    d = T.read_size_file(p)
+    assert d["cpv"] is None and d["fpc"] is None
+    open(p, "w").write("items\t2\ntype\tvideo\ncpi\t[(3, 1)]\nfpc\t4\nlabelcount\t1\n")
+    with pytest.raises(ValueError):
+        T.read_size_file(p)

@@ -1,0 +1,202 @@
+"""Dataset: the reference's TFRecord-backed video dataset (dataset_.py) with the device-side split of
+process_image: the host reads raw uint8 frames (native reader) and draws crop offsets / mirror flags
+exactly as the reference does; crop, mean subtraction, mirror and the NHWC->NCHW float conversion run on
+the device (vl_input_prep_u8).  Only input_mode video + data_format tfrecord + batch_item default are on
+the path (Feeder hard-codes video, settings_.py:302; batch_item clip is broken in the reference)."""
+import math
+import os
+import random
+
+import numpy as np
+
+from . import _hostio, tfrecord
+from .defs_ import defs
+from .utils_ import debug, error, info, labels_to_one_hot, warning
+
+
+class Dataset:
+    def initialize(self, id, path, mean_image, prepend_folder, desired_image_shape, imgproc, raw_image_shape, data_format,
+                   frame_format, batch_item, num_classes, tag, read_tries):
+        """dataset_.py:503-519."""
+        info("Initializing dataset [%s]" % id)
+        self.id, self.path, self.tag = id, path, tag
+        self.data_format, self.frame_format, self.prepend_folder = data_format, frame_format, prepend_folder
+        self.mean_image = mean_image
+        self.desired_image_shape = tuple(desired_image_shape) if desired_image_shape is not None else None
+        self.raw_image_shape = tuple(raw_image_shape) if raw_image_shape is not None else None
+        self.imgproc = list(imgproc)
+        self.batch_item, self.num_classes, self.read_tries = batch_item, num_classes, read_tries
+        self.batch_index = self.epoch_index = 0
+        self.batches, self.offset = None, 0
+        self.frames, self.labels = [], []
+        self.rng = random.Random()          # the reference uses the unseeded `random` module (dataset_.py:454,498)
+        if data_format != defs.data_format.tfrecord:
+            error("Only data_format tfrecord is on the hot path (got [%s])" % data_format)
+        if batch_item != defs.batch_item.default:
+            error("batch_item [%s] is not supported (broken in the reference, dataset_.py:415)" % batch_item)
+
+    def seed(self, s):
+        self.rng = random.Random(s)
+
+    def get_image_shape(self):
+        return self.desired_image_shape if self.desired_image_shape is not None else self.raw_image_shape
+
+    def read_frames_metadata(self):
+        """dataset_.py:71-84: 'path label...' per line."""
+        self.frames, self.labels = [], []
+        with open(self.path, "r") as f:
+            for line in f:
+                parts = line.split()
+                if not parts:
+                    continue
+                item = parts[0]
+                if self.prepend_folder:
+                    item = os.path.join(self.prepend_folder, item)
+                self.frames.append(item)
+                self.labels.append(parts[1:])
+
+    def get_input_data_count(self):
+        """dataset_.py:701-756."""
+        size_file = self.record_path + ".size"
+        if not os.path.exists(size_file):
+            error("Could not file data size file: %s" % size_file)
+        d = tfrecord.read_size_file(size_file)
+        if d["type"] != self.input_mode:
+            error("Specified input mode is [%s] but the size file contains [%s]" % (self.input_mode, d["type"]))
+        if d["cpv"] is None or d["fpc"] is None:
+            error("Read cpi: %s / fpc: %s but input mode is %s" % (d["cpv"], d["fpc"], self.input_mode))
+        self.num_items = d["items"]
+        self.clips_per_video = d["cpv"] if isinstance(d["cpv"], list) else [d["cpv"]] * self.num_items
+        self.num_frames_per_clip = d["fpc"]
+        self.max_caption_length = d["labelcount"]
+        info("Read [%s] data, count: %d, fpc: %s, type: %s" % (self.id, self.num_items, self.num_frames_per_clip, self.input_mode))
+
+    def compute_crop(self, raw_image_shape, image_shape, mode):
+        """dataset_.py:571-577.  rand range(0, raw - want - 1) excludes the last two legal offsets, as the reference does."""
+        if mode == defs.imgproc.center_crop:
+            return tuple(int(np.floor((r - w) / 2)) for r, w in zip(raw_image_shape, image_shape))[:2]
+        return (list(range(0, raw_image_shape[0] - image_shape[0] - 1)), list(range(0, raw_image_shape[1] - image_shape[1] - 1)))
+
+    def initialize_imgproc(self):
+        """dataset_.py:540-560 (+ build_mean_image 521-530: mean_image[0] is blue)."""
+        self.mean_bgr = np.asarray(self.mean_image, np.float32) if defs.imgproc.sub_mean in self.imgproc else None
+        self.crop_mode = None
+        if defs.imgproc.rand_crop in self.imgproc:
+            self.crop_mode = defs.imgproc.rand_crop
+        elif defs.imgproc.center_crop in self.imgproc:
+            self.crop_mode = defs.imgproc.center_crop
+        elif defs.imgproc.resize in self.imgproc:
+            error("imgproc resize (scipy imresize) is not on the device path; serialize at the network size instead")
+        if self.raw_image_shape is None:
+            self.raw_image_shape = self.desired_image_shape
+        if self.crop_mode is None and tuple(self.raw_image_shape) != tuple(self.desired_image_shape):
+            error("Encountered image shape %s but desired shape is %s" % (self.raw_image_shape, self.desired_image_shape))
+        if self.crop_mode:
+            self.crop_h, self.crop_w = self.compute_crop(self.raw_image_shape, self.desired_image_shape, self.crop_mode)
+
+    def calculate_batches(self, batch_size, input_mode):
+        """dataset_.py:582-613."""
+        self.batch_size, self.input_mode = batch_size, input_mode
+        if not os.path.exists(self.path):
+            error("Dataset path does not exist: %s" % self.path)
+        self.read_frames_metadata()
+        self.record_path = self.path + ".tfrecord"
+        if not os.path.exists(self.record_path):
+            error("TFRecord file path does not exist: %s" % self.record_path)
+        self.reset_iterator()
+        self.get_input_data_count()
+        self.initialize_imgproc()
+        whole = self.num_items // self.batch_size
+        left = self.num_items - whole * self.batch_size
+        self.batches = [self.batch_size] * whole + ([left] if left else [])
+        self.tell()
+
+    def tell(self):
+        clips = sum(self.clips_per_video)
+        info("Dataset batch information per epoch: items %d, clips %d, frames %d, b-size %d, b-num %d, b-index %d, imgprc %s" %
+             (self.num_items, clips, clips * self.num_frames_per_clip, self.batch_size, len(self.batches), self.batch_index,
+              defs.imgproc.to_str(self.imgproc)))
+
+    def compute_dataset_portion(self, freq_per_epoch, epochs):
+        """dataset_.py:562-568."""
+        save_interval = math.ceil(len(self.batches) / freq_per_epoch)
+        num_saves = math.ceil(freq_per_epoch * epochs)
+        info("Computed batch save interval (from %2.4f per %d-batched epoch) to %d batches and %d total saves" %
+             (freq_per_epoch, len(self.batches), save_interval, num_saves))
+        return save_interval, num_saves
+
+    # ---- iteration ---------------------------------------------------------------------------------
+    def reset_iterator(self):
+        self.offset = 0
+
+    def rewind(self):
+        self.reset_iterator()
+        self.batch_index = 0
+
+    def loop(self):
+        return self.batch_index < len(self.batches)
+
+    def _read(self, count):
+        """deserialize_from_tfrecord (dataset_.py:171-217): on EOF mid-batch the reference rewinds and re-reads from
+        the start of the file (reread_serialized, 219-230); parse errors are retried read_tries times."""
+        tries = 0
+        while True:
+            try:
+                imgs, labels, self.offset = _hostio.read_frames(self.record_path, self.offset, count, self.raw_image_shape)
+                return imgs, labels
+            except EOFError as ex:
+                warning("Unexpected EOF after %d/%d records of the batch; rewinding the iterator" % (ex.records_read, count))
+                self.reset_iterator()
+                tries += 1
+                if tries > max(1, self.read_tries):
+                    error("Failed to troubleshoot serialization error.")
+            except _hostio.HostIOError as ex:
+                tries += 1
+                warning("Encountered exception while reading TFRecord batch (%s); try %d" % (ex, tries))
+                if tries > self.read_tries:
+                    error("Failed to troubleshoot serialization error.")
+
+    def get_next_batch(self):
+        """get_next_batch_video_tfr (dataset_.py:386-420): batch = batch_size videos; reads sum(cpv)*fpc consecutive
+        frame records; one label per clip (its first frame's).  Returns (frames uint8 [n,H,W,C] raw, crop_y, crop_x,
+        mirror, onehot int32 [clips, classes])."""
+        v0 = self.batch_index * self.batch_size
+        cpv = self.clips_per_video[v0:v0 + self.batch_size]
+        fpc = self.num_frames_per_clip
+        n = sum(fpc * c for c in cpv)
+        if not n:
+            error("Computed 0 frames in next batch.")
+        frames, labels_per_frame = self._read(n)
+        labels, first = [], 0
+        for c in cpv:
+            labels.extend([labels_per_frame[first]] * c)
+            first += c * fpc
+        cy = np.zeros(n, np.int32)
+        cx = np.zeros(n, np.int32)
+        mirror = np.zeros(n, np.uint8)
+        for i in range(n):      # per-frame draws, like process_image per frame (dataset_.py:481-501)
+            if self.crop_mode == defs.imgproc.rand_crop:
+                cy[i], cx[i] = self.rng.choice(self.crop_h), self.rng.choice(self.crop_w)
+            elif self.crop_mode == defs.imgproc.center_crop:
+                cy[i], cx[i] = self.crop_h, self.crop_w
+            if defs.imgproc.rand_mirror in self.imgproc:
+                mirror[i] = 0 if self.rng.randrange(2) else 1          # `if not randrange(2)` mirrors
+        ground_truth = labels_to_one_hot(labels, self.num_classes)
+        self.batch_index += 1
+        return frames, cy, cx, mirror, ground_truth
+
+    # ---- resume ------------------------------------------------------------------------------------
+    def restore(self, batch_index, epoch_index):
+        """dataset_.py:534-538."""
+        self.batch_index, self.epoch_index = batch_index, epoch_index
+        self.fast_forward_iter()
+
+    def fast_forward_iter(self):
+        """dataset_.py:772-811: skip the records of the first batch_index batches (variable cpv aware)."""
+        if len(self.batches) <= self.batch_index:
+            info("Fast-forward not necessary for batch index %d with a total of %d batches." % (self.batch_index + 1, len(self.batches)))
+            return
+        item_index = self.batch_index * self.batch_size
+        num_forward = sum(self.clips_per_video[:item_index]) * self.num_frames_per_clip
+        info("Fast forwarding to batch # %d/%d ( image # %d )" % (self.batch_index + 1, len(self.batches), num_forward + 1))
+        self.offset = _hostio.skip_records(self.record_path, 0, num_forward)

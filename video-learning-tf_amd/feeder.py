@@ -1,0 +1,160 @@
+"""Feeder: batch delivery and checkpoint save / resume with the reference's surface (feeder.py).
+The feed dict of the reference (placeholder -> numpy) becomes a plain dict of device-ready arrays."""
+import os
+import pickle
+
+import numpy as np
+
+from . import dataset_
+from .defs_ import defs
+from .utils_ import debug, error, get_datetime_str, get_run_checkpoints, info, warning
+
+
+class Feeder:
+    def __init__(self, input_mode, phases, trainval, save_freq_per_epoch, run_folder, resume):
+        """feeder.py:16-29."""
+        self.datasets = {}
+        self.input_mode, self.phases, self.phase = input_mode, phases, None
+        self.run_folder, self.resume = run_folder, resume
+        self.train, self.val = trainval
+        self.save_freq_per_epoch = save_freq_per_epoch
+        self.save_interval, self.num_saves = -1, 0
+        self.saved = []
+
+    def add_dataset(self, dataset_phase, id, path, mean_image, prepend_folder, image_shape, imgproc, raw_image_shape, data_format,
+                    frame_format, batch_item, num_classes, tag, read_tries, captioning_config=None):
+        """feeder.py:31-38."""
+        dset = dataset_.Dataset()
+        self.datasets.setdefault(dataset_phase, []).append(dset)
+        dset.initialize(id, path, mean_image, prepend_folder, image_shape, imgproc, raw_image_shape, data_format, frame_format,
+                        batch_item, num_classes, tag, read_tries)
+
+    def set_phase(self, phase):
+        self.phase = phase
+
+    def initialize_datasets(self):
+        """feeder.py:43-54."""
+        if not self.datasets:
+            error("No dataset configured to active phase [%s]" % self.phase)
+        for phase in self.phases:
+            for i, dset in enumerate(self.datasets.get(phase, [])):
+                info("Reading dataset %d / %d : [%s]" % (i + 1, len(self.datasets[phase]), dset.id))
+                bs = self.train.batch_size if (defs.phase.train in self.phases and self.train) else self.val.batch_size
+                dset.calculate_batches(bs, self.input_mode)
+
+    def loop(self):
+        return self.datasets[self.phase][0].loop()
+
+    def get_dataset_by_tag(self, tag):
+        return [d for d in self.datasets[self.phase] if d.tag == tag]
+
+    def get_datasets(self):
+        return self.datasets[self.phase]
+
+    def get_num_batches(self):
+        return len(self.datasets[self.phase][0].batches) if self.datasets else -1
+
+    def get_batch_index(self):
+        return self.datasets[self.phase][0].batch_index
+
+    def get_batch_sizes(self):
+        return [d.batch_size for d in self.datasets[self.phase]]
+
+    def rewind_datasets(self):
+        for d in self.datasets[self.phase]:
+            d.rewind()
+
+    def get_feed_dict(self, tag=defs.dataset_tag.main):
+        """feeder.py:84-106: -> (fdict, num_data, num_labels, padding).  fdict holds the raw uint8 frames and the
+        device-side imgproc arguments instead of float32 frames."""
+        dsets = self.get_dataset_by_tag(tag)
+        if len(dsets) != 1:
+            error("%d datasets satisfy the network input requirement [%s], but exactly one must." % (len(dsets), tag))
+        d = dsets[0]
+        frames, cy, cx, mirror, onehot = d.get_next_batch()
+        fdict = {"frames_u8": frames, "crop_y": cy, "crop_x": cx, "mirror": mirror, "labels": onehot, "mean_bgr": d.mean_bgr,
+                 "dataset": d}
+        return fdict, [len(frames)], len(onehot), 0
+
+    # ---- save cadence (feeder.py:111-129) ---------------------------------------------------------------
+    def compute_save_interval(self):
+        if not self.train:
+            self.save_interval, self.num_saves = -1, 0
+            return
+        for d in self.datasets[self.phase]:
+            self.save_interval, self.num_saves = d.compute_dataset_portion(self.save_freq_per_epoch, self.train.epochs)
+
+    def should_save(self, step):
+        if self.save_interval < 0 or self.phase == defs.phase.val:
+            return False
+        return step % self.save_interval == 0
+
+    # ---- checkpoints (feeder.py:143-288) -------------------------------------------------------------------
+    # <run_folder>/checkpoints/<ddmmyy_HHMMSS>_ep_E_btch_B_gs_G.graph-<gs>.weights.npz  {tf variable name: array}
+    #                                                            ...  .graph-<gs>.snap   pickle [batch_index, epoch_index, global_step]
+    def _resolve(self, resume_file):
+        if resume_file == defs.names.latest_savefile:
+            ck = get_run_checkpoints(self.run_folder)
+            if not ck:
+                error("Specified resume file: [%s], but no checkpoint exists in %s" % (resume_file, self.run_folder))
+            return ck[-1]
+        return resume_file.strip("\"'")
+
+    def resume_snap(self, resume_file):
+        """feeder.py:143-194 -> (epoch_index, global_step); fast-forwards the record iterators."""
+        if not self.resume:
+            return None
+        base = self._resolve(resume_file)
+        snap = base + ".snap"
+        info("Resuming metadata: [%s]" % snap)
+        if not os.path.exists(snap):
+            error("Metaparameters savefile does not exist: %s" % snap)
+        with open(snap, "rb") as f:
+            params = pickle.load(f)            # a file this code wrote
+        batch_info, epoch = params[:2]
+        global_step = params[2] if len(params) > 2 else int(os.path.basename(base).split("-")[-1])
+        for d in self.get_datasets():
+            idx = batch_info.get(d.tag, 0) if isinstance(batch_info, dict) else batch_info
+            d.restore(idx, epoch)
+        info("Restored training snapshot of epoch %d, train index %s, global step %d" % (epoch + 1, str(batch_info), global_step))
+        return epoch, global_step
+
+    def init_saveload(self, engine, resume_file, ignorable_variable_names=()):
+        """feeder.py:198-257: restore variables; a variable-set mismatch fails instead of prompting."""
+        self.compute_save_interval()
+        if not self.resume:
+            return
+        base = self._resolve(resume_file)
+        wfile = base + ".weights.npz"
+        info("Resuming weights: [%s]" % wfile)
+        if not os.path.exists(wfile) or not os.path.exists(base + ".snap"):
+            error("Missing weights or snap part of savefile: %s" % base)
+        with np.load(wfile, allow_pickle=False) as z:
+            stored = {k: z[k] for k in z.files}
+        ignor = set(ignorable_variable_names) | {defs.names.global_step}
+        want = {n for n, _ in engine.specs}
+        missing = sorted(want - set(stored) - ignor)
+        extra = sorted(set(stored) - want - ignor)
+        if missing or extra:
+            error("Failed to load checkpoint: variables missing from it %s, unknown to the network %s" % (missing, extra))
+        engine.load_params({k: v for k, v in stored.items() if k in want})
+
+    def save(self, engine, progress, global_step):
+        """feeder.py:263-288."""
+        folder = os.path.join(self.run_folder, "checkpoints")
+        os.makedirs(folder, exist_ok=True)
+        base = os.path.join(folder, get_datetime_str() + "_" + progress) + ".graph-%d" % global_step
+        info("Saving graph  to [%s]" % base)
+        np.savez(base + ".weights.npz", **engine.get_params())
+        info("Saving params for epoch index %d, train index %d" % (self.train.epoch_index + 1, self.get_batch_index()))
+        with open(base + ".snap", "wb") as f:
+            pickle.dump([self.get_batch_index(), self.train.epoch_index, global_step], f)
+        with open(os.path.join(folder, "checkpoint"), "w") as f:
+            f.write('model_checkpoint_path: "%s"\n' % base)
+        self.saved.append(base)
+        while self.num_saves > 0 and len(self.saved) > self.num_saves:      # tf.train.Saver(max_to_keep=num_saves)
+            old = self.saved.pop(0)
+            for suf in (".weights.npz", ".snap"):
+                if os.path.exists(old + suf):
+                    os.remove(old + suf)
+        return base

@@ -1,0 +1,70 @@
+"""Train: learning-rate table and the per-step call with the reference's surface (train.py:50-149, 199-222)."""
+import math
+import os
+
+import torch
+
+from .defs_ import defs
+from .utils_ import error, info
+
+
+def precompute_learning_rates(settings, num_batches):
+    """train.py:50-109, including the schedule dump to <run_id>_lr_decay_schedule.txt.  Because idx advances by
+    decay_freq per block, exp and staircase give the same piecewise-constant table."""
+    base_lr, decay_params = settings.train.base_lr, settings.train.lr_decay
+    total = num_batches * settings.train.epochs
+    if decay_params is None:
+        return [base_lr] * total
+    offset = 0 if len(tuple(decay_params)) == 4 else decay_params[-1]
+    strategy, scheme, freq, factor = tuple(decay_params[:4])
+    if strategy not in (defs.decay.exp, defs.decay.staircase):
+        error("Undefined decay strategy %s" % strategy)
+    staircase = strategy == defs.decay.staircase
+    if scheme == defs.periodicity.interval:
+        period = freq
+    elif scheme == defs.periodicity.drops:
+        period = math.ceil(total / freq)
+    else:
+        error("Undefined decay scheme %s" % scheme)
+    lrs, idx = [], 0
+    while len(lrs) < total:
+        fraction = idx // freq if staircase else idx / freq
+        lrs.extend([base_lr * pow(factor, fraction)] * period)
+        idx += freq
+    lrs = lrs[:total]
+    if offset:
+        lrs = [base_lr] * offset + lrs[0:-offset]
+    path = os.path.join(settings.run_folder, settings.run_id + "_lr_decay_schedule.txt")
+    with open(path, "w") as f:
+        k = 0
+        for ep in range(settings.train.epochs):
+            for b in range(num_batches):
+                f.write("Epoch %d/%d, batch %d/%d, lr %2.8f\n" % (ep + 1, settings.train.epochs, b + 1, num_batches, lrs[k]))
+                k += 1
+    info("Dropping LR of %2.5f, mid / last lr is: %1.5f, %1.5f, total drops: %d" % (base_lr, lrs[len(lrs) // 2], lrs[-1], len(set(lrs))))
+    return lrs
+
+
+class Train:
+    """train.py:112-149: owns the LR table and global_step; run_step is the train sess.run."""
+
+    def __init__(self, settings, feeder, engine):
+        self.engine = engine
+        self.learning_rates = precompute_learning_rates(settings, feeder.get_num_batches())
+        self.global_step = settings.global_step
+        self.clip_norm = float(settings.train.clip_norm or 0)
+
+    def run_step(self, fdict, dp=None):
+        """-> (loss, current_lr, global_step) like sess.run([.., loss, current_lr, global_step, optimizer])."""
+        if self.global_step >= len(self.learning_rates):
+            error("global step %d exceeds the precomputed learning-rate table (%d)" % (self.global_step, len(self.learning_rates)))
+        lr = float(self.learning_rates[self.global_step])
+        dev = self.engine.dev
+        out = self.engine.train_step_u8(torch.from_numpy(fdict["frames_u8"]).to(dev, non_blocking=True),
+                                        torch.from_numpy(fdict["labels"]).to(dev),
+                                        lr, self.clip_norm, fdict["mean_bgr"],
+                                        torch.from_numpy(fdict["crop_y"]).to(dev), torch.from_numpy(fdict["crop_x"]).to(dev),
+                                        torch.from_numpy(fdict["mirror"]).to(dev))
+        self.global_step += 1
+        self.last = out
+        return out["loss"], lr, self.global_step
