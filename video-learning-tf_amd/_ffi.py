@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvltf_hip.so")
+LIB_PATH = os.environ.get("VLTF_HIP_LIB") or os.path.join(_HERE, "libvltf_hip.so")   # override: kernel experiments only
 
 p = C.c_void_p
 i32, i64, f32, u64, sz = C.c_int, C.c_int64, C.c_float, C.c_uint64, C.c_size_t

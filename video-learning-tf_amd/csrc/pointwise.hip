@@ -159,7 +159,7 @@ __global__ void lrn_bwd_kernel(const float* __restrict__ x, const float* __restr
         const float sc = bias + alpha * s;
         const float pw = pow_neg(sc, beta);
         const float g = (c >= 0 && c < C) ? gp[(int64_t)c * HW] : 0.f;
-        t[i] = g * xv[i + R] * pw / sc;
+        t[i] = g * xv[i + R] * pw * __builtin_amdgcn_rcpf(sc);
         if (i >= R && i < CH + R) u[i - R] = g * pw;
     }
 #pragma unroll
@@ -180,72 +180,95 @@ __global__ void lrn_bwd_kernel(const float* __restrict__ x, const float* __restr
 // never materialised.  One thread = one (image, pixel) column x CH channels.  The <= 4 pooling windows
 // that contain the pixel are the same for every channel, so they are decoded once; per channel the
 // routed gradient is a <= 4-term gather from the (tiny, cache resident) pooled gradient + arg-max maps.
-template <int CH, int R>
-__global__ void pool_lrn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dp, const uint8_t* __restrict__ arg,
-                                    float* __restrict__ dx, int n, int C, int H, int W, int OH, int OW, int64_t ps_n, int64_t ps_c,
-                                    int ps_h, float alpha, float beta, float bias, int relu_fused, int halo) {
+// One workgroup = (image, CH-channel chunk, band of 2*PR input rows).  The pooled gradient and the arg-max
+// bytes that band can touch ((PR+1) pooled rows x CH+2R channels: ~20 KB) are staged in LDS with coalesced
+// loads; every per-pixel gather then hits LDS, never the texture path (a per-pixel global gather version
+// was TA-bound at 3.5-6 ms for lrn1).
+template <int CH, int R, int NPIX>
+__global__ __launch_bounds__(256) void pool_lrn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dp,
+                                                           const uint8_t* __restrict__ arg, float* __restrict__ dx, int C, int H,
+                                                           int W, int OH, int OW, int64_t ps_n, int ps_c, int ps_h, float alpha,
+                                                           float beta, float bias, int relu_fused, int halo) {
+    constexpr int NC = CH + 2 * R;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int HW = H * W;
-    const int64_t pos = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (pos >= (int64_t)n * HW) return;
-    const int img = (int)(pos / HW);
-    const int p = (int)(pos - (int64_t)img * HW);
-    const int py = p / W, px = p - py * W;
-    const int c0 = blockIdx.y * CH;
-    // windows (k = 3, s = 2) covering (py, px): row candidates (py>>1, local py&1) and, for even py, (py/2-1, local 2)
-    int woff[4], wloc[4];
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {
-        const int oh = (py >> 1) - a, lr = (py & 1) + 2 * a;
-        const bool rok = oh >= 0 && oh < OH && lr <= 2;
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const int ow = (px >> 1) - b, lc = (px & 1) + 2 * b;
-            const bool ok = rok && ow >= 0 && ow < OW && lc <= 2;
-            woff[a * 2 + b] = ok ? oh * ps_h + ow : -1;
-            wloc[a * 2 + b] = lr * 3 + lc;
-        }
-    }
-    const float* xp = x + (int64_t)img * C * HW + p;
+    const int img = blockIdx.z, c0 = blockIdx.y * CH;
+    const int p0 = blockIdx.x * NPIX;                                 // band = NPIX consecutive pixels of the plane
+    const int npix = min(NPIX, HW - p0);
+    const int r0 = p0 / W, r1 = (p0 + npix - 1) / W;                  // input rows the band touches
+    const int oh0 = (r0 >> 1) - 1;                                    // first pooled row that can reach the band
+    const int prow = (r1 >> 1) - oh0 + 1;                             // pooled rows staged
+    const int rowlen = prow * OW;
+    float* sdp = reinterpret_cast<float*>(smem);                      // [NC][prow][OW]
+    uint8_t* sarg = smem + (size_t)NC * rowlen * sizeof(float);       // [NC][prow][OW]
     const float* dpp = dp + (int64_t)img * ps_n;
     const uint8_t* ap = arg + (int64_t)img * ps_n;
-    float xv[CH + 4 * R];
-#pragma unroll
-    for (int i = 0; i < CH + 4 * R; ++i) {
-        const int c = c0 - 2 * R + i;
-        xv[i] = (c >= 0 && c < C) ? xp[(int64_t)c * HW] : 0.f;
+    for (int e = threadIdx.x; e < NC * rowlen; e += 256) {
+        const int ci = e / rowlen, rem = e - ci * rowlen;
+        const int rr = rem / OW, ow = rem - rr * OW;
+        const int c = c0 - R + ci, oh = oh0 + rr;
+        const bool ok = c >= 0 && c < C && oh >= 0 && oh < OH;
+        const int o = ok ? c * ps_c + oh * ps_h + ow : 0;
+        sdp[e] = ok ? dpp[o] : 0.f;
+        sarg[e] = ok ? ap[o] : (uint8_t)255;                           // 255 never equals a window-local index
     }
-    float t[CH + 2 * R], u[CH];
-#pragma unroll
-    for (int i = 0; i < CH + 2 * R; ++i) {
-        const int c = c0 - R + i;
-        float g = 0.f;
-        if (c >= 0 && c < C) {
-            const int64_t cb = (int64_t)c * ps_c;
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (woff[q] >= 0 && (int)ap[cb + woff[q]] == wloc[q]) g += dpp[cb + woff[q]];
-        }
-        float s = 0.f;
-#pragma unroll
-        for (int d = 0; d <= 2 * R; ++d) s += xv[i + d] * xv[i + d];
-        const float sc = bias + alpha * s;
-        const float pw = pow_neg(sc, beta);
-        t[i] = g * xv[i + R] * pw / sc;
-        if (i >= R && i < CH + R) u[i - R] = g * pw;
-    }
+    __syncthreads();
+    const float* xim = x + (int64_t)img * C * HW;
     const int wp = W + 2 * halo;
     const int64_t dplane = (int64_t)(H + 2 * halo) * wp;
-    float* dxp = dx + (int64_t)img * C * dplane + (int64_t)(py + halo) * wp + px + halo;
+    float* dxim = dx + (int64_t)img * C * dplane;
+    for (int pix = threadIdx.x; pix < npix; pix += 256) {
+        const int py = (p0 + pix) / W, px = (p0 + pix) - py * W;
+        // the <= 4 windows (k = 3, s = 2) containing (py, px), as LDS offsets within a channel slab
+        int woff[4], wloc[4];
 #pragma unroll
-    for (int i = 0; i < CH; ++i) {
-        if (c0 + i < C) {
-            float a = 0.f;
+        for (int a = 0; a < 2; ++a) {
+            const int oh = (py >> 1) - a, lr = (py & 1) + 2 * a;
+            const bool rok = oh >= 0 && oh < OH && lr <= 2;
 #pragma unroll
-            for (int d = 0; d <= 2 * R; ++d) a += t[i + d];
-            const float xc = xv[i + 2 * R];
-            float r = u[i] - 2.f * alpha * beta * xc * a;
-            if (relu_fused) r = xc > 0.f ? r : 0.f;
-            dxp[(int64_t)(c0 + i) * dplane] = r;
+            for (int b = 0; b < 2; ++b) {
+                const int ow = (px >> 1) - b, lc = (px & 1) + 2 * b;
+                const bool ok = rok && ow >= 0 && ow < OW && lc <= 2;
+                woff[a * 2 + b] = ok ? (oh - oh0) * OW + ow : 0;
+                wloc[a * 2 + b] = ok ? lr * 3 + lc : 254;              // 254: matches neither a real index nor the 255 filler
+            }
+        }
+        const float* xp = xim + (int64_t)py * W + px;
+        float xv[CH + 4 * R];
+#pragma unroll
+        for (int i = 0; i < CH + 4 * R; ++i) {
+            const int c = c0 - 2 * R + i;
+            xv[i] = (c >= 0 && c < C) ? xp[(int64_t)c * HW] : 0.f;
+        }
+        float t[NC], u[CH];
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            float g = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int o = i * rowlen + woff[q];
+                g += ((int)sarg[o] == wloc[q]) ? sdp[o] : 0.f;
+            }
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d <= 2 * R; ++d) s += xv[i + d] * xv[i + d];
+            const float sc = bias + alpha * s;
+            const float pw = pow_neg(sc, beta);
+            t[i] = g * xv[i + R] * pw * __builtin_amdgcn_rcpf(sc);
+            if (i >= R && i < CH + R) u[i - R] = g * pw;
+        }
+        float* dxp = dxim + (int64_t)(py + halo) * wp + px + halo;
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            if (c0 + i < C) {
+                float a = 0.f;
+#pragma unroll
+                for (int d = 0; d <= 2 * R; ++d) a += t[i + d];
+                const float xc = xv[i + 2 * R];
+                float r = u[i] - 2.f * alpha * beta * xc * a;
+                if (relu_fused) r = xc > 0.f ? r : 0.f;
+                dxp[(int64_t)(c0 + i) * dplane] = r;
+            }
         }
     }
 }
@@ -259,10 +282,14 @@ extern "C" int vl_pool_lrn_bwd(const float* x, const float* dp, const uint8_t* a
     const int owp = ow + 2 * p_halo;
     const int64_t pplane = (int64_t)(oh + 2 * p_halo) * owp;
     const int64_t origin = (int64_t)p_halo * owp + p_halo;
-    constexpr int CH = 16;
-    dim3 grid(ceil_div((int64_t)n * h * w, 256), ceil_div(c, CH));
-    hipLaunchKernelGGL((pool_lrn_bwd_kernel<CH, 2>), grid, dim3(256), 0, (hipStream_t)stream, x, dp + origin, argmax + origin, dx, n,
-                       c, h, w, oh, ow, (int64_t)c * pplane, pplane, owp, alpha, beta, bias, relu_fused, dx_halo);
+    constexpr int CH = 16, NPIX = 512;
+    VL_CHECK(n <= 65535, "vl_pool_lrn_bwd: batch %d exceeds the grid limit", n);
+    const int max_prow = ((NPIX + w - 1) / w + 1) / 2 + 3;             // pooled rows one band can touch
+    const size_t lds = (((size_t)(CH + 4) * max_prow * ow * (sizeof(float) + 1)) + 15) & ~(size_t)15;
+    VL_CHECK(lds <= 64 * 1024, "vl_pool_lrn_bwd: pooled plane too wide (%d) for the LDS staging", ow);
+    dim3 grid(ceil_div((int64_t)h * w, NPIX), ceil_div(c, CH), n);
+    hipLaunchKernelGGL((pool_lrn_bwd_kernel<CH, 2, NPIX>), grid, dim3(256), lds, (hipStream_t)stream, x, dp + origin, argmax + origin, dx,
+                       c, h, w, oh, ow, (int64_t)c * pplane, (int)pplane, owp, alpha, beta, bias, relu_fused, dx_halo);
     VL_LAUNCH_CHECK();
     return 0;
 }
@@ -292,43 +319,64 @@ extern "C" int vl_lrn_bwd(const float* x, const float* dy, float* dx, int n, int
 }
 
 // ---- max-pool VALID (alexnet.py:91-98) --------------------------------------------------------
-__global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, uint8_t* __restrict__ arg, int n, int C,
-                                   int H, int W, int OH, int OW, int k, int s, int64_t ysn, int64_t ysc, int64_t ysh,
-                                   int64_t ysw) {
-    const int64_t total = (int64_t)n * C * OH * OW;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int ow = (int)(e % OW);
-        const int oh = (int)((e / OW) % OH);
-        const int c = (int)((e / ((int64_t)OW * OH)) % C);
-        const int img = (int)(e / ((int64_t)OW * OH * C));
-        const float* xp = x + (((int64_t)img * C + c) * H + oh * s) * W + ow * s;
+// Index decode uses 32-bit magic-number division (total element counts are < 2^31, checked on the host);
+// K, S > 0 are compile-time for the 3x3/2 case the reference uses, 0 = runtime k, s.
+template <int K, int S>
+__global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, uint8_t* __restrict__ arg, uint32_t total,
+                                   int C, int H, int W, int OH, int OW, int k_, int s_, FastDiv dOHW, FastDiv dOW, FastDiv dC,
+                                   int64_t ysn, int64_t ysc, int64_t ysh, int64_t ysw) {
+    const int k = K ? K : k_, s = S ? S : s_;
+    const int OHW = OH * OW;
+    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const uint32_t plane = fd_div(e, dOHW);
+        const uint32_t p = e - plane * OHW;
+        const uint32_t oh = fd_div(p, dOW), ow = p - oh * OW;
+        const uint32_t img = fd_div(plane, dC), c = plane - img * C;
+        const float* xp = x + ((int64_t)plane * H + oh * s) * W + ow * s;
         float best = -INFINITY;
         int bi = 0;
-        for (int i = 0; i < k; ++i)
-            for (int j = 0; j < k; ++j) {
-                const float v = xp[i * W + j];
-                if (v > best) {  // strict: the first maximum in scan order wins
-                    best = v;
-                    bi = i * k + j;
+#pragma unroll
+        for (int i = 0; i < (K ? K : 1); ++i)
+#pragma unroll
+            for (int j = 0; j < (K ? K : 1); ++j) {
+                if (K) {
+                    const float v = xp[i * W + j];
+                    if (v > best) {  // strict: the first maximum in scan order wins
+                        best = v;
+                        bi = i * K + j;
+                    }
                 }
             }
+        if (!K) {
+            for (int i = 0; i < k; ++i)
+                for (int j = 0; j < k; ++j) {
+                    const float v = xp[i * W + j];
+                    if (v > best) {
+                        best = v;
+                        bi = i * k + j;
+                    }
+                }
+        }
         const int64_t o = img * ysn + c * ysc + oh * ysh + ow * ysw;
         y[o] = best;
         if (arg) arg[o] = (uint8_t)bi;
     }
 }
 
+template <int K, int S>
 __global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ arg, float* __restrict__ dx,
-                                   const float* __restrict__ mask, int n, int C, int H, int W, int OH, int OW, int k, int s,
-                                   int64_t ysn, int64_t ysc, int64_t ysh, int64_t ysw, int halo) {
-    const int64_t total = (int64_t)n * C * H * W;
+                                   const float* __restrict__ mask, uint32_t total, int C, int H, int W, int OH, int OW, int k_,
+                                   int s_, FastDiv dHW, FastDiv dW, FastDiv dC, int64_t ysn, int64_t ysc, int64_t ysh, int64_t ysw,
+                                   int halo) {
+    const int k = K ? K : k_, s = S ? S : s_;
+    const int HW = H * W;
     const int wp = W + 2 * halo;
     const int64_t pp = (int64_t)(H + 2 * halo) * wp;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int iw = (int)(e % W);
-        const int ih = (int)((e / W) % H);
-        const int c = (int)((e / ((int64_t)W * H)) % C);
-        const int img = (int)(e / ((int64_t)W * H * C));
+    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const uint32_t plane = fd_div(e, dHW);
+        const uint32_t p = e - plane * HW;
+        const int ih = (int)fd_div(p, dW), iw = (int)(p - ih * W);
+        const uint32_t img = fd_div(plane, dC), c = plane - img * C;
         float acc = 0.f;
         if (!mask || mask[e] > 0.f) {
             int oh_lo = (ih - k + s) / s;  // ceil((ih - k + 1) / s) for ih-k+1 >= 0
@@ -343,7 +391,7 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* 
                     if ((int)arg[o] == (ih - oh * s) * k + (iw - ow * s)) acc += dy[o];
                 }
         }
-        dx[((int64_t)img * C + c) * pp + (int64_t)(ih + halo) * wp + iw + halo] = acc;
+        dx[(int64_t)plane * pp + (int64_t)(ih + halo) * wp + iw + halo] = acc;
     }
 }
 
@@ -352,8 +400,15 @@ extern "C" int vl_maxpool_fwd(const float* x, float* y, uint8_t* argmax, int n, 
     VL_CHECK(x && y && n > 0 && c > 0 && k > 0 && s > 0 && h >= k && w >= k && k * k <= 255, "vl_maxpool_fwd: bad argument");
     const int oh = (h - k) / s + 1, ow = (w - k) / s + 1;
     const int64_t total = (int64_t)n * c * oh * ow;
-    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(total, 256, 16384)), dim3(256), 0, (hipStream_t)stream, x, y, argmax, n, c,
-                       h, w, oh, ow, k, s, ys_n, ys_c, ys_h, ys_w);
+    VL_CHECK(total < (1ll << 31) && (int64_t)n * c * h * w < (1ll << 40), "vl_maxpool_fwd: tensor too large");
+    const dim3 grid(grid_for(total, 256, 16384));
+    const FastDiv d1 = make_fastdiv(oh * ow), d2 = make_fastdiv(ow), d3 = make_fastdiv(c);
+    if (k == 3 && s == 2)
+        hipLaunchKernelGGL((maxpool_fwd_kernel<3, 2>), grid, dim3(256), 0, (hipStream_t)stream, x, y, argmax, (uint32_t)total, c, h, w, oh,
+                           ow, k, s, d1, d2, d3, ys_n, ys_c, ys_h, ys_w);
+    else
+        hipLaunchKernelGGL((maxpool_fwd_kernel<0, 0>), grid, dim3(256), 0, (hipStream_t)stream, x, y, argmax, (uint32_t)total, c, h, w, oh,
+                           ow, k, s, d1, d2, d3, ys_n, ys_c, ys_h, ys_w);
     VL_LAUNCH_CHECK();
     return 0;
 }
@@ -364,8 +419,15 @@ extern "C" int vl_maxpool_bwd(const float* dy, const uint8_t* argmax, float* dx,
     VL_CHECK(dy && argmax && dx && n > 0 && c > 0 && k > 0 && s > 0 && h >= k && w >= k && dx_halo >= 0, "vl_maxpool_bwd: bad argument");
     const int oh = (h - k) / s + 1, ow = (w - k) / s + 1;
     const int64_t total = (int64_t)n * c * h * w;
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total, 256, 16384)), dim3(256), 0, (hipStream_t)stream, dy, argmax, dx,
-                       relu_mask, n, c, h, w, oh, ow, k, s, ys_n, ys_c, ys_h, ys_w, dx_halo);
+    VL_CHECK(total < (1ll << 31), "vl_maxpool_bwd: tensor too large");
+    const dim3 grid(grid_for(total, 256, 16384));
+    const FastDiv d1 = make_fastdiv(h * w), d2 = make_fastdiv(w), d3 = make_fastdiv(c);
+    if (k == 3 && s == 2)
+        hipLaunchKernelGGL((maxpool_bwd_kernel<3, 2>), grid, dim3(256), 0, (hipStream_t)stream, dy, argmax, dx, relu_mask, (uint32_t)total,
+                           c, h, w, oh, ow, k, s, d1, d2, d3, ys_n, ys_c, ys_h, ys_w, dx_halo);
+    else
+        hipLaunchKernelGGL((maxpool_bwd_kernel<0, 0>), grid, dim3(256), 0, (hipStream_t)stream, dy, argmax, dx, relu_mask, (uint32_t)total,
+                           c, h, w, oh, ow, k, s, d1, d2, d3, ys_n, ys_c, ys_h, ys_w, dx_halo);
     VL_LAUNCH_CHECK();
     return 0;
 }
