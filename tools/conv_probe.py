@@ -23,12 +23,22 @@ def main():
     cin, h, w, cout, k, s, g = GEOM[layer]
     conv = ops.Conv(cin, h, w, cout, k, k, s, g)
     dev = "cuda:0"
-    x = torch.randn(n, cin, h, w, device=dev)
+    padded = os.environ.get("VL_PROBE_DENSE") is None          # default: the engine's zero-halo layout
+    xh = conv.same_pad() if padded else 0
+    dyh = conv.same_pad() if (padded and s == 1) else 0
+    conv.set_halo(xh, 0, dyh, 0)
+
+    def haloed(c_, h_, w_, halo):
+        t = torch.zeros(n, c_, h_ + 2 * halo, w_ + 2 * halo, device=dev)
+        t[:, :, halo:halo + h_, halo:halo + w_] = torch.randn(n, c_, h_, w_, device=dev)
+        return t
+
+    x = haloed(cin, h, w, xh)
     wt = torch.randn(k, k, cin // g, cout, device=dev) * 0.05
     b = torch.zeros(cout, device=dev)
     y = torch.empty(n, cout, conv.oh, conv.ow, device=dev)
-    dy = torch.randn(n, cout, conv.oh, conv.ow, device=dev)
-    dx = torch.empty_like(x)
+    dy = haloed(cout, conv.oh, conv.ow, dyh)
+    dx = torch.empty(n, cin, h, w, device=dev)
     dw = torch.empty_like(wt)
     wtt = torch.empty(wt.numel(), device=dev)
     ws = torch.empty(max(conv.wgrad_ws_bytes(n) // 4, 1), device=dev)

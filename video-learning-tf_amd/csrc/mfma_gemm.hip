@@ -30,6 +30,7 @@
 // B[r = l>>5][j = l&31]; D register q of lane l is D[i = (q&3) + 8*(q>>2) + 4*(l>>5)][j = l&31].
 // j is therefore the coalesced (lane) dimension of every store.
 #include <stdlib.h>
+#include <string.h>
 
 #include "common.h"
 
@@ -168,6 +169,7 @@ struct ConvGeom {
     int64_t img_stride;  // elements between images   (Cin_total * Pp)
     int64_t grp_stride;  // elements between groups   (Cin_g * Pp)
     int64_t total;       // elements in x
+    int zero;            // always 0: lets a loader make an address depend on the tile index without changing it
 };
 
 // im2col gather for forward / dgrad: x = output pixel across lanes (coalesced along ow), r = im2col
@@ -307,17 +309,20 @@ struct WgradGather {
 
 // dy rows for wgrad: x = output channel (within the group), r = output pixel across lanes.
 // dy is NCHW [n][Cout_total][OH + 2 halo][OW + 2 halo].
+struct DyParams {
+    const float* dy;
+    int M, OHW, OW, Cog, Cout_total, halo, OWp;
+    FastDiv dOHW, dOW;
+    int64_t plane;   // (OH + 2 halo) * OWp
+    int64_t total;   // elements in dy
+    int zero;        // always 0 (see ConvGeom::zero)
+};
+
 template <int BX, int BR>
 struct DyRows {
     using L = LdsTile<BX, BR>;
     static constexpr int NLD = BX * BR / NT;
-    struct Params {
-        const float* dy;
-        int M, OHW, OW, Cog, Cout_total, halo, OWp;
-        FastDiv dOHW, dOW;
-        int64_t plane;   // (OH + 2 halo) * OWp
-        int64_t total;   // elements in dy
-    };
+    using Params = DyParams;
     __amdgpu_buffer_rsrc_t rsrc;
     uint32_t co_off[NLD];
     bool co_ok[NLD];
@@ -363,6 +368,103 @@ struct DyRows {
     __device__ __forceinline__ void store(float* tile, const float (&v)[NLD]) const {
 #pragma unroll
         for (int j = 0; j < NLD; ++j) tile[loff[j]] = v[j];
+    }
+};
+
+// ---- wgrad, VALU-free form (padded layout only): the reduction tile is 64 pixels = the 64 lanes of a wave,
+// so one load instruction fetches ONE operand row for those pixels: the row's byte offset is a scalar
+// (soffset, from the table / from co * plane) and the per-lane pixel offset is decoded once per tile.
+template <int BX, int BR>
+struct WgradGatherU {
+    using L = LdsTile<BX, BR>;
+    static constexpr int NLD = BX * BR / NT;   // rows per wave (each wave owns NLD consecutive rows)
+    static_assert(BR == 64 && NLD * 4 == BX, "lanes are the reduction pixels");
+    using Params = ConvGeom;
+    __amdgpu_buffer_rsrc_t rsrc;
+    const int* tab;
+    int lbase, M, OHW, OW, stride, pt, pl, halo, Wp, zero;
+    FastDiv dOHW, dOW;
+    int64_t img_stride;
+    __device__ __forceinline__ void init(const Params& P, int x0, int zg) {
+        const int row0 = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) * NLD;
+        zero = P.zero;
+        tab = P.ktab + x0 + row0;
+        lbase = row0 * L::STR + (threadIdx.x & 63);
+        rsrc = make_rsrc(P.x + (int64_t)zg * P.grp_stride, (P.total - (int64_t)zg * P.grp_stride) * 4);
+        M = P.M; OHW = P.OHW; OW = P.OW; stride = P.stride; pt = P.pt; pl = P.pl; halo = P.halo; Wp = P.Wp;
+        dOHW = P.dOHW; dOW = P.dOW;
+        img_stride = P.img_stride;
+    }
+    __device__ __forceinline__ void prefetch(int) {}
+    __device__ __forceinline__ void load(int rt, float (&v)[NLD]) const {
+        const int m = rt * BR + (threadIdx.x & 63);
+        const bool vm = m < M;
+        const uint32_t mm = vm ? m : 0;
+        const uint32_t n = fd_div(mm, dOHW);
+        const uint32_t p = mm - n * OHW;
+        const uint32_t oh = fd_div(p, dOW);
+        const uint32_t ow = p - oh * OW;
+        const int ih0 = (int)oh * stride - pt + halo, iw0 = (int)ow * stride - pl + halo;
+        const uint32_t vo = (uint32_t)((int64_t)n * img_stride + (int64_t)ih0 * Wp + iw0) * 4u;
+        const uint32_t voff = vm ? vo : OOB_OFF;
+        // opaque per tile: keeps hipcc from hoisting NLD scalar offsets out of the tile loop (it spilled ~90 SGPRs)
+        const int* t = tab + rt * zero;   // zero is a kernel argument that is always 0 (uniform, but not foldable)
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) v[j] = buf_load(rsrc, voff, t[j]);
+    }
+    __device__ __forceinline__ void store(float* tile, const float (&v)[NLD]) const {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) tile[lbase + j * L::STR] = v[j];
+    }
+};
+
+template <int BX, int BR>
+struct DyRowsU {
+    using L = LdsTile<BX, BR>;
+    static constexpr int NLD = BX * BR / NT;
+    static_assert(BR == 64 && NLD * 4 == BX, "lanes are the reduction pixels");
+    using Params = DyParams;
+    __amdgpu_buffer_rsrc_t rsrc;
+    int lbase, M, OHW, OW, halo, OWp, row_bytes, first_bytes, nvalid, zero;
+    int64_t img_stride;
+    FastDiv dOHW, dOW;
+    __device__ __forceinline__ void init(const Params& P, int x0, int zg) {
+        const int row0 = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) * NLD;
+        zero = P.zero;
+        const int64_t goff = (int64_t)zg * P.Cog * P.plane;
+        rsrc = make_rsrc(P.dy + goff, (P.total - goff) * 4);
+        lbase = row0 * L::STR + (threadIdx.x & 63);
+        M = P.M; OHW = P.OHW; OW = P.OW; halo = P.halo; OWp = P.OWp;
+        img_stride = (int64_t)P.Cout_total * P.plane;
+        dOHW = P.dOHW; dOW = P.dOW;
+        row_bytes = (int)(P.plane * 4);
+        first_bytes = (x0 + row0) * row_bytes;
+        nvalid = P.Cog - (x0 + row0);   // rows of this wave that are real channels (uniform)
+    }
+    __device__ __forceinline__ void prefetch(int) {}
+    __device__ __forceinline__ void load(int rt, float (&v)[NLD]) const {
+        const int m = rt * BR + (threadIdx.x & 63);
+        const bool vm = m < M;
+        const uint32_t mm = vm ? m : 0;
+        const uint32_t n = fd_div(mm, dOHW);
+        const uint32_t p = mm - n * OHW;
+        const uint32_t oh = fd_div(p, dOW);
+        const uint32_t ow = p - oh * OW;
+        const uint32_t vo = (uint32_t)((int64_t)n * img_stride + (int64_t)(oh + halo) * OWp + ow + halo) * 4u;
+        const uint32_t voff = vm ? vo : OOB_OFF;
+        const int rb = row_bytes + rt * zero;   // opaque per tile (see WgradGatherU::load)
+        int so = first_bytes;
+        if (nvalid >= NLD) {
+#pragma unroll
+            for (int j = 0; j < NLD; ++j, so += rb) v[j] = buf_load(rsrc, voff, so);
+        } else {   // channel tail of the group (uniform per wave)
+#pragma unroll
+            for (int j = 0; j < NLD; ++j, so += rb) v[j] = j < nvalid ? buf_load(rsrc, voff, so) : 0.f;
+        }
+    }
+    __device__ __forceinline__ void store(float* tile, const float (&v)[NLD]) const {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) tile[lbase + j * L::STR] = v[j];
     }
 };
 
@@ -452,6 +554,15 @@ struct EpiConvNCHW {
     }
 };
 
+// XCD-aware tile order (cdna_hip_programming.md T1): workgroup ids are dealt round-robin over the 8 XCDs, each
+// with a private L2.  Remapping id -> (id % 8) * chunk + id / 8 gives every XCD a contiguous chunk of the tile
+// grid, so tiles that share operand panels (the co-tiles of one pixel tile, neighbouring pixel tiles) hit the
+// same L2.  Bijective for any grid size.  Placement only affects speed, never results.
+__device__ __forceinline__ int xcd_swizzle(int id, int n) {
+    const int q = n >> 3, r = n & 7, xcd = id & 7, k = id >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
 // ---- the kernel -------------------------------------------------------------------------------
 // grid.x = tiles_i * tiles_j (i fastest), grid.y = groups (zg), grid.z = reduction splits (zs).
 template <int BM, int BN, int BR, int WM, int WN, class LA, class LB, class EP>
@@ -466,7 +577,8 @@ __global__ __launch_bounds__(NT) void mfma_contract(const typename LA::Params pa
     constexpr int SA = BM * STR, SB = BN * STR;
     __shared__ __attribute__((aligned(16))) float lds[2 * (SA + SB)];
 
-    const int ti_blk = blockIdx.x % tiles_i, tj_blk = blockIdx.x / tiles_i;
+    const int bid = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int ti_blk = bid % tiles_i, tj_blk = bid / tiles_i;
     const int zg = blockIdx.y, zs = blockIdx.z;
     const int i0 = ti_blk * BM, j0 = tj_blk * BN;
     const int lane = threadIdx.x & 63;
@@ -553,6 +665,82 @@ __global__ __launch_bounds__(NT) void mfma_contract(const typename LA::Params pa
         __syncthreads();
     }
     if (ntiles > 0 && (ntiles & 1)) compute(0);   // ntiles <= 0 for a trailing, empty reduction split
+    EP::template apply<TM, TN>(pe, zg, zs, i0 + wi0, j0 + wj0, acc);
+}
+
+// Same contraction with ONE LDS buffer (large reduction tiles: wgrad's 64-pixel tiles need 68 KB): the next
+// tile is prefetched into registers during the MFMAs and written after a barrier; two workgroups per CU
+// cover each other's barrier/store phases.
+template <int BM, int BN, int BR, int WM, int WN, class LA, class LB, class EP>
+__global__ __launch_bounds__(NT) void mfma_contract_1buf(const typename LA::Params pa, const typename LB::Params pb,
+                                                         const typename EP::Params pe, int tiles_i, int rtiles,
+                                                         int rt_per_split) {
+    static_assert(WM * WN == 4 && BR % 4 == 0, "shape");
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int STR = BR + 2;
+    constexpr int SA = BM * STR;
+    extern __shared__ __attribute__((aligned(16))) float lds1[];
+    const int bid = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int ti_blk = bid % tiles_i, tj_blk = bid / tiles_i;
+    const int zg = blockIdx.y, zs = blockIdx.z;
+    const int i0 = ti_blk * BM, j0 = tj_blk * BN;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wi0 = (wave / WN) * (BM / WM), wj0 = (wave % WN) * (BN / WN);
+    LA la;
+    LB lb;
+    la.init(pa, i0, zg);
+    lb.init(pb, j0, zg);
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
+    const float* fa = lds1 + (wi0 + (lane & 31)) * STR + 2 * (lane >> 5);
+    const float* fb = lds1 + SA + (wj0 + (lane & 31)) * STR + 2 * (lane >> 5);
+    const int rt0 = zs * rt_per_split;
+    const int rt1 = min(rtiles, rt0 + rt_per_split);
+    float ra[LA::NLD], rb[LB::NLD];
+    if (rt0 < rt1) {
+        la.load(rt0, ra);
+        lb.load(rt0, rb);
+        la.store(lds1, ra);
+        lb.store(lds1 + SA, rb);
+    }
+    __syncthreads();
+    for (int rt = rt0; rt < rt1; ++rt) {
+        const bool more = rt + 1 < rt1;
+        if (more) {
+            la.load(rt + 1, ra);
+            lb.load(rt + 1, rb);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < BR / 4; ++t) {
+            float2 af[TM], bf[TN];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) af[a] = *reinterpret_cast<const float2*>(fa + a * 32 * STR + 4 * t);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) bf[b] = *reinterpret_cast<const float2*>(fb + b * 32 * STR + 4 * t);
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].x, bf[b].x, acc[a][b], 0, 0, 0);
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].y, bf[b].y, acc[a][b], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        if (more) {
+            la.store(lds1, ra);
+            lb.store(lds1 + SA, rb);
+        }
+        __syncthreads();
+    }
     EP::template apply<TM, TN>(pe, zg, zs, i0 + wi0, j0 + wj0, acc);
 }
 
@@ -750,6 +938,7 @@ static void fill_geom(ConvGeom& g, const float* x, int n, int cin_total, int cig
     g.img_stride = (int64_t)cin_total * Pp;
     g.grp_stride = (int64_t)cig * Pp;
     g.total = g.img_stride * n;
+    g.zero = 0;
 }
 
 extern "C" int vl_conv_fwd(const vl_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int n,
@@ -806,9 +995,74 @@ extern "C" int vl_conv_dgrad(const vl_conv_desc* d, const float* dy, const float
 }
 
 // ---- conv wgrad -------------------------------------------------------------------------------
+static void dy_params(const vl_conv_desc* d, const ConvGeom& g, const float* dy, DyParams& pb) {
+    pb.dy = dy; pb.M = g.M; pb.OHW = g.OHW; pb.OW = g.OW; pb.Cog = d->cog; pb.Cout_total = d->cout; pb.halo = d->dy_halo;
+    pb.OWp = d->ow + 2 * d->dy_halo; pb.dOHW = g.dOHW; pb.dOW = g.dOW;
+    pb.plane = (int64_t)(d->oh + 2 * d->dy_halo) * pb.OWp;
+    pb.total = (int64_t)d->cout * pb.plane * (g.M / g.OHW);
+    pb.zero = 0;
+}
+
+static int reduce_wgrad(const vl_conv_desc* d, float* dw, const float* ws, int splits, hipStream_t s) {
+    const int64_t slab = (int64_t)d->K * d->cout;
+    if (splits > 1) {
+        const int blocks = (int)((slab + 255) / 256 < 4096 ? (slab + 255) / 256 : 4096);
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, s, ws, dw, slab, splits, slab, nullptr, 0, 0, 0, nullptr);
+        VL_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+// checked-mode (dense NCHW input) wgrad: 32-pixel tiles, per-element bounds tests
+template <int BN, int WM, int WN>
+static int launch_wgrad(const vl_conv_desc* d, const ConvGeom& g, const float* dy, float* dw, float* ws, int splits,
+                        hipStream_t s) {
+    constexpr int BM = 128, BR = 32;
+    using LA = WgradGather<BM, BR, false>;
+    using LB = DyRows<BN, BR>;
+    DyParams pb;
+    dy_params(d, g, dy, pb);
+    const int64_t slab = (int64_t)d->K * d->cout;
+    EpiRowMajor::Params pe{splits > 1 ? ws : dw, d->cout, d->K, d->cog, nullptr, nullptr, 0, d->cog, splits > 1 ? slab : 0};
+    const int tiles_i = ceil_div(d->K, BM), tiles_j = ceil_div(d->cog, BN);
+    const int rtiles = ceil_div(g.M, BR);
+    dim3 grid(tiles_i * tiles_j, d->groups, splits);
+    hipLaunchKernelGGL((mfma_contract<BM, BN, BR, WM, WN, LA, LB, EpiRowMajor>), grid, dim3(NT), 0, s, g, pb, pe, tiles_i, rtiles,
+                       ceil_div(rtiles, splits));
+    VL_LAUNCH_CHECK();
+    return reduce_wgrad(d, dw, ws, splits, s);
+}
+
+// padded-mode wgrad: 64-pixel tiles, wave-uniform rows, no per-element VALU
+template <int BN, int WM, int WN>
+static int launch_wgrad_u(const vl_conv_desc* d, const ConvGeom& g, const float* dy, float* dw, float* ws, int splits,
+                          hipStream_t s) {
+    constexpr int BM = 128, BR = 64;
+    using LA = WgradGatherU<BM, BR>;
+    using LB = DyRowsU<BN, BR>;
+    DyParams pb;
+    dy_params(d, g, dy, pb);
+    const int64_t slab = (int64_t)d->K * d->cout;
+    EpiRowMajor::Params pe{splits > 1 ? ws : dw, d->cout, d->K, d->cog, nullptr, nullptr, 0, d->cog, splits > 1 ? slab : 0};
+    const int tiles_i = ceil_div(d->K, BM), tiles_j = ceil_div(d->cog, BN);
+    const int rtiles = ceil_div(g.M, BR);
+    constexpr size_t lds = (size_t)(BM + BN) * (BR + 2) * sizeof(float);
+    static bool attr_set = false;
+    auto kern = mfma_contract_1buf<BM, BN, BR, WM, WN, LA, LB, EpiRowMajor>;
+    if (!attr_set) {
+        VL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    dim3 grid(tiles_i * tiles_j, d->groups, splits);
+    hipLaunchKernelGGL(kern, grid, dim3(NT), lds, s, g, pb, pe, tiles_i, rtiles, ceil_div(rtiles, splits));
+    VL_LAUNCH_CHECK();
+    return reduce_wgrad(d, dw, ws, splits, s);
+}
+
 static int wgrad_splits(const vl_conv_desc* d, int n) {
+    // the reduction runs over 32-pixel (checked) or 64-pixel (padded) tiles; aim at ~2048 workgroups
     const int64_t M = (int64_t)n * d->oh * d->ow;
-    const int rtiles = ceil_div(M, 32);
+    const int rtiles = ceil_div(M, d->fwd_padded ? 64 : 32);
     const int tiles = ceil_div(d->K, 128) * ceil_div(d->cog, d->cog % 128 == 0 ? 128 : 96) * d->groups;
     int splits = ceil_div(2048, tiles);
     if (splits > rtiles) splits = rtiles;
@@ -819,35 +1073,6 @@ static int wgrad_splits(const vl_conv_desc* d, int n) {
 extern "C" size_t vl_conv_wgrad_ws_bytes(const vl_conv_desc* d, int n) {
     if (!d || n <= 0) return 0;
     return (size_t)wgrad_splits(d, n) * d->K * d->cout * sizeof(float);
-}
-
-template <int BN, int WM, int WN, bool PADDED>
-static int launch_wgrad(const vl_conv_desc* d, const ConvGeom& g, const float* dy, float* dw, float* ws, int splits,
-                        hipStream_t s) {
-    constexpr int BM = 128, BR = 32;
-    using LA = WgradGather<BM, BR, PADDED>;
-    using LB = DyRows<BN, BR>;
-    typename LB::Params pb;
-    pb.dy = dy; pb.M = g.M; pb.OHW = g.OHW; pb.OW = g.OW; pb.Cog = d->cog; pb.Cout_total = d->cout; pb.halo = d->dy_halo;
-    pb.OWp = d->ow + 2 * d->dy_halo; pb.dOHW = g.dOHW; pb.dOW = g.dOW;
-    pb.plane = (int64_t)(d->oh + 2 * d->dy_halo) * pb.OWp;
-    pb.total = (int64_t)d->cout * pb.plane * (g.M / g.OHW);
-    const int64_t slab = (int64_t)d->K * d->cout;
-    // slab z: [K][Cout_total], group g = column block
-    EpiRowMajor::Params pe{splits > 1 ? ws : dw, d->cout, d->K, d->cog, nullptr, nullptr, 0, d->cog, splits > 1 ? slab : 0};
-    const int tiles_i = ceil_div(d->K, BM), tiles_j = ceil_div(d->cog, BN);
-    const int rtiles = ceil_div(g.M, BR);
-    const int per = ceil_div(rtiles, splits);
-    dim3 grid(tiles_i * tiles_j, d->groups, splits);
-    hipLaunchKernelGGL((mfma_contract<BM, BN, BR, WM, WN, LA, LB, EpiRowMajor>), grid, dim3(NT), 0, s, g, pb, pe, tiles_i, rtiles,
-                       per);
-    VL_LAUNCH_CHECK();
-    if (splits > 1) {
-        const int blocks = (int)((slab + 255) / 256 < 4096 ? (slab + 255) / 256 : 4096);
-        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, s, ws, dw, slab, splits, slab, nullptr, 0, 0, 0, nullptr);
-        VL_LAUNCH_CHECK();
-    }
-    return 0;
 }
 
 extern "C" int vl_conv_wgrad(const vl_conv_desc* d, const float* x, const float* dy, float* dw, void* ws, size_t ws_bytes,
@@ -863,11 +1088,11 @@ extern "C" int vl_conv_wgrad(const vl_conv_desc* d, const float* x, const float*
     VL_CHECK(g.total * 4 < MAX_BUF_BYTES && dy_total * 4 < MAX_BUF_BYTES, "vl_conv_wgrad: operand exceeds the buffer-offset range");
     hipStream_t s = (hipStream_t)stream;
     if (d->cog % 128 == 0) {
-        if (d->fwd_padded) return launch_wgrad<128, 2, 2, true>(d, g, dy, dw, (float*)ws, splits, s);
-        return launch_wgrad<128, 2, 2, false>(d, g, dy, dw, (float*)ws, splits, s);
+        if (d->fwd_padded) return launch_wgrad_u<128, 2, 2>(d, g, dy, dw, (float*)ws, splits, s);
+        return launch_wgrad<128, 2, 2>(d, g, dy, dw, (float*)ws, splits, s);
     }
-    if (d->fwd_padded) return launch_wgrad<96, 4, 1, true>(d, g, dy, dw, (float*)ws, splits, s);
-    return launch_wgrad<96, 4, 1, false>(d, g, dy, dw, (float*)ws, splits, s);
+    if (d->fwd_padded) return launch_wgrad_u<96, 4, 1>(d, g, dy, dw, (float*)ws, splits, s);
+    return launch_wgrad<96, 4, 1>(d, g, dy, dw, (float*)ws, splits, s);
 }
 
 // ---- dense GEMM -------------------------------------------------------------------------------
