@@ -139,6 +139,17 @@ int vl_lstm_step_fwd(const float* gx, const float* gh, float* act, float* cseq, 
 int vl_lstm_step_bwd(const float* dout, const float* dh_next, const float* act, const float* cseq, float* dc,
                      float* dz, int batch, int T, int t, int H, vl_stream_t stream);
 
+/* Persistent form of the recurrence: all T steps of every clip in ONE launch (clips are independent, a clip
+ * lives in one workgroup slice; no inter-workgroup traffic).  kh = kernel[D:] ([H][4H], row stride 4H).
+ * Same outputs as T x {vl_gemm + vl_lstm_step_fwd}.  H <= 1024. */
+int vl_lstm_seq_fwd(const float* gx, const float* kh, float* act, float* cseq, float* hseq, float* hprev,
+                    int batch, int T, int H, float forget_bias, vl_stream_t stream);
+/* BPTT over all steps: kh_t = transpose of kh ([4H][H], see vl_transpose); dout may be NULL; writes dz[r][4H]. */
+int vl_lstm_seq_bwd(const float* dout, const float* kh_t, const float* act, const float* cseq, float* dz,
+                    int batch, int T, int H, vl_stream_t stream);
+/* dst[cols][rows] = src[rows][cols]^T (src row stride ld). */
+int vl_transpose(const float* src, int64_t ld, float* dst, int rows, int cols, vl_stream_t stream);
+
 /* ---- apply_temporal_fusion (tf_util.py:4-30) over x[batch][T][H] ---------------------------------
  * method 0 = avg, 1 = last. */
 int vl_temporal_fusion_fwd(const float* x, float* y, int batch, int T, int H, int method, vl_stream_t stream);

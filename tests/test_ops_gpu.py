@@ -327,6 +327,39 @@ def test_lstm_steps_match_layer(ops):
     close(host(dx).reshape(b, T, d), dxo, rtol=1e-4, atol_rel=1e-5, msg="lstm dx")
 
 
+@pytest.mark.parametrize("b,T,d,H", [(5, 4, 24, 16), (3, 6, 40, 256), (9, 3, 12, 300), (2, 2, 8, 7)])
+def test_lstm_persistent_kernels(ops, b, T, d, H):
+    """vl_lstm_seq_fwd / _bwd (one launch for all steps) against the oracle layer, incl. H > 256 (two waves per clip)."""
+    rng = np.random.default_rng(b * H)
+    x = rng.standard_normal((b, T, d)).astype(np.float32)
+    kern = (rng.standard_normal((d + H, 4 * H)) * (0.5 / math.sqrt(H))).astype(np.float32)
+    bias = (rng.standard_normal(4 * H) * 0.1).astype(np.float32)
+    out, (c_last, _), cache = O.lstm_layer_forward(x, kern, bias)
+    xd, kd = dev(x.reshape(b * T, d)), dev(kern)
+    gx = torch.empty((b * T, 4 * H), device=DEV)
+    ops.gemm(xd, kd, gx, b * T, 4 * H, d, bias=dev(bias))
+    act, cseq = torch.empty((b * T, 4 * H), device=DEV), torch.empty((b * T, H), device=DEV)
+    hseq, hprev = torch.empty((b * T, H), device=DEV), torch.empty((b * T, H), device=DEV)
+    ops.lstm_seq_fwd(gx, kd[d:], act, cseq, hseq, hprev, b, T, H)
+    close(host(hseq).reshape(b, T, H), out, rtol=1e-5, atol_rel=1e-6, msg="outputs")
+    close(host(cseq).reshape(b, T, H)[:, -1], c_last, rtol=1e-5, atol_rel=1e-6)
+    close(host(hprev).reshape(b, T, H), np.concatenate([np.zeros((b, 1, H)), out[:, :-1]], axis=1), rtol=1e-5, atol_rel=1e-6)
+    dout = rng.standard_normal(out.shape).astype(np.float32)
+    dxo, dko, dbo, _, _ = O.lstm_layer_backward(kern, cache, dout)
+    kt = torch.empty((4 * H, H), device=DEV)
+    ops.transpose(kd[d:], kt, H, 4 * H)
+    np.testing.assert_array_equal(host(kt), kern[d:].T)
+    dz = torch.empty((b * T, 4 * H), device=DEV)
+    ops.lstm_seq_bwd(dev(dout.reshape(b * T, H)), kt, act, cseq, dz, b, T, H)
+    dk = torch.empty_like(kd)
+    ops.gemm(xd, dz, dk, d, 4 * H, b * T, transa=True)
+    ops.gemm(hprev, dz, dk[d:], H, 4 * H, b * T, transa=True)
+    dx = torch.empty((b * T, d), device=DEV)
+    ops.gemm(dz, kd, dx, b * T, d, 4 * H, transb=True)
+    close(host(dk), dko, rtol=1e-4, atol_rel=1e-5, msg="dkernel")
+    close(host(dx).reshape(b, T, d), dxo, rtol=1e-4, atol_rel=1e-5, msg="dx")
+
+
 @pytest.mark.parametrize("method", ["avg", "last"])
 def test_temporal_fusion(ops, method):
     rng = np.random.default_rng(5)

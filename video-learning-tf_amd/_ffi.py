@@ -36,6 +36,9 @@ SIGNATURES = {
     "vl_colsum": (i32, [p, i64, p, p, i32, i32, p]),
     "vl_lstm_step_fwd": (i32, [p, p, p, p, p, p, i32, i32, i32, i32, f32, p]),
     "vl_lstm_step_bwd": (i32, [p, p, p, p, p, p, i32, i32, i32, i32, p]),
+    "vl_lstm_seq_fwd": (i32, [p, p, p, p, p, p, i32, i32, i32, f32, p]),
+    "vl_lstm_seq_bwd": (i32, [p, p, p, p, p, i32, i32, i32, p]),
+    "vl_transpose": (i32, [p, i64, p, i32, i32, p]),
     "vl_temporal_fusion_fwd": (i32, [p, p, i32, i32, i32, i32, p]),
     "vl_temporal_fusion_bwd": (i32, [p, p, i32, i32, i32, i32, p]),
     "vl_dropout_fwd": (i32, [p, p, p, i64, f32, u64, p]),

@@ -578,6 +578,155 @@ extern "C" int vl_lstm_step_bwd(const float* dout, const float* dh_next, const f
     return 0;
 }
 
+// ---- persistent per-clip LSTM recurrence ------------------------------------------------------------
+// Clips are independent, so the whole T-step recurrence of a clip runs inside ONE workgroup with no
+// inter-workgroup traffic: lane u owns hidden unit u (all four gates), h_{t-1} / dz_t are exchanged through
+// LDS, and the recurrent weights (kh = kernel[D:], [H][4H]) are streamed from L2 every step (1 MB for H = 256).
+// Loads are staged through a register array so a whole batch is in flight (hipcc otherwise waits after every
+// load), and every clip starts at a different row so the CUs do not hit one L2 channel in lockstep.
+// Replaces T x {vl_gemm(M = clips), vl_lstm_step_*} launches.
+template <bool BWD>
+__global__ void lstm_seq_kernel(const float* __restrict__ gx, const float* __restrict__ kmat, float* __restrict__ act,
+                                float* __restrict__ cseq, float* __restrict__ hseq, float* __restrict__ hprev,
+                                const float* __restrict__ dout, float* __restrict__ dz, int T, int H, float forget_bias) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int b = blockIdx.x, u = threadIdx.x;
+    const bool live = u < H;
+    const int uc = live ? u : 0;                       // clamped: idle lanes load valid addresses, results unused
+    const int H4 = 4 * H;
+    constexpr int KB = 16;
+    if (!BWD) {
+        float c = 0.f;
+        for (int i = threadIdx.x; i < H; i += blockDim.x) sm[i] = 0.f;
+        __syncthreads();
+        const int nb = H / KB, rot = (b * 5) % (nb > 0 ? nb : 1);
+        for (int t = 0; t < T; ++t) {
+            const int64_t r = (int64_t)b * T + t;
+            float z[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) z[q] = gx[r * H4 + q * H + uc];
+            if (t > 0) {
+                for (int ib = 0; ib < nb; ++ib) {
+                    const int kb = ((ib + rot) % nb) * KB;
+                    float w[KB][4];
+#pragma unroll
+                    for (int kk = 0; kk < KB; ++kk)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) w[kk][q] = kmat[(int64_t)(kb + kk) * H4 + q * H + uc];
+#pragma unroll
+                    for (int kk = 0; kk < KB; ++kk) {
+                        const float hk = sm[kb + kk];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) z[q] += hk * w[kk][q];
+                    }
+                }
+                for (int k = nb * KB; k < H; ++k) {
+                    const float hk = sm[k];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) z[q] += hk * kmat[(int64_t)k * H4 + q * H + uc];
+                }
+            }
+            const float hp = sm[uc];
+            __syncthreads();                           // everyone has consumed h_{t-1}
+            if (live) {
+                const float gi = sigmoidf_(z[0]), gj = tanhf(z[1]), gf = sigmoidf_(z[2] + forget_bias), go = sigmoidf_(z[3]);
+                c = c * gf + gi * gj;
+                const float h = tanhf(c) * go;
+                sm[u] = h;
+                float* a = act + r * H4 + u;
+                a[0] = gi; a[H] = gj; a[2 * H] = gf; a[3 * H] = go;
+                cseq[r * H + u] = c;
+                hseq[r * H + u] = h;
+                hprev[r * H + u] = hp;
+            }
+            __syncthreads();                           // h_t visible before the next step
+        }
+    } else {
+        // kmat = khT [4H][H]: dh_prev[u] = sum_g dz[g] * khT[g][u]
+        float dc = 0.f, dh = 0.f;
+        const int nb = H4 / KB, rot = (b * 5) % (nb > 0 ? nb : 1);
+        for (int t = T - 1; t >= 0; --t) {
+            const int64_t r = (int64_t)b * T + t;
+            if (live) {
+                const float din = (dout ? dout[r * H + u] : 0.f) + dh;
+                const float* a = act + r * H4 + u;
+                const float gi = a[0], gj = a[H], gf = a[2 * H], go = a[3 * H];
+                const float cc = cseq[r * H + u];
+                const float cp = t > 0 ? cseq[(r - 1) * H + u] : 0.f;
+                const float tc = tanhf(cc);
+                const float d_o = din * tc;
+                const float dcv = dc + din * go * (1.f - tc * tc);
+                const float zi = dcv * gj * gi * (1.f - gi), zj = dcv * gi * (1.f - gj * gj);
+                const float zf = dcv * cp * gf * (1.f - gf), zo = d_o * go * (1.f - go);
+                dc = dcv * gf;
+                float* zp = dz + r * H4 + u;
+                zp[0] = zi; zp[H] = zj; zp[2 * H] = zf; zp[3 * H] = zo;
+                sm[u] = zi; sm[H + u] = zj; sm[2 * H + u] = zf; sm[3 * H + u] = zo;
+            }
+            __syncthreads();                           // dz_t complete in LDS
+            if (t > 0) {
+                float acc = 0.f;
+                for (int ib = 0; ib < nb; ++ib) {
+                    const int g = ((ib + rot) % nb) * KB;
+                    float w[KB];
+#pragma unroll
+                    for (int gg = 0; gg < KB; ++gg) w[gg] = kmat[(int64_t)(g + gg) * H + uc];
+#pragma unroll
+                    for (int gg = 0; gg < KB; ++gg) acc += sm[g + gg] * w[gg];
+                }
+                for (int g = nb * KB; g < H4; ++g) acc += sm[g] * kmat[(int64_t)g * H + uc];
+                dh = acc;
+            }
+            __syncthreads();                           // dz_t consumed before it is overwritten
+        }
+    }
+}
+
+static int lstm_seq_threads(int H) { return ((H + 63) / 64) * 64; }
+
+extern "C" int vl_lstm_seq_fwd(const float* gx, const float* kh, float* act, float* cseq, float* hseq, float* hprev, int batch,
+                               int T, int H, float forget_bias, vl_stream_t stream) {
+    VL_CHECK(gx && kh && act && cseq && hseq && hprev, "vl_lstm_seq_fwd: null argument");
+    VL_CHECK(batch > 0 && T > 0 && H > 0 && H <= 1024, "vl_lstm_seq_fwd: bad shape (hidden size must be <= 1024)");
+    hipLaunchKernelGGL((lstm_seq_kernel<false>), dim3(batch), dim3(lstm_seq_threads(H)), (size_t)H * sizeof(float),
+                       (hipStream_t)stream, gx, kh, act, cseq, hseq, hprev, (const float*)nullptr, (float*)nullptr, T, H, forget_bias);
+    VL_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vl_lstm_seq_bwd(const float* dout, const float* kh_t, const float* act, const float* cseq, float* dz, int batch,
+                               int T, int H, vl_stream_t stream) {
+    VL_CHECK(kh_t && act && cseq && dz, "vl_lstm_seq_bwd: null argument");
+    VL_CHECK(batch > 0 && T > 0 && H > 0 && H <= 1024, "vl_lstm_seq_bwd: bad shape (hidden size must be <= 1024)");
+    hipLaunchKernelGGL((lstm_seq_kernel<true>), dim3(batch), dim3(lstm_seq_threads(H)), (size_t)4 * H * sizeof(float),
+                       (hipStream_t)stream, (const float*)nullptr, kh_t, const_cast<float*>(act), const_cast<float*>(cseq),
+                       (float*)nullptr, (float*)nullptr, dout, dz, T, H, 0.f);
+    VL_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void transpose2d_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols, int64_t ld) {
+    __shared__ float tile[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+        const int r = by + i, c = bx + threadIdx.x;
+        tile[i][threadIdx.x] = (r < rows && c < cols) ? src[(int64_t)r * ld + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+        const int r = bx + i, c = by + threadIdx.x;     // dst is [cols][rows]
+        if (r < cols && c < rows) dst[(int64_t)r * rows + c] = tile[threadIdx.x][i];
+    }
+}
+
+extern "C" int vl_transpose(const float* src, int64_t ld, float* dst, int rows, int cols, vl_stream_t stream) {
+    VL_CHECK(src && dst && rows > 0 && cols > 0 && ld >= cols, "vl_transpose: bad argument");
+    hipLaunchKernelGGL(transpose2d_kernel, dim3(ceil_div(cols, 32), ceil_div(rows, 32)), dim3(32, 8), 0, (hipStream_t)stream, src,
+                       dst, rows, cols, ld);
+    VL_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---- temporal fusion (tf_util.py:4-30) --------------------------------------------------------
 __global__ void temporal_fusion_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int batch, int T, int H,
                                            int method) {

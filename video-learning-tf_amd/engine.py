@@ -239,6 +239,7 @@ class LRCNEngine:
             self.logits = buf(B, C) if H != C else self.dropped
             if training:
                 self.dh, self.dc = buf(B, H), buf(B, H)
+                self.kh_t = buf(4 * H, H)
                 self.dfused, self.ddropped = buf(B, H), buf(B, H)
         else:
             ff = cfg.frame_fusion
@@ -360,11 +361,14 @@ class LRCNEngine:
                 K = P[pre + "kernel"]
                 # hoisted input projection for all (clip, t) rows, then the serial recurrence
                 ops.gemm(xin, K, S["gx"], n, 4 * H, d, bias=P[pre + "bias"], ws=self.ws)
-                for t in range(T):
-                    if t > 0:
-                        ops.gemm(S["hseq"][t - 1:], K[d:], self.gh, b, 4 * H, H, lda=T * H)
-                    ops.lstm_step_fwd(S["gx"], self.gh if t > 0 else None, S["act"], S["cseq"], S["hseq"], S["hprev"], b, T, t,
-                                      H, FORGET_BIAS)
+                if H <= 1024:
+                    ops.lstm_seq_fwd(S["gx"], K[d:], S["act"], S["cseq"], S["hseq"], S["hprev"], b, T, H, FORGET_BIAS)
+                else:
+                    for t in range(T):
+                        if t > 0:
+                            ops.gemm(S["hseq"][t - 1:], K[d:], self.gh, b, 4 * H, H, lda=T * H)
+                        ops.lstm_step_fwd(S["gx"], self.gh if t > 0 else None, S["act"], S["cseq"], S["hseq"], S["hprev"], b, T,
+                                          t, H, FORGET_BIAS)
                 xin, d = S["hseq"], H
             ops.temporal_fusion_fwd(xin, self.fused, b, T, H, cfg.fusion)
             v = self.fused
@@ -426,11 +430,15 @@ class LRCNEngine:
                 K = P[pre + "kernel"]
                 din = D if l == 0 else H
                 xin = self.feat if l == 0 else self.lstm[l - 1]["hseq"]
-                ops.fill(self.dc, 0.0)
-                for t in reversed(range(T)):
-                    ops.lstm_step_bwd(S["dout"], self.dh if t < T - 1 else None, S["act"], S["cseq"], self.dc, S["dz"], b, T, t, H)
-                    if t > 0:
-                        ops.gemm(S["dz"][t:], K[din:], self.dh, b, H, 4 * H, transb=True, lda=T * 4 * H)
+                if H <= 1024:
+                    ops.transpose(K[din:], self.kh_t, H, 4 * H)
+                    ops.lstm_seq_bwd(S["dout"], self.kh_t, S["act"], S["cseq"], S["dz"], b, T, H)
+                else:
+                    ops.fill(self.dc, 0.0)
+                    for t in reversed(range(T)):
+                        ops.lstm_step_bwd(S["dout"], self.dh if t < T - 1 else None, S["act"], S["cseq"], self.dc, S["dz"], b, T, t, H)
+                        if t > 0:
+                            ops.gemm(S["dz"][t:], K[din:], self.dh, b, H, 4 * H, transb=True, lda=T * 4 * H)
                 ops.gemm(xin, S["dz"], G[pre + "kernel"], din, 4 * H, n, transa=True, ws=self.ws)
                 ops.gemm(S["hprev"], S["dz"], G[pre + "kernel"][din:], H, 4 * H, n, transa=True, ws=self.ws)
                 ops.colsum(S["dz"], G[pre + "bias"], sw, n, 4 * H)

@@ -233,6 +233,22 @@ def lstm_step_bwd(dout, dh_next, act, cseq, dc, dz, batch, T, t, H):
     _ffi.call("vl_lstm_step_bwd", _p(dout), _p(dh_next), _p(act), _p(cseq), _p(dc), _p(dz), batch, T, t, H, stream())
 
 
+def lstm_seq_fwd(gx, kh, act, cseq, hseq, hprev, batch, T, H, forget_bias=1.0):
+    """All T steps in one persistent launch; kh = kernel[D:] view ([H, 4H])."""
+    _f32(gx, kh, act, cseq, hseq, hprev)
+    _ffi.call("vl_lstm_seq_fwd", _p(gx), _p(kh), _p(act), _p(cseq), _p(hseq), _p(hprev), batch, T, H, forget_bias, stream())
+
+
+def lstm_seq_bwd(dout, kh_t, act, cseq, dz, batch, T, H):
+    _f32(dout, kh_t, act, cseq, dz)
+    _ffi.call("vl_lstm_seq_bwd", _p(dout), _p(kh_t), _p(act), _p(cseq), _p(dz), batch, T, H, stream())
+
+
+def transpose(src, dst, rows, cols, ld=None):
+    _f32(src, dst)
+    _ffi.call("vl_transpose", _p(src), ld if ld is not None else cols, _p(dst), rows, cols, stream())
+
+
 FUSION_CODE = {"avg": 0, "last": 1}
 
 
