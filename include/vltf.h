@@ -76,10 +76,14 @@ int vl_conv_wt_transpose(const vl_conv_desc* d, const float* w_hwio, float* wt, 
  * (same shape as dx) the ReluGrad of the producing layer is fused: dx = relu_mask > 0 ? dx : 0. */
 int vl_conv_dgrad(const vl_conv_desc* d, const float* dy, const float* wt, float* dx, const float* relu_mask,
                   int n, vl_stream_t stream);
-/* dw (HWIO) = d(loss)/dw.  Deterministic split reduction through `ws` (>= vl_conv_wgrad_ws_bytes). */
+/* dw (HWIO) = d(loss)/dw.  Deterministic split reduction through `ws` (>= vl_conv_wgrad_ws_bytes).
+ * db (optional, [cout]): the bias gradient sum_{n,h,w} dy, accumulated from the dy tiles the kernel streams
+ * anyway (no second pass over dy); available when vl_conv_wgrad_fuses_bias() != 0 (padded layout), else pass
+ * NULL and use vl_bias_grad_nchw. */
 size_t vl_conv_wgrad_ws_bytes(const vl_conv_desc* d, int n);
-int vl_conv_wgrad(const vl_conv_desc* d, const float* x, const float* dy, float* dw, void* ws, size_t ws_bytes,
-                  int n, vl_stream_t stream);
+int vl_conv_wgrad_fuses_bias(const vl_conv_desc* d);
+int vl_conv_wgrad(const vl_conv_desc* d, const float* x, const float* dy, float* dw, float* db, void* ws,
+                  size_t ws_bytes, int n, vl_stream_t stream);
 /* db[c] = sum_{n,h,w} dy[n][c][h][w]  (gradient of tf.nn.bias_add, alexnet.py:31).
  * ws: float[64*c] scratch. */
 int vl_bias_grad_nchw(const float* dy, float* db, float* ws, int n, int c, int hw, vl_stream_t stream);

@@ -140,6 +140,16 @@ def test_conv_fwd_bwd(ops, padded, n, h, w, cin, cout, k, s, g):
     db = torch.empty(cout, device=DEV)
     ops.bias_grad_nchw(dyd, db, torch.empty(64 * cout, device=DEV))       # halo zeros add nothing
     close(host(db), dbo, msg="bias grad")
+    assert conv.fuses_bias() == padded
+    if padded:                                                            # bias gradient fused into the wgrad pass
+        db2 = torch.full((cout,), 7.0, device=DEV)
+        dw.zero_()
+        conv.wgrad(xd, dyd, dw, ws, db=db2)
+        close(host(dw), dwo, msg="conv wgrad (with fused bias grad)")
+        close(host(db2), dbo, msg="fused bias grad")
+    else:
+        with pytest.raises(Exception):
+            conv.wgrad(xd, dyd, dw, ws, db=db)
     if s == 1:
         wtt = torch.empty(wd.numel(), device=DEV)
         conv.wt_transpose(wd, wtt)

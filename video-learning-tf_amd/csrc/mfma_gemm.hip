@@ -425,11 +425,15 @@ struct DyRowsU {
     static_assert(BR == 64 && NLD * 4 == BX, "lanes are the reduction pixels");
     using Params = DyParams;
     __amdgpu_buffer_rsrc_t rsrc;
-    int lbase, M, OHW, OW, halo, OWp, row_bytes, first_bytes, nvalid, zero;
+    int lbase, M, OHW, OW, halo, OWp, row_bytes, first_bytes, nvalid, zero, co0;
     int64_t img_stride;
     FastDiv dOHW, dOW;
+    float bsum[NLD];   // per-lane partial of sum_pixels dy[co][pixel] (bias gradient), only used by the i-tile-0 workgroups
     __device__ __forceinline__ void init(const Params& P, int x0, int zg) {
         const int row0 = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) * NLD;
+        co0 = zg * P.Cog + x0 + row0;
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) bsum[j] = 0.f;
         zero = P.zero;
         const int64_t goff = (int64_t)zg * P.Cog * P.plane;
         rsrc = make_rsrc(P.dy + goff, (P.total - goff) * 4);
@@ -465,6 +469,18 @@ struct DyRowsU {
     __device__ __forceinline__ void store(float* tile, const float (&v)[NLD]) const {
 #pragma unroll
         for (int j = 0; j < NLD; ++j) tile[lbase + j * L::STR] = v[j];
+    }
+    // bias gradient (tf.nn.bias_add, alexnet.py:31): every dy element passes through v[] exactly once per i-tile
+    __device__ __forceinline__ void accumulate(const float (&v)[NLD]) {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) bsum[j] += v[j];
+    }
+    __device__ __forceinline__ void flush(float* db_slab) const {   // db_slab: [Cout_total] partial of this split
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const float t = wave_sum(bsum[j]);
+            if ((threadIdx.x & 63) == 0 && j < nvalid) db_slab[co0 + j] = t;
+        }
     }
 };
 
@@ -674,7 +690,7 @@ __global__ __launch_bounds__(NT) void mfma_contract(const typename LA::Params pa
 template <int BM, int BN, int BR, int WM, int WN, class LA, class LB, class EP>
 __global__ __launch_bounds__(NT) void mfma_contract_1buf(const typename LA::Params pa, const typename LB::Params pb,
                                                          const typename EP::Params pe, int tiles_i, int rtiles,
-                                                         int rt_per_split) {
+                                                         int rt_per_split, float* db_slabs, int db_stride) {
     static_assert(WM * WN == 4 && BR % 4 == 0, "shape");
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int STR = BR + 2;
@@ -702,12 +718,14 @@ __global__ __launch_bounds__(NT) void mfma_contract_1buf(const typename LA::Para
     const float* fb = lds1 + SA + (wj0 + (lane & 31)) * STR + 2 * (lane >> 5);
     const int rt0 = zs * rt_per_split;
     const int rt1 = min(rtiles, rt0 + rt_per_split);
+    const bool do_bias = db_slabs != nullptr && ti_blk == 0;   // uniform: one i-tile per (j-tile, group, split)
     float ra[LA::NLD], rb[LB::NLD];
     if (rt0 < rt1) {
         la.load(rt0, ra);
         lb.load(rt0, rb);
         la.store(lds1, ra);
         lb.store(lds1 + SA, rb);
+        if (do_bias) lb.accumulate(rb);
     }
     __syncthreads();
     for (int rt = rt0; rt < rt1; ++rt) {
@@ -738,9 +756,11 @@ __global__ __launch_bounds__(NT) void mfma_contract_1buf(const typename LA::Para
         if (more) {
             la.store(lds1, ra);
             lb.store(lds1 + SA, rb);
+            if (do_bias) lb.accumulate(rb);
         }
         __syncthreads();
     }
+    if (do_bias) lb.flush(db_slabs + (int64_t)zs * db_stride);
     EP::template apply<TM, TN>(pe, zg, zs, i0 + wi0, j0 + wj0, acc);
 }
 
@@ -1035,7 +1055,7 @@ static int launch_wgrad(const vl_conv_desc* d, const ConvGeom& g, const float* d
 
 // padded-mode wgrad: 64-pixel tiles, wave-uniform rows, no per-element VALU
 template <int BN, int WM, int WN>
-static int launch_wgrad_u(const vl_conv_desc* d, const ConvGeom& g, const float* dy, float* dw, float* ws, int splits,
+static int launch_wgrad_u(const vl_conv_desc* d, const ConvGeom& g, const float* dy, float* dw, float* db, float* ws, int splits,
                           hipStream_t s) {
     constexpr int BM = 128, BR = 64;
     using LA = WgradGatherU<BM, BR>;
@@ -1053,9 +1073,16 @@ static int launch_wgrad_u(const vl_conv_desc* d, const ConvGeom& g, const float*
         VL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
+    // bias-gradient partials live behind the weight slabs: [splits][Cout_total]
+    float* db_slabs = db ? (splits > 1 ? ws + (int64_t)splits * slab : db) : nullptr;
     dim3 grid(tiles_i * tiles_j, d->groups, splits);
-    hipLaunchKernelGGL(kern, grid, dim3(NT), lds, s, g, pb, pe, tiles_i, rtiles, ceil_div(rtiles, splits));
+    hipLaunchKernelGGL(kern, grid, dim3(NT), lds, s, g, pb, pe, tiles_i, rtiles, ceil_div(rtiles, splits), db_slabs, d->cout);
     VL_LAUNCH_CHECK();
+    if (db && splits > 1) {
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(ceil_div(d->cout, 256)), dim3(256), 0, s, db_slabs, db, (int64_t)d->cout, splits,
+                           (int64_t)d->cout, nullptr, 0, 0, 0, nullptr);
+        VL_LAUNCH_CHECK();
+    }
     return reduce_wgrad(d, dw, ws, splits, s);
 }
 
@@ -1072,12 +1099,15 @@ static int wgrad_splits(const vl_conv_desc* d, int n) {
 
 extern "C" size_t vl_conv_wgrad_ws_bytes(const vl_conv_desc* d, int n) {
     if (!d || n <= 0) return 0;
-    return (size_t)wgrad_splits(d, n) * d->K * d->cout * sizeof(float);
+    return (size_t)wgrad_splits(d, n) * ((size_t)d->K + 1) * d->cout * sizeof(float);   // weight slabs + bias partials
 }
 
-extern "C" int vl_conv_wgrad(const vl_conv_desc* d, const float* x, const float* dy, float* dw, void* ws, size_t ws_bytes,
-                             int n, vl_stream_t stream) {
+extern "C" int vl_conv_wgrad_fuses_bias(const vl_conv_desc* d) { return d && d->fwd_padded ? 1 : 0; }
+
+extern "C" int vl_conv_wgrad(const vl_conv_desc* d, const float* x, const float* dy, float* dw, float* db, void* ws,
+                             size_t ws_bytes, int n, vl_stream_t stream) {
     VL_CHECK(d && x && dy && dw, "vl_conv_wgrad: null argument");
+    VL_CHECK(!db || d->fwd_padded, "vl_conv_wgrad: the fused bias gradient needs the padded layout (see vl_conv_wgrad_fuses_bias)");
     VL_CHECK(n > 0 && (int64_t)n * d->oh * d->ow < (1ll << 31), "vl_conv_wgrad: bad batch %d", n);
     const int splits = wgrad_splits(d, n);
     VL_CHECK(splits == 1 || (ws && ws_bytes >= vl_conv_wgrad_ws_bytes(d, n)), "vl_conv_wgrad: workspace too small (%zu < %zu)",
@@ -1088,10 +1118,10 @@ extern "C" int vl_conv_wgrad(const vl_conv_desc* d, const float* x, const float*
     VL_CHECK(g.total * 4 < MAX_BUF_BYTES && dy_total * 4 < MAX_BUF_BYTES, "vl_conv_wgrad: operand exceeds the buffer-offset range");
     hipStream_t s = (hipStream_t)stream;
     if (d->cog % 128 == 0) {
-        if (d->fwd_padded) return launch_wgrad_u<128, 2, 2>(d, g, dy, dw, (float*)ws, splits, s);
+        if (d->fwd_padded) return launch_wgrad_u<128, 2, 2>(d, g, dy, dw, db, (float*)ws, splits, s);
         return launch_wgrad<128, 2, 2>(d, g, dy, dw, (float*)ws, splits, s);
     }
-    if (d->fwd_padded) return launch_wgrad_u<96, 4, 1>(d, g, dy, dw, (float*)ws, splits, s);
+    if (d->fwd_padded) return launch_wgrad_u<96, 4, 1>(d, g, dy, dw, db, (float*)ws, splits, s);
     return launch_wgrad<96, 4, 1>(d, g, dy, dw, (float*)ws, splits, s);
 }
 

@@ -496,8 +496,11 @@ class LRCNEngine:
             elif L["pool"]:
                 self._pool_bwd(L, n, dy, L["y"][:n], L["dy_halo"])
             # else: dy was written (ReluGrad fused) by the next layer's dgrad epilogue
-            self._run(name + ".wgrad", conv.wgrad, x_in, dy, G["dcnn/%sW" % name], self.ws)
-            ops.bias_grad_nchw(dy, G["dcnn/%sb" % name], sw)
+            if conv.fuses_bias():      # bias gradient comes out of the same pass over dy
+                self._run(name + ".wgrad", conv.wgrad, x_in, dy, G["dcnn/%sW" % name], self.ws, db=G["dcnn/%sb" % name])
+            else:
+                self._run(name + ".wgrad", conv.wgrad, x_in, dy, G["dcnn/%sW" % name], self.ws)
+                ops.bias_grad_nchw(dy, G["dcnn/%sb" % name], sw)
             if li > 0:
                 prev = self.layers[li - 1]
                 conv.wt_transpose(P["dcnn/%sW" % name], self.wt)

@@ -123,14 +123,18 @@ class Conv:
     def wgrad_ws_bytes(self, n):
         return int(_ffi.lib().vl_conv_wgrad_ws_bytes(self._d, n))
 
-    def wgrad(self, x, dy, dw, ws):
-        _f32(x, dy, dw); _dense(x, dy, dw, ws)
+    def fuses_bias(self):
+        return bool(_ffi.lib().vl_conv_wgrad_fuses_bias(self._d))
+
+    def wgrad(self, x, dy, dw, ws, db=None):
+        """dw (and, when fuses_bias(), db = sum of dy over n,h,w in the same pass)."""
+        _f32(x, dy, dw, db); _dense(x, dy, dw, ws, db)
         n = x.shape[0]
         if tuple(x.shape) != self._shape(n, self.cin, self.h, self.w, self.x_halo) or \
                 tuple(dy.shape) != self._shape(n, self.cout, self.oh, self.ow, self.dy_halo):
             raise _ffi.VltfError("conv.wgrad: shape mismatch x=%s dy=%s" % (tuple(x.shape), tuple(dy.shape)))
         nbytes = 0 if ws is None else ws.numel() * ws.element_size()
-        _ffi.call("vl_conv_wgrad", self._d, _p(x), _p(dy), _p(dw), _p(ws), nbytes, x.shape[0], stream())
+        _ffi.call("vl_conv_wgrad", self._d, _p(x), _p(dy), _p(dw), _p(db), _p(ws), nbytes, x.shape[0], stream())
 
 
 def bias_grad_nchw(dy, db, ws):
