@@ -21,9 +21,10 @@
 //   conv fwd / dgrad : A = HWIO weights [r=(kh,kw,ci)][i=co]               (DenseKX)
 //                      B = implicit im2col gather [r][j=pixel], NCHW input  (ConvGather)
 //                      epilogue writes NCHW (+bias, ReLU | ReluGrad mask)
-//   conv wgrad       : A = implicit im2col gather [i=(kh,kw,ci)][r=pixel]   (WgradGather)
-//                      B = dy [j=co][r=pixel]                               (DyRows)
-//                      epilogue writes per-split HWIO slabs, reduced deterministically
+//   conv wgrad       : A = implicit im2col gather [i=(kh,kw,ci)][r=pixel], B = dy [j=co][r=pixel];
+//                      epilogue writes per-split HWIO slabs, reduced deterministically.
+//                      padded layout: wgrad_dma_kernel (LDS-DMA operand rows, one workgroup per CU);
+//                      dense layout:  the template with WgradGather / DyRows (bounds-tested)
 //   dense GEMM       : A, B = DenseKX / DenseXK by transpose flag (fc6/7/8, LSTM, output fc)
 //
 // MFMA operand maps (cdna_hip_programming.md section 3): lane l holds A[i = l&31][r = l>>5] and
@@ -371,119 +372,6 @@ struct DyRows {
     }
 };
 
-// ---- wgrad, VALU-free form (padded layout only): the reduction tile is 64 pixels = the 64 lanes of a wave,
-// so one load instruction fetches ONE operand row for those pixels: the row's byte offset is a scalar
-// (soffset, from the table / from co * plane) and the per-lane pixel offset is decoded once per tile.
-template <int BX, int BR>
-struct WgradGatherU {
-    using L = LdsTile<BX, BR>;
-    static constexpr int NLD = BX * BR / NT;   // rows per wave (each wave owns NLD consecutive rows)
-    static_assert(BR == 64 && NLD * 4 == BX, "lanes are the reduction pixels");
-    using Params = ConvGeom;
-    __amdgpu_buffer_rsrc_t rsrc;
-    const int* tab;
-    int lbase, M, OHW, OW, stride, pt, pl, halo, Wp, zero;
-    FastDiv dOHW, dOW;
-    int64_t img_stride;
-    __device__ __forceinline__ void init(const Params& P, int x0, int zg) {
-        const int row0 = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) * NLD;
-        zero = P.zero;
-        tab = P.ktab + x0 + row0;
-        lbase = row0 * L::STR + (threadIdx.x & 63);
-        rsrc = make_rsrc(P.x + (int64_t)zg * P.grp_stride, (P.total - (int64_t)zg * P.grp_stride) * 4);
-        M = P.M; OHW = P.OHW; OW = P.OW; stride = P.stride; pt = P.pt; pl = P.pl; halo = P.halo; Wp = P.Wp;
-        dOHW = P.dOHW; dOW = P.dOW;
-        img_stride = P.img_stride;
-    }
-    __device__ __forceinline__ void prefetch(int) {}
-    __device__ __forceinline__ void load(int rt, float (&v)[NLD]) const {
-        const int m = rt * BR + (threadIdx.x & 63);
-        const bool vm = m < M;
-        const uint32_t mm = vm ? m : 0;
-        const uint32_t n = fd_div(mm, dOHW);
-        const uint32_t p = mm - n * OHW;
-        const uint32_t oh = fd_div(p, dOW);
-        const uint32_t ow = p - oh * OW;
-        const int ih0 = (int)oh * stride - pt + halo, iw0 = (int)ow * stride - pl + halo;
-        const uint32_t vo = (uint32_t)((int64_t)n * img_stride + (int64_t)ih0 * Wp + iw0) * 4u;
-        const uint32_t voff = vm ? vo : OOB_OFF;
-        // opaque per tile: keeps hipcc from hoisting NLD scalar offsets out of the tile loop (it spilled ~90 SGPRs)
-        const int* t = tab + rt * zero;   // zero is a kernel argument that is always 0 (uniform, but not foldable)
-#pragma unroll
-        for (int j = 0; j < NLD; ++j) v[j] = buf_load(rsrc, voff, t[j]);
-    }
-    __device__ __forceinline__ void store(float* tile, const float (&v)[NLD]) const {
-#pragma unroll
-        for (int j = 0; j < NLD; ++j) tile[lbase + j * L::STR] = v[j];
-    }
-};
-
-template <int BX, int BR>
-struct DyRowsU {
-    using L = LdsTile<BX, BR>;
-    static constexpr int NLD = BX * BR / NT;
-    static_assert(BR == 64 && NLD * 4 == BX, "lanes are the reduction pixels");
-    using Params = DyParams;
-    __amdgpu_buffer_rsrc_t rsrc;
-    int lbase, M, OHW, OW, halo, OWp, row_bytes, first_bytes, nvalid, zero, co0;
-    int64_t img_stride;
-    FastDiv dOHW, dOW;
-    float bsum[NLD];   // per-lane partial of sum_pixels dy[co][pixel] (bias gradient), only used by the i-tile-0 workgroups
-    __device__ __forceinline__ void init(const Params& P, int x0, int zg) {
-        const int row0 = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) * NLD;
-        co0 = zg * P.Cog + x0 + row0;
-#pragma unroll
-        for (int j = 0; j < NLD; ++j) bsum[j] = 0.f;
-        zero = P.zero;
-        const int64_t goff = (int64_t)zg * P.Cog * P.plane;
-        rsrc = make_rsrc(P.dy + goff, (P.total - goff) * 4);
-        lbase = row0 * L::STR + (threadIdx.x & 63);
-        M = P.M; OHW = P.OHW; OW = P.OW; halo = P.halo; OWp = P.OWp;
-        img_stride = (int64_t)P.Cout_total * P.plane;
-        dOHW = P.dOHW; dOW = P.dOW;
-        row_bytes = (int)(P.plane * 4);
-        first_bytes = (x0 + row0) * row_bytes;
-        nvalid = P.Cog - (x0 + row0);   // rows of this wave that are real channels (uniform)
-    }
-    __device__ __forceinline__ void prefetch(int) {}
-    __device__ __forceinline__ void load(int rt, float (&v)[NLD]) const {
-        const int m = rt * BR + (threadIdx.x & 63);
-        const bool vm = m < M;
-        const uint32_t mm = vm ? m : 0;
-        const uint32_t n = fd_div(mm, dOHW);
-        const uint32_t p = mm - n * OHW;
-        const uint32_t oh = fd_div(p, dOW);
-        const uint32_t ow = p - oh * OW;
-        const uint32_t vo = (uint32_t)((int64_t)n * img_stride + (int64_t)(oh + halo) * OWp + ow + halo) * 4u;
-        const uint32_t voff = vm ? vo : OOB_OFF;
-        const int rb = row_bytes + rt * zero;   // opaque per tile (see WgradGatherU::load)
-        int so = first_bytes;
-        if (nvalid >= NLD) {
-#pragma unroll
-            for (int j = 0; j < NLD; ++j, so += rb) v[j] = buf_load(rsrc, voff, so);
-        } else {   // channel tail of the group (uniform per wave)
-#pragma unroll
-            for (int j = 0; j < NLD; ++j, so += rb) v[j] = j < nvalid ? buf_load(rsrc, voff, so) : 0.f;
-        }
-    }
-    __device__ __forceinline__ void store(float* tile, const float (&v)[NLD]) const {
-#pragma unroll
-        for (int j = 0; j < NLD; ++j) tile[lbase + j * L::STR] = v[j];
-    }
-    // bias gradient (tf.nn.bias_add, alexnet.py:31): every dy element passes through v[] exactly once per i-tile
-    __device__ __forceinline__ void accumulate(const float (&v)[NLD]) {
-#pragma unroll
-        for (int j = 0; j < NLD; ++j) bsum[j] += v[j];
-    }
-    __device__ __forceinline__ void flush(float* db_slab) const {   // db_slab: [Cout_total] partial of this split
-#pragma unroll
-        for (int j = 0; j < NLD; ++j) {
-            const float t = wave_sum(bsum[j]);
-            if ((threadIdx.x & 63) == 0 && j < nvalid) db_slab[co0 + j] = t;
-        }
-    }
-};
-
 // ---- epilogues --------------------------------------------------------------------------------
 // Row-major C[i][j] (ldc).  With zs_stride != 0 the raw partial goes to slab zs (split reduction).
 struct EpiRowMajor {
@@ -684,29 +572,134 @@ __global__ __launch_bounds__(NT) void mfma_contract(const typename LA::Params pa
     EP::template apply<TM, TN>(pe, zg, zs, i0 + wi0, j0 + wj0, acc);
 }
 
-// Same contraction with ONE LDS buffer (large reduction tiles: wgrad's 64-pixel tiles need 68 KB): the next
-// tile is prefetched into registers during the MFMAs and written after a barrier; two workgroups per CU
-// cover each other's barrier/store phases.
-template <int BM, int BN, int BR, int WM, int WN, class LA, class LB, class EP>
-__global__ __launch_bounds__(NT) void mfma_contract_1buf(const typename LA::Params pa, const typename LB::Params pb,
-                                                         const typename EP::Params pe, int tiles_i, int rtiles,
-                                                         int rt_per_split, float* db_slabs, int db_stride) {
-    static_assert(WM * WN == 4 && BR % 4 == 0, "shape");
+// ---- wgrad, LDS-DMA form (padded layout) -------------------------------------------------------
+// dW[i = im2col row][j = co] = sum over pixels.  128 x BN x 64-pixel tiles, ONE workgroup per CU, two LDS
+// buffers (2 x (128 + BN) x 66 floats = 135 KB of the CU's 160 KB).  Operand rows go global -> LDS with
+// `buffer_load_dword ... lds` (LDS-DMA): a wave instruction fetches ONE operand row for the tile's 64 pixels
+// (lane = pixel, per-lane byte offset decoded once per tile; the row's offset is a scalar) and the hardware
+// writes the 64 dwords to consecutive LDS addresses = one [x][66] row.  No staging registers, no ds_write,
+// no VALU per element.  The 64 row fetches of tile rt+1 are issued one per MFMA during the FIRST half of
+// tile rt's 128 MFMAs (a burst of 64 loads ahead of the MFMAs held the wave at the issue port for ~2000
+// cycles: the earlier 2-workgroup form ran its matrix pipe 67 % busy), the second half covers their latency,
+// then `s_waitcnt vmcnt(0)` + one barrier per tile.
+// Bias gradient: db[co] = sum_pixels 1 * dy[co][pixel] is one more row of the same product.  When K is not a
+// multiple of 128 the last i-tile has spare rows: row K of the A tile is overwritten with 1.0f in LDS after the
+// DMA lands, and the epilogue writes accumulator row K to the db slab (exact: fma(1, dy, acc)).
+template <int BN>
+struct WgradDmaCfg {
+    static constexpr int BM = 128, BR = 64, STR = BR + 2;
+    static constexpr int BUF = (BM + BN) * STR;           // floats per LDS buffer
+    static constexpr size_t LDS_BYTES = 2 * BUF * sizeof(float);
+};
+
+// LDS-DMA row fetch, in inline asm on purpose: behind the `__builtin_amdgcn_raw_ptr_buffer_load_lds` form hipcc (ROCm 7.2)
+// puts `s_waitcnt vmcnt(0)` in front of every later ds_read (it cannot tell the DMA's LDS buffer from the one being read)
+// and turns every later table read into a vector load + readfirstlane loop (the builtin counts as a store to any memory).
+// The asm form is invisible to both: the kernel orders DMA -> ds_read itself (vmcnt(0) + barrier at the end of a tile).
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) int* const_int_ptr;   // constant address space: uniform reads become s_load
+__device__ __forceinline__ i32x4 rsrc_words(const float* base, int64_t bytes) {
+    const uint64_t a = (uint64_t)base;
+    return i32x4{(int)(uint32_t)a, (int)((uint32_t)(a >> 32) & 0xffffu), (int)(uint32_t)bytes, 0x00020000};
+}
+__device__ __forceinline__ void lds_dma_row(i32x4 rs, uint32_t lds_byte_addr, uint32_t voff, int soff) {
+    // M0 = LDS destination of lane 0; lane l lands at M0 + 4 l.  s_nop: SALU write of M0 -> LDS-DMA needs one wait state.
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds" ::"s"(lds_byte_addr), "v"(voff), "s"(rs), "s"(soff)
+                 : "m0");
+}
+
+template <int BN, int WM, int WN>
+__global__ __launch_bounds__(NT, 1) void wgrad_dma_kernel(const ConvGeom g, const DyParams d, const EpiRowMajor::Params pe,
+                                                          int tiles_i, int tiles_j, int groups, int units, int rtiles,
+                                                          int rt_per_split, float* db_slabs, int db_stride) {
+    using C = WgradDmaCfg<BN>;
+    constexpr int BM = C::BM, STR = C::STR, SA = BM * STR, BUF = C::BUF;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int STR = BR + 2;
-    constexpr int SA = BM * STR;
-    extern __shared__ __attribute__((aligned(16))) float lds1[];
-    const int bid = xcd_swizzle(blockIdx.x, gridDim.x);
-    const int ti_blk = bid % tiles_i, tj_blk = bid / tiles_i;
-    const int zg = blockIdx.y, zs = blockIdx.z;
+    constexpr int RA = BM / 4, RB = BN / 4;               // rows each wave fetches per tile (A: 32, B: 32 | 24)
+    static_assert(WM * WN == 4 && TM * WM * 32 == BM && TN * WN * 32 == BN, "tile shape");
+    static_assert(RA + RB <= 10 * 2 * TM * TN, "row fetches must leave the last third of a tile's MFMAs to cover their latency");
+    extern __shared__ __attribute__((aligned(16))) float ldsw[];
+
+    // Workgroup -> (unit = (group, split), tile) so that ALL tiles of a unit run on ONE XCD, back to back: workgroup ids are
+    // dealt round-robin over the 8 XCDs (id % 8 labels the XCD), so XCD x takes units x, x + 8, ... and walks each unit's
+    // tiles (i fastest) in dispatch order.  The tiles of a unit read the same pixels of x and dy at the same pace, so one
+    // workgroup's fetch is the others' L2 hit.  Placement only affects speed.
+    const int tiles = tiles_i * tiles_j;
+    const int k8 = blockIdx.x >> 3;
+    const int unit = (k8 / tiles) * 8 + (blockIdx.x & 7);
+    if (unit >= units) return;                            // grid padded to 8 * ceil(units / 8) * tiles
+    const int tile_id = k8 % tiles;
+    const int ti_blk = tile_id % tiles_i, tj_blk = tile_id / tiles_i;
+    const int zg = unit % groups, zs = unit / groups;
     const int i0 = ti_blk * BM, j0 = tj_blk * BN;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wi0 = (wave / WN) * (BM / WM), wj0 = (wave % WN) * (BN / WN);
-    LA la;
-    LB lb;
-    la.init(pa, i0, zg);
-    lb.init(pb, j0, zg);
+
+    // operand A: im2col rows of x (table of byte offsets); operand B: dy rows (co * plane)
+    const i32x4 rs_x = rsrc_words(g.x + (int64_t)zg * g.grp_stride, (g.total - (int64_t)zg * g.grp_stride) * 4);
+    const int64_t goff = (int64_t)zg * d.Cog * d.plane;
+    const i32x4 rs_dy = rsrc_words(d.dy + goff, (d.total - goff) * 4);
+    const int* tab = g.ktab + i0 + wave * RA;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)ldsw;   // LDS byte address of the array
+    const int row_bytes = (int)(d.plane * 4);
+    const int b_row0 = j0 + wave * RB;                    // first dy channel (within the group) this wave fetches
+    const int b_last = d.Cog - 1;                         // rows past the group's channels re-read the last one (outputs dropped)
+    const int64_t dy_img = (int64_t)d.Cout_total * d.plane;
+
+    uint32_t voff_x, voff_dy;
+    auto decode = [&](int rt) {                           // per-lane byte offsets of the tile's 64 pixels
+        const int m = rt * 64 + lane;
+        const bool vm = m < g.M;
+        const uint32_t mm = vm ? m : 0;
+        const uint32_t n = fd_div(mm, g.dOHW);
+        const uint32_t p = mm - n * g.OHW;
+        const uint32_t oh = fd_div(p, g.dOW);
+        const uint32_t ow = p - oh * g.OW;
+        const int ih0 = (int)oh * g.stride - g.pt + g.halo, iw0 = (int)ow * g.stride - g.pl + g.halo;
+        const uint32_t vx = (uint32_t)((int64_t)n * g.img_stride + (int64_t)ih0 * g.Wp + iw0) * 4u;
+        const uint32_t vd = (uint32_t)((int64_t)n * dy_img + (int64_t)(oh + d.halo) * d.OWp + ow + d.halo) * 4u;
+        voff_x = vm ? vx : OOB_OFF;                       // pixels past M: range check fails, the DMA writes 0
+        voff_dy = vm ? vd : OOB_OFF;
+        asm volatile("" : "+v"(voff_x), "+v"(voff_dy));   // computed HERE (hipcc otherwise sinks the arithmetic to the first use)
+    };
+    // one t-step's share of the next tile's row fetches, into LDS buffer `nb` (a literal).  Every scalar that depends only
+    // on the row (LDS destination, table entry, dy row offset) is derived from a base made opaque per tile (`+ rt * zero`,
+    // zero is a kernel argument that is always 0): left loop-invariant, hipcc hoists all ~200 of them out of the tile loop
+    // and spills SGPRs to VGPR lanes.
+    // The wave's RA table entries (byte offsets of its im2col rows) sit in SGPRs.  They never change, but they are re-read
+    // in the quiet tail of every tile and made opaque: left to itself hipcc re-materialises the s_loads right in front of the
+    // first fetch of each tile and waits for them there.
+    int tabv[RA];
+    auto load_table = [&](int rt) {                        // issue the wide s_loads ...
+        const const_int_ptr tt = (const_int_ptr)(uintptr_t)(tab + rt * g.zero);
+#pragma unroll
+        for (int f = 0; f < RA; ++f) tabv[f] = tt[f];
+    };
+    auto pin_table = [&]() {                               // ... and, a few MFMAs later, wait for them and fix them in SGPRs
+#pragma unroll
+        for (int f = 0; f < RA; ++f) asm volatile("" : "+s"(tabv[f]));
+    };
+    // fetch number f (0 .. RA + RB - 1) of the next tile: A rows first, then B rows
+    auto dma = [&](const int nb, const int f, int rt_next) {
+        const int z = rt_next * g.zero;
+        if (f < RA) {
+            const uint32_t la = lds0 + (uint32_t)(wave * (RA * STR) + z) * 4u;
+            lds_dma_row(rs_x, la + (uint32_t)(nb * BUF + f * STR) * 4u, voff_x, tabv[f]);
+        } else {
+            const int r = f - RA;
+            const uint32_t lb = lds0 + (uint32_t)(SA + wave * (RB * STR) + z) * 4u;
+            lds_dma_row(rs_dy, lb + (uint32_t)(nb * BUF + r * STR) * 4u, voff_dy, min(b_row0 + z + r, b_last) * row_bytes);
+        }
+    };
+    // bias row: local row K - i0 of the LAST i-tile (uniform)
+    const int ones_row = (db_slabs != nullptr && g.K >= i0 && g.K < i0 + BM) ? g.K - i0 : -1;
+    auto finish_tile = [&](const int nb) {                // DMAs of buffer nb landed -> visible to every wave
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (ones_row >= 0 && (ones_row / RA) == wave) ldsw[nb * BUF + ones_row * STR + lane] = 1.0f;
+        __syncthreads();
+    };
+
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int a = 0; a < TM; ++a)
@@ -714,54 +707,98 @@ __global__ __launch_bounds__(NT) void mfma_contract_1buf(const typename LA::Para
         for (int b = 0; b < TN; ++b)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
-    const float* fa = lds1 + (wi0 + (lane & 31)) * STR + 2 * (lane >> 5);
-    const float* fb = lds1 + SA + (wj0 + (lane & 31)) * STR + 2 * (lane >> 5);
+
     const int rt0 = zs * rt_per_split;
     const int rt1 = min(rtiles, rt0 + rt_per_split);
-    const bool do_bias = db_slabs != nullptr && ti_blk == 0;   // uniform: one i-tile per (j-tile, group, split)
-    float ra[LA::NLD], rb[LB::NLD];
-    if (rt0 < rt1) {
-        la.load(rt0, ra);
-        lb.load(rt0, rb);
-        la.store(lds1, ra);
-        lb.store(lds1 + SA, rb);
-        if (do_bias) lb.accumulate(rb);
+    const int ntiles = rt1 - rt0;
+    if (ntiles > 0) {
+        decode(rt0);
+        load_table(rt0);
+        pin_table();
+#pragma unroll
+        for (int f = 0; f < RA + RB; ++f) dma(0, f, rt0);
+        decode(rt0 + 1);
+        finish_tile(0);
     }
-    __syncthreads();
-    for (int rt = rt0; rt < rt1; ++rt) {
-        const bool more = rt + 1 < rt1;
-        if (more) {
-            la.load(rt + 1, ra);
-            lb.load(rt + 1, rb);
+    const float* fa = ldsw + (wi0 + (lane & 31)) * STR + 2 * (lane >> 5);
+    const float* fb = ldsw + SA + (wj0 + (lane & 31)) * STR + 2 * (lane >> 5);
+
+    // one tile: MFMAs on buffer `cur` while tile rt_next streams into the other buffer.  The fetch for a tile past
+    // this split's range is harmless (valid or range-checked addresses, never read) and keeps the body branch-free.
+    auto tile = [&](const int cur, int rt_next) {
+        float2 af[2][TM], bf[2][TN];
+#pragma unroll
+        for (int a = 0; a < TM; ++a) af[0][a] = *reinterpret_cast<const float2*>(fa + cur * BUF + a * 32 * STR);
+#pragma unroll
+        for (int b = 0; b < TN; ++b) bf[0][b] = *reinterpret_cast<const float2*>(fb + cur * BUF + b * 32 * STR);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int c = t & 1, nx = c ^ 1;
+            if (t + 1 < 16) {                             // fragments of the next step: their latency hides behind this step's MFMAs
+#pragma unroll
+                for (int a = 0; a < TM; ++a) af[nx][a] = *reinterpret_cast<const float2*>(fa + cur * BUF + a * 32 * STR + 4 * (t + 1));
+#pragma unroll
+                for (int b = 0; b < TN; ++b) bf[nx][b] = *reinterpret_cast<const float2*>(fb + cur * BUF + b * 32 * STR + 4 * (t + 1));
+            }
+            // one row fetch in the shadow of each MFMA (64 cycles of matrix pipe): its ~7 scalar instructions and the DMA
+            // issue while the pipe works.  sched_barrier pins the pairing; left alone hipcc bunches 8 fetches (~250 cycles
+            // of issue) between two MFMAs and the pipe idles.
+#pragma unroll
+            for (int m = 0; m < 2 * TM * TN; ++m) {
+                const int a = (m % (TM * TN)) / TN, b = m % TN;
+                if (m < TM * TN) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][a].x, bf[c][b].x, acc[a][b], 0, 0, 0);
+                else acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][a].y, bf[c][b].y, acc[a][b], 0, 0, 0);
+                const int f = t * (2 * TM * TN) + m;
+                if (f < RA + RB) {
+                    dma(cur ^ 1, f, rt_next);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            // pixel offsets of the tile after next, computed in the quiet tail of this tile (the fetches above have read
+            // their address registers at issue), so that a tile starts with MFMAs + fetches, not with ~25 VALU instructions
+            if (t == 10) {
+                load_table(rt_next + 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (t == 13) {
+                int rtn = rt_next + 1;
+                asm volatile("" : "+s"(rtn));             // the decode's input becomes known HERE, not at the top of the tile
+                decode(rtn);
+                pin_table();
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 0; t < BR / 4; ++t) {
-            float2 af[TM], bf[TN];
-#pragma unroll
-            for (int a = 0; a < TM; ++a) af[a] = *reinterpret_cast<const float2*>(fa + a * 32 * STR + 4 * t);
-#pragma unroll
-            for (int b = 0; b < TN; ++b) bf[b] = *reinterpret_cast<const float2*>(fb + b * 32 * STR + 4 * t);
-#pragma unroll
-            for (int a = 0; a < TM; ++a)
-#pragma unroll
-                for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].x, bf[b].x, acc[a][b], 0, 0, 0);
-#pragma unroll
-            for (int a = 0; a < TM; ++a)
-#pragma unroll
-                for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].y, bf[b].y, acc[a][b], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
-        if (more) {
-            la.store(lds1, ra);
-            lb.store(lds1 + SA, rb);
-            if (do_bias) lb.accumulate(rb);
-        }
-        __syncthreads();
+        finish_tile(cur ^ 1);
+    };
+    int rt = rt0;
+    for (int i = 0; i + 1 < ntiles; i += 2, rt += 2) {
+        tile(0, rt + 1);
+        tile(1, rt + 2);
     }
-    if (do_bias) lb.flush(db_slabs + (int64_t)zs * db_stride);
-    EP::template apply<TM, TN>(pe, zg, zs, i0 + wi0, j0 + wj0, acc);
+    if (ntiles > 0 && (ntiles & 1)) tile(0, rt + 1);
+
+    EpiRowMajor::template apply<TM, TN>(pe, zg, zs, i0 + wi0, j0 + wj0, acc);
+    if (ones_row >= 0) {                                  // accumulator row K -> this split's db partial
+        float* dbs = db_slabs + (int64_t)zs * db_stride + zg * d.Cog;
+        const int lr = ones_row - wi0;                    // row within this wave's block of BM / WM rows
+        if (lr >= 0 && lr < BM / WM) {
+            const int a = lr >> 5, rr = lr & 31;          // D register q of lane l holds row (q&3) + 8*(q>>2) + 4*(l>>5)
+            const int q = (rr & 3) + 4 * (rr >> 3);
+            if (((rr >> 2) & 1) == (lane >> 5)) {
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    const int j = j0 + wj0 + 32 * b + (lane & 31);
+                    float v = 0.f;
+#pragma unroll
+                    for (int aa = 0; aa < TM; ++aa)
+#pragma unroll
+                        for (int qq = 0; qq < 16; ++qq)
+                            if (aa == a && qq == q) v = acc[aa][b][qq];
+                    if (j < d.Cog) dbs[j] = v;
+                }
+            }
+        }
+    }
 }
 
 // out[e] = sum_s slab[s][e] (+bias[e % n_cols]) (relu) (mask) : deterministic split reduction.
@@ -1053,30 +1090,28 @@ static int launch_wgrad(const vl_conv_desc* d, const ConvGeom& g, const float* d
     return reduce_wgrad(d, dw, ws, splits, s);
 }
 
-// padded-mode wgrad: 64-pixel tiles, wave-uniform rows, no per-element VALU
+// padded-mode wgrad, LDS-DMA form: one workgroup per CU (135 KB of LDS)
 template <int BN, int WM, int WN>
-static int launch_wgrad_u(const vl_conv_desc* d, const ConvGeom& g, const float* dy, float* dw, float* db, float* ws, int splits,
-                          hipStream_t s) {
-    constexpr int BM = 128, BR = 64;
-    using LA = WgradGatherU<BM, BR>;
-    using LB = DyRowsU<BN, BR>;
+static int launch_wgrad_dma(const vl_conv_desc* d, const ConvGeom& g, const float* dy, float* dw, float* db, float* ws, int splits,
+                            hipStream_t s) {
+    using C = WgradDmaCfg<BN>;
     DyParams pb;
     dy_params(d, g, dy, pb);
     const int64_t slab = (int64_t)d->K * d->cout;
     EpiRowMajor::Params pe{splits > 1 ? ws : dw, d->cout, d->K, d->cog, nullptr, nullptr, 0, d->cog, splits > 1 ? slab : 0};
-    const int tiles_i = ceil_div(d->K, BM), tiles_j = ceil_div(d->cog, BN);
-    const int rtiles = ceil_div(g.M, BR);
-    constexpr size_t lds = (size_t)(BM + BN) * (BR + 2) * sizeof(float);
+    const int tiles_i = ceil_div(d->K, C::BM), tiles_j = ceil_div(d->cog, BN);
+    const int rtiles = ceil_div(g.M, C::BR);
     static bool attr_set = false;
-    auto kern = mfma_contract_1buf<BM, BN, BR, WM, WN, LA, LB, EpiRowMajor>;
+    auto kern = wgrad_dma_kernel<BN, WM, WN>;
     if (!attr_set) {
-        VL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        VL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
         attr_set = true;
     }
-    // bias-gradient partials live behind the weight slabs: [splits][Cout_total]
-    float* db_slabs = db ? (splits > 1 ? ws + (int64_t)splits * slab : db) : nullptr;
-    dim3 grid(tiles_i * tiles_j, d->groups, splits);
-    hipLaunchKernelGGL(kern, grid, dim3(NT), lds, s, g, pb, pe, tiles_i, rtiles, ceil_div(rtiles, splits), db_slabs, d->cout);
+    float* db_slabs = db ? (splits > 1 ? ws + (int64_t)splits * slab : db) : nullptr;   // [splits][Cout_total] behind the weight slabs
+    const int units = d->groups * splits;
+    dim3 grid((unsigned)(ceil_div(units, 8) * 8 * tiles_i * tiles_j), 1, 1);
+    hipLaunchKernelGGL(kern, grid, dim3(NT), C::LDS_BYTES, s, g, pb, pe, tiles_i, tiles_j, d->groups, units, rtiles,
+                       ceil_div(rtiles, splits), db_slabs, d->cout);
     VL_LAUNCH_CHECK();
     if (db && splits > 1) {
         hipLaunchKernelGGL(reduce_slabs_kernel, dim3(ceil_div(d->cout, 256)), dim3(256), 0, s, db_slabs, db, (int64_t)d->cout, splits,
@@ -1086,15 +1121,44 @@ static int launch_wgrad_u(const vl_conv_desc* d, const ConvGeom& g, const float*
     return reduce_wgrad(d, dw, ws, splits, s);
 }
 
+static int device_cus() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
 static int wgrad_splits(const vl_conv_desc* d, int n) {
-    // the reduction runs over 32-pixel (checked) or 64-pixel (padded) tiles; aim at ~2048 workgroups
     const int64_t M = (int64_t)n * d->oh * d->ow;
-    const int rtiles = ceil_div(M, d->fwd_padded ? 64 : 32);
     const int tiles = ceil_div(d->K, 128) * ceil_div(d->cog, d->cog % 128 == 0 ? 128 : 96) * d->groups;
-    int splits = ceil_div(2048, tiles);
-    if (splits > rtiles) splits = rtiles;
-    if (splits < 1) splits = 1;
-    return splits;
+    if (!d->fwd_padded) {   // checked mode: 32-pixel tiles, several workgroups per CU; aim at ~2048 workgroups
+        const int rtiles = ceil_div(M, 32);
+        int splits = ceil_div(2048, tiles);
+        return splits > rtiles ? rtiles : (splits < 1 ? 1 : splits);
+    }
+    // LDS-DMA form: one workgroup per CU, all of equal length, units = groups * splits dealt over the 8 XCDs.  Minimise
+    // (rounds of the chip) x (tiles per workgroup + ~2 tiles of prologue / epilogue) over split counts that give every XCD
+    // the same number of units; slabs are capped at 512 MB.
+    const int rtiles = ceil_div(M, 64);
+    const int per_xcd = device_cus() / 8 > 0 ? device_cus() / 8 : 1;
+    const int64_t slab_bytes = ((int64_t)d->K + 1) * d->cout * 4;
+    int best = 1;
+    int64_t best_cost = -1;
+    for (int s = 1; s <= rtiles && s <= 4096; ++s) {
+        if (s > 1 && slab_bytes * s > (512ll << 20)) break;
+        const bool balanced = ((int64_t)d->groups * s) % 8 == 0;
+        const int64_t wgs_xcd = (int64_t)ceil_div((int64_t)d->groups * s, 8) * (tiles / d->groups);
+        const int64_t cost = (int64_t)ceil_div(wgs_xcd, per_xcd) * (ceil_div(rtiles, s) + 2) + (balanced ? 0 : 1);
+        if (best_cost < 0 || cost < best_cost) {
+            best_cost = cost;
+            best = s;
+        }
+    }
+    return best;
 }
 
 extern "C" size_t vl_conv_wgrad_ws_bytes(const vl_conv_desc* d, int n) {
@@ -1102,12 +1166,13 @@ extern "C" size_t vl_conv_wgrad_ws_bytes(const vl_conv_desc* d, int n) {
     return (size_t)wgrad_splits(d, n) * ((size_t)d->K + 1) * d->cout * sizeof(float);   // weight slabs + bias partials
 }
 
-extern "C" int vl_conv_wgrad_fuses_bias(const vl_conv_desc* d) { return d && d->fwd_padded ? 1 : 0; }
+// the bias row rides in a spare row of the last 128-row tile of K (wgrad_dma_kernel); K % 128 == 0 leaves none
+extern "C" int vl_conv_wgrad_fuses_bias(const vl_conv_desc* d) { return d && d->fwd_padded && d->K % 128 != 0 ? 1 : 0; }
 
 extern "C" int vl_conv_wgrad(const vl_conv_desc* d, const float* x, const float* dy, float* dw, float* db, void* ws,
                              size_t ws_bytes, int n, vl_stream_t stream) {
     VL_CHECK(d && x && dy && dw, "vl_conv_wgrad: null argument");
-    VL_CHECK(!db || d->fwd_padded, "vl_conv_wgrad: the fused bias gradient needs the padded layout (see vl_conv_wgrad_fuses_bias)");
+    VL_CHECK(!db || vl_conv_wgrad_fuses_bias(d), "vl_conv_wgrad: no fused bias gradient for this layer (see vl_conv_wgrad_fuses_bias)");
     VL_CHECK(n > 0 && (int64_t)n * d->oh * d->ow < (1ll << 31), "vl_conv_wgrad: bad batch %d", n);
     const int splits = wgrad_splits(d, n);
     VL_CHECK(splits == 1 || (ws && ws_bytes >= vl_conv_wgrad_ws_bytes(d, n)), "vl_conv_wgrad: workspace too small (%zu < %zu)",
@@ -1118,10 +1183,10 @@ extern "C" int vl_conv_wgrad(const vl_conv_desc* d, const float* x, const float*
     VL_CHECK(g.total * 4 < MAX_BUF_BYTES && dy_total * 4 < MAX_BUF_BYTES, "vl_conv_wgrad: operand exceeds the buffer-offset range");
     hipStream_t s = (hipStream_t)stream;
     if (d->cog % 128 == 0) {
-        if (d->fwd_padded) return launch_wgrad_u<128, 2, 2>(d, g, dy, dw, db, (float*)ws, splits, s);
+        if (d->fwd_padded) return launch_wgrad_dma<128, 2, 2>(d, g, dy, dw, db, (float*)ws, splits, s);
         return launch_wgrad<128, 2, 2>(d, g, dy, dw, (float*)ws, splits, s);
     }
-    if (d->fwd_padded) return launch_wgrad_u<96, 4, 1>(d, g, dy, dw, db, (float*)ws, splits, s);
+    if (d->fwd_padded) return launch_wgrad_dma<96, 4, 1>(d, g, dy, dw, db, (float*)ws, splits, s);
     return launch_wgrad<96, 4, 1>(d, g, dy, dw, (float*)ws, splits, s);
 }
 
