@@ -31,7 +31,7 @@ PEAK_FP32_MFMA_TFLOPS = 157.3              # MI355X_MICROARCH.md: v_mfma_f32_32x
 # launches that share the single-kernel symbol mfma_contract<128,128,16,2,2,DenseKX,ConvGather,EpiConvNCHW>
 # (output-channel tile 128: conv2/3/5 forward and conv3 dgrad, whose output channel count is 256)
 DOMINANT = ("conv2.fwd", "conv3.fwd", "conv5.fwd", "conv3.dgrad")
-DOMINANT_SYMBOL = "mfma_contract<128, 128, 16, 2, 2, DenseKX<128, 16>, ConvGather<128, 16, true>, EpiConvNCHW>"
+DOMINANT_SYMBOL = "mfma_contract<128, 128, 16, 2, 2, ConvWeightKX<128, 16>, ConvGather<128, 16, true>, EpiConvNCHW, 1>"
 MEAN_BGR = np.array([99.197148, 105.293620, 109.503945], np.float32)
 
 

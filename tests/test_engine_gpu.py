@@ -110,13 +110,15 @@ def test_full_geometry_logits_and_step():
     np.testing.assert_allclose(eng.logits_host(), logits, rtol=1e-3, atol=1e-3)
     assert abs(out["loss"] - loss) < 1e-4 * max(1, abs(loss)) and abs(out["grad_norm"] - gn) < 1e-3 * gn
     g = eng.get_grads()
-    # deep chain in fp32 vs fp64: a near-tie can flip a pool arg-max / ReLU gate, which moves single
-    # gradient elements discretely, so bound the relative L2 error per tensor instead of every element
+    # deep chain in fp32 vs fp64: a near-tie can flip a pool arg-max / ReLU gate, which moves gradient elements
+    # discretely, so bound the relative L2 error per tensor instead of every element.  Measured on this very case
+    # (tools/grad_flip_noise.py, fp64 oracle with the weights perturbed by 6e-8 relative): no flip -> 3e-6 everywhere;
+    # ONE flip -> 8e-3 on conv1W, 6e-3 on conv1b, 4-5e-3 on conv2W/b, 3e-3 on conv3b, nothing above the flipped gate.
+    # The oracle's own fp32 run lands at 5.2e-3 / 1.2e-3 / 6e-4.  Which gates flip depends on the (valid) summation
+    # order of the kernels, so conv-stack tensors get room for ~3 flips; tensors above pool5 cannot be hit and stay tight.
     for k in p:
         err = np.linalg.norm((g[k] - grads[k]).ravel()) / (np.linalg.norm(grads[k].ravel()) + 1e-30)
-        # measured: the oracle itself run in fp32 deviates from its fp64 run by 5.2e-3 on conv1W, 1.2e-3 on
-        # conv1b, ~6e-4 on conv2..4 and <3e-5 above pool5 on this very case; allow 3x that
-        bound = 1.6e-2 if k == "dcnn/conv1W" else 4e-3
+        bound = 2.5e-2 if k == "dcnn/conv1W" else (1.8e-2 if k.startswith("dcnn/conv") else 1e-3)
         assert err < bound, "grad %s: relative L2 error %.3e" % (k, err)
 
 

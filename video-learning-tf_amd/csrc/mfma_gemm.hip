@@ -36,6 +36,11 @@
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+// Read-only tables are read through the constant address space: a uniform read from it is always a scalar load (s_load).
+// Through a plain pointer hipcc falls back to a per-lane load + readfirstlane loop whenever it cannot prove that no store
+// in the kernel clobbers the table.
+typedef const __attribute__((address_space(4))) int* const_int_ptr;
+__device__ __forceinline__ const_int_ptr as_const(const int* p) { return (const_int_ptr)(uintptr_t)p; }
 static constexpr int NT = 256;  // threads per workgroup
 
 // Byte offset that fails the buffer range check of every resource we build (num_records < 0xE0000000);
@@ -96,6 +101,57 @@ struct DenseKX {
         const __amdgpu_buffer_rsrc_t rs = make_rsrc(base + done, (total - done) * 4);
 #pragma unroll
         for (int j = 0; j < NLD; ++j) v[j] = buf_load(rs, voff[j], 0);
+    }
+    __device__ __forceinline__ void store(float* tile, const float (&v)[NLD]) const {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) tile[loff[j]] = v[j];
+    }
+};
+
+// Conv weights as the A operand: stored [r][x] like DenseKX, but reduction tile rt covers the BR consecutive rows that
+// start at row_tab[rt] (one scalar table read per tile, prefetched a tile ahead): the reduction runs over a PERMUTED row
+// order (channel block outermost, taps inside it -- see build_ktabs) while the weights keep their HWIO layout.
+template <int BX, int BR>
+struct ConvWeightKX {
+    using L = LdsTile<BX, BR>;
+    static constexpr int NLD = BX * BR / NT;
+    static_assert(BX * BR % NT == 0, "tile must divide over 256 threads");
+    struct Params {
+        const float* p;
+        int64_t ld;
+        int X, R;
+        int64_t zg_stride;
+        const int* row_tab;   // [ceil(R / BR) + 1] first row of each reduction tile
+    };
+    const float* base;
+    const int* row_tab;
+    int64_t ld;
+    int R, row0;
+    uint32_t voff[NLD];
+    int loff[NLD];
+    __device__ __forceinline__ void init(const Params& P, int x0, int zg) {
+        base = P.p + (int64_t)zg * P.zg_stride;
+        ld = P.ld;
+        R = P.R;
+        row_tab = P.row_tab;
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int e = threadIdx.x + NT * j;
+            const int xl = e % BX, rl = e / BX;
+            voff[j] = (x0 + xl < P.X) ? (uint32_t)(((int64_t)rl * P.ld + x0 + xl) * 4) : OOB_OFF;
+            loff[j] = xl * L::STR + rl;
+        }
+    }
+    __device__ __forceinline__ void prefetch(int rt) { row0 = as_const(row_tab)[rt]; }
+    __device__ __forceinline__ void load(int rt, float (&v)[NLD]) {
+        // rows of this tile that exist (a natural-order reduction may end in a partial tile): the others fail the range check
+        // (rt is always a real tile here, so valid >= 1; a min AND a max would become a VALU v_med3 and drag the whole
+        // resource descriptor into VGPRs -> a readfirstlane loop around every load)
+        const int valid = min(BR, R - rt * BR);
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(base + (int64_t)row0 * ld, (int64_t)valid * ld * 4);
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) v[j] = buf_load(rs, voff[j], 0);
+        prefetch(rt + 1);
     }
     __device__ __forceinline__ void store(float* tile, const float (&v)[NLD]) const {
 #pragma unroll
@@ -469,8 +525,11 @@ __device__ __forceinline__ int xcd_swizzle(int id, int n) {
 
 // ---- the kernel -------------------------------------------------------------------------------
 // grid.x = tiles_i * tiles_j (i fastest), grid.y = groups (zg), grid.z = reduction splits (zs).
-template <int BM, int BN, int BR, int WM, int WN, class LA, class LB, class EP>
-__global__ __launch_bounds__(NT) void mfma_contract(const typename LA::Params pa, const typename LB::Params pb,
+// OCC = workgroups per CU the register allocation must allow (__launch_bounds__' second argument = waves per SIMD).
+// Measured: the conv instances use 144 registers (3 waves per SIMD); with OCC = 4 hipcc fits the same loop in 126 without
+// a spill, and nothing gets faster (conv2..5 fwd / dgrad within +-2 %) -- occupancy is not what holds these kernels back.
+template <int BM, int BN, int BR, int WM, int WN, class LA, class LB, class EP, int OCC = 1>
+__global__ __launch_bounds__(NT, OCC) void mfma_contract(const typename LA::Params pa, const typename LB::Params pb,
                                                     const typename EP::Params pe, int tiles_i, int rtiles,
                                                     int rt_per_split) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
@@ -597,7 +656,6 @@ struct WgradDmaCfg {
 // and turns every later table read into a vector load + readfirstlane loop (the builtin counts as a store to any memory).
 // The asm form is invisible to both: the kernel orders DMA -> ds_read itself (vmcnt(0) + barrier at the end of a tile).
 typedef int i32x4 __attribute__((ext_vector_type(4)));
-typedef const __attribute__((address_space(4))) int* const_int_ptr;   // constant address space: uniform reads become s_load
 __device__ __forceinline__ i32x4 rsrc_words(const float* base, int64_t bytes) {
     const uint64_t a = (uint64_t)base;
     return i32x4{(int)(uint32_t)a, (int)((uint32_t)(a >> 32) & 0xffffu), (int)(uint32_t)bytes, 0x00020000};
@@ -829,10 +887,16 @@ struct vl_conv_desc {
     int K;    // kh*kw*cig
     int Kd;   // kh*kw*cog (dgrad reduction length)
     int x_halo, y_halo, dy_halo, dx_halo;
-    int2* ktab2_fwd;  // checked-mode tables (device), halo-aware offsets
-    int2* ktab2_bwd;
-    int* ktab_fwd;    // padded-mode tables
-    int* ktab_bwd;
+    int2* ktab2_fwd;  // natural order, checked mode: {byte offset, kh << 16 | kw} (device), halo-aware
+    int* ktab_fwd;    // natural order, padded mode: byte offset
+    // forward / dgrad run their reduction in the permuted order (build_ktabs): gather tables in that order + first weight
+    // row of every 16-row reduction tile.  wgrad keeps the natural-order tables above (its rows ARE the output rows).
+    int2* ptab2_fwd;
+    int2* ptab2_bwd;
+    int* ptab_fwd;
+    int* ptab_bwd;
+    int* rowtab_fwd;
+    int* rowtab_bwd;
     int fwd_padded, bwd_padded;
 };
 
@@ -844,50 +908,94 @@ static void tf_same_pad(int in, int k, int s, int* out, int* before, int* after)
     *after = total - *before;
 }
 
-// tables over planes of physical size (H + 2 halo) x (W + 2 halo); rows ordered (kh, kw, c) like HWIO
-static int build_ktabs(int** dev1, int2** dev2, int kh, int kw, int cg, int H, int W, int halo) {
+// Reduction-order position k of a conv contraction -> weight / im2col row (ky, kx, c) (the HWIO row index is
+// (ky * kw + kx) * cg + c).
+//   natural  : k = (ky, kx, c), c fastest -- the HWIO row order; wgrad uses it (its rows are the output rows).
+//   permuted : k = (c / 16, ky, kx, c % 16) when cg % 16 == 0 -- forward and dgrad.  A 16-row reduction tile is then ONE
+//              tap of ONE 16-channel block, and the kh*kw tiles that follow it are the other taps of the same block: they
+//              re-touch the same ~(16 channels x pixel-tile footprint) = 10-20 KB of the input, which stays in L1/L2.
+//              In natural order a tile sweeps ALL cg channels before the next tap returns to them; with 128 workgroups
+//              per XCD that is a 7-19 MB working set against a 4 MB L2 (measured: conv2 dgrad fetched 19 GB per launch,
+//              18x its input, at 4 TB/s -- HBM-bound).  Each 16-row tile is still 16 CONSECUTIVE weight rows.
+static constexpr int KBLK = 16;   // = the reduction tile of launch_conv
+
+static void k_to_row(int k, int kh, int kw, int cg, bool permuted, int* ky, int* kx, int* c) {
+    if (permuted) {
+        const int cl = k % KBLK, t = k / KBLK;
+        *kx = t % kw;
+        *ky = (t / kw) % kh;
+        *c = (t / (kw * kh)) * KBLK + cl;
+    } else {
+        *c = k % cg;
+        *kx = (k / cg) % kw;
+        *ky = k / (cg * kw);
+    }
+}
+
+static void free_dev(void* p) {
+    if (p) (void)hipFree(p);
+}
+
+template <class T>
+static int upload(T** dev, const T* host, size_t count) {
+    free_dev(*dev);
+    *dev = nullptr;
+    hipError_t e = hipMalloc((void**)dev, sizeof(T) * count);
+    if (e == hipSuccess) e = hipMemcpy(*dev, host, sizeof(T) * count, hipMemcpyHostToDevice);
+    return e == hipSuccess ? 0 : 2;
+}
+
+// Gather tables over planes of physical size (H + 2 halo) x (W + 2 halo) in the given reduction order:
+//   dev1[k] = byte offset of tap k                        (padded mode)
+//   dev2[k] = {byte offset, ky << 16 | kx}                (checked mode)
+//   rowtab[t] = first HWIO weight row of reduction tile t (16 consecutive rows), when rowtab != null
+static int build_ktabs(int** dev1, int2** dev2, int** rowtab, int kh, int kw, int cg, int H, int W, int halo, bool permuted) {
     const int K = kh * kw * cg;
     const int pad = ((K + 127) / 128) * 128 + 256;
     const int Wp = W + 2 * halo;
     const int64_t Pp = (int64_t)(H + 2 * halo) * Wp;
+    const int ntiles = pad / KBLK;
     int* h1 = (int*)malloc(sizeof(int) * pad);
     int2* h2 = (int2*)malloc(sizeof(int2) * pad);
-    if (!h1 || !h2) {
+    int* h3 = (int*)malloc(sizeof(int) * ntiles);
+    if (!h1 || !h2 || !h3) {
         free(h1);
         free(h2);
+        free(h3);
         return 1;
     }
     for (int k = 0; k < pad; ++k) {
         if (k < K) {
-            const int c = k % cg, kx = (k / cg) % kw, ky = k / (cg * kw);
+            int ky, kx, c;
+            k_to_row(k, kh, kw, cg, permuted, &ky, &kx, &c);
             const int64_t off = ((int64_t)c * Pp + (int64_t)ky * Wp + kx) * 4;
             h1[k] = (int)off;
             h2[k].x = (int)off;
             h2[k].y = (ky << 16) | kx;
+            if (k % KBLK == 0) h3[k / KBLK] = (ky * kw + kx) * cg + c;
         } else {
             h1[k] = 0;               // padded mode: a valid address; the weight row is zero (range check)
             h2[k].x = 0;
             h2[k].y = 0x4000 << 16;  // checked mode: fails the row test
+            if (k % KBLK == 0) h3[k / KBLK] = 0;
         }
     }
-    if (*dev1) (void)hipFree(*dev1);
-    if (*dev2) (void)hipFree(*dev2);
-    *dev1 = nullptr;
-    *dev2 = nullptr;
-    hipError_t e = hipMalloc((void**)dev1, sizeof(int) * pad);
-    if (e == hipSuccess) e = hipMalloc((void**)dev2, sizeof(int2) * pad);
-    if (e == hipSuccess) e = hipMemcpy(*dev1, h1, sizeof(int) * pad, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(*dev2, h2, sizeof(int2) * pad, hipMemcpyHostToDevice);
+    int rc = upload(dev1, h1, pad);
+    if (rc == 0) rc = upload(dev2, h2, pad);
+    if (rc == 0 && rowtab) rc = upload(rowtab, h3, ntiles);
     free(h1);
     free(h2);
-    return e == hipSuccess ? 0 : 2;
+    free(h3);
+    return rc;
 }
 
 static int rebuild_tables(vl_conv_desc* d) {
-    int rc = build_ktabs(&d->ktab_fwd, &d->ktab2_fwd, d->kh, d->kw, d->cig, d->h, d->w, d->x_halo);
+    int rc = build_ktabs(&d->ktab_fwd, &d->ktab2_fwd, nullptr, d->kh, d->kw, d->cig, d->h, d->w, d->x_halo, false);
+    if (rc == 0)
+        rc = build_ktabs(&d->ptab_fwd, &d->ptab2_fwd, &d->rowtab_fwd, d->kh, d->kw, d->cig, d->h, d->w, d->x_halo, d->cig % KBLK == 0);
     d->fwd_padded = d->x_halo >= d->pt && d->x_halo >= d->pb && d->x_halo >= d->pl && d->x_halo >= d->pr;
     if (rc == 0 && d->stride == 1) {
-        rc = build_ktabs(&d->ktab_bwd, &d->ktab2_bwd, d->kh, d->kw, d->cog, d->oh, d->ow, d->dy_halo);
+        rc = build_ktabs(&d->ptab_bwd, &d->ptab2_bwd, &d->rowtab_bwd, d->kh, d->kw, d->cog, d->oh, d->ow, d->dy_halo, d->cog % KBLK == 0);
         // dgrad pads dy by K-1-pad before and by the forward pad-before after
         const int need = (d->kh - 1 - d->pt > d->pt ? d->kh - 1 - d->pt : d->pt);
         const int needw = (d->kw - 1 - d->pl > d->pl ? d->kw - 1 - d->pl : d->pl);
@@ -930,10 +1038,14 @@ extern "C" int vl_conv_set_halo(vl_conv_desc* d, int x_halo, int y_halo, int dy_
 
 extern "C" void vl_conv_destroy(vl_conv_desc* d) {
     if (!d) return;
-    if (d->ktab_fwd) (void)hipFree(d->ktab_fwd);
-    if (d->ktab_bwd) (void)hipFree(d->ktab_bwd);
-    if (d->ktab2_fwd) (void)hipFree(d->ktab2_fwd);
-    if (d->ktab2_bwd) (void)hipFree(d->ktab2_bwd);
+    free_dev(d->ktab_fwd);
+    free_dev(d->ktab2_fwd);
+    free_dev(d->ptab_fwd);
+    free_dev(d->ptab2_fwd);
+    free_dev(d->ptab_bwd);
+    free_dev(d->ptab2_bwd);
+    free_dev(d->rowtab_fwd);
+    free_dev(d->rowtab_bwd);
     free(d);
 }
 
@@ -954,12 +1066,12 @@ struct ConvOut {
 };
 
 template <int BM, int WM, int WN, bool PADDED>
-static int launch_conv(const ConvGeom& g, const float* w, int64_t w_ld, int w_grp_stride, int Cog, int Cout_total,
-                       const ConvOut& o, hipStream_t s) {
-    constexpr int BN = 128, BR = 16;
-    using LA = DenseKX<BM, BR>;
+static int launch_conv(const ConvGeom& g, const float* w, int64_t w_ld, int w_grp_stride, const int* row_tab, int Cog,
+                       int Cout_total, const ConvOut& o, hipStream_t s) {
+    constexpr int BN = 128, BR = KBLK;
+    using LA = ConvWeightKX<BM, BR>;
     using LB = ConvGather<BN, BR, PADDED>;
-    typename LA::Params pa{w, w_ld, Cog, g.K, (int64_t)w_grp_stride};
+    typename LA::Params pa{w, w_ld, Cog, g.K, (int64_t)w_grp_stride, row_tab};
     EpiConvNCHW::Params pe;
     pe.y = o.y; pe.bias = o.bias; pe.mask = o.mask; pe.relu = o.relu;
     pe.Cog = Cog; pe.Cout_total = Cout_total; pe.OHW = g.OHW; pe.OW = g.OW; pe.M = g.M;
@@ -969,20 +1081,20 @@ static int launch_conv(const ConvGeom& g, const float* w, int64_t w_ld, int w_gr
     const int tiles_i = ceil_div(Cog, BM), tiles_j = ceil_div(g.M, BN);
     const int rtiles = ceil_div(g.K, BR);
     dim3 grid(tiles_i * tiles_j, (unsigned)(Cout_total / Cog), 1);
-    hipLaunchKernelGGL((mfma_contract<BM, BN, BR, WM, WN, LA, LB, EpiConvNCHW>), grid, dim3(NT), 0, s, pa, g, pe, tiles_i, rtiles,
-                       rtiles);
+    hipLaunchKernelGGL((mfma_contract<BM, BN, BR, WM, WN, LA, LB, EpiConvNCHW>), grid, dim3(NT), 0, s, pa, g, pe,
+                       tiles_i, rtiles, rtiles);
     VL_LAUNCH_CHECK();
     return 0;
 }
 
 template <bool PADDED>
-static int dispatch_conv(const ConvGeom& g, const float* w, int64_t w_ld, int w_grp_stride, int Cog, int Cout_total,
-                         const ConvOut& o, hipStream_t s) {
+static int dispatch_conv(const ConvGeom& g, const float* w, int64_t w_ld, int w_grp_stride, const int* row_tab, int Cog,
+                         int Cout_total, const ConvOut& o, hipStream_t s) {
     // output-channel tile: 128 when it divides well, else 96 (conv1: 96, conv4: 192) or 64 (conv2 dgrad: 48)
     const int w128 = ceil_div(Cog, 128) * 128, w96 = ceil_div(Cog, 96) * 96, w64 = ceil_div(Cog, 64) * 64;
-    if (w128 <= w96 && w128 <= w64) return launch_conv<128, 2, 2, PADDED>(g, w, w_ld, w_grp_stride, Cog, Cout_total, o, s);
-    if (w96 <= w64) return launch_conv<96, 1, 4, PADDED>(g, w, w_ld, w_grp_stride, Cog, Cout_total, o, s);
-    return launch_conv<64, 1, 4, PADDED>(g, w, w_ld, w_grp_stride, Cog, Cout_total, o, s);
+    if (w128 <= w96 && w128 <= w64) return launch_conv<128, 2, 2, PADDED>(g, w, w_ld, w_grp_stride, row_tab, Cog, Cout_total, o, s);
+    if (w96 <= w64) return launch_conv<96, 1, 4, PADDED>(g, w, w_ld, w_grp_stride, row_tab, Cog, Cout_total, o, s);
+    return launch_conv<64, 1, 4, PADDED>(g, w, w_ld, w_grp_stride, row_tab, Cog, Cout_total, o, s);
 }
 
 static void fill_geom(ConvGeom& g, const float* x, int n, int cin_total, int cig, int H, int W, int halo, int OH, int OW,
@@ -1003,12 +1115,12 @@ extern "C" int vl_conv_fwd(const vl_conv_desc* d, const float* x, const float* w
     VL_CHECK(d && x && w && y, "vl_conv_fwd: null argument");
     VL_CHECK(n > 0 && (int64_t)n * d->oh * d->ow < (1ll << 31), "vl_conv_fwd: bad batch %d", n);
     ConvGeom g;
-    fill_geom(g, x, n, d->cin, d->cig, d->h, d->w, d->x_halo, d->oh, d->ow, d->stride, d->pt, d->pl, d->K, d->ktab_fwd, d->ktab2_fwd);
+    fill_geom(g, x, n, d->cin, d->cig, d->h, d->w, d->x_halo, d->oh, d->ow, d->stride, d->pt, d->pl, d->K, d->ptab_fwd, d->ptab2_fwd);
     VL_CHECK(g.total * 4 < MAX_BUF_BYTES, "vl_conv_fwd: input of %lld elements exceeds the buffer-offset range", (long long)g.total);
     ConvOut o{y, bias, nullptr, relu, d->y_halo, 0, d->oh, d->ow};
     // HWIO weights are the [K][Cout_total] GEMM operand as they stand; group g = column block g*cog.
-    if (d->fwd_padded) return dispatch_conv<true>(g, w, d->cout, d->cog, d->cog, d->cout, o, (hipStream_t)stream);
-    return dispatch_conv<false>(g, w, d->cout, d->cog, d->cog, d->cout, o, (hipStream_t)stream);
+    if (d->fwd_padded) return dispatch_conv<true>(g, w, d->cout, d->cog, d->rowtab_fwd, d->cog, d->cout, o, (hipStream_t)stream);
+    return dispatch_conv<false>(g, w, d->cout, d->cog, d->rowtab_fwd, d->cog, d->cout, o, (hipStream_t)stream);
 }
 
 __global__ void conv_wt_transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, int KH, int KW, int cig,
@@ -1044,11 +1156,11 @@ extern "C" int vl_conv_dgrad(const vl_conv_desc* d, const float* dy, const float
     // dx = conv(dy, wt) with pad' = K-1-pad: the same kernel with the roles of the channel sets swapped.
     ConvGeom g;
     fill_geom(g, dy, n, d->cout, d->cog, d->oh, d->ow, d->dy_halo, d->h, d->w, 1, d->kh - 1 - d->pt, d->kw - 1 - d->pl, d->Kd,
-              d->ktab_bwd, d->ktab2_bwd);
+              d->ptab_bwd, d->ptab2_bwd);
     VL_CHECK(g.total * 4 < MAX_BUF_BYTES, "vl_conv_dgrad: dy of %lld elements exceeds the buffer-offset range", (long long)g.total);
     ConvOut o{dx, nullptr, relu_mask, 0, d->dx_halo, d->x_halo, d->h, d->w};
-    if (d->bwd_padded) return dispatch_conv<true>(g, wt, d->cin, d->cig, d->cig, d->cin, o, (hipStream_t)stream);
-    return dispatch_conv<false>(g, wt, d->cin, d->cig, d->cig, d->cin, o, (hipStream_t)stream);
+    if (d->bwd_padded) return dispatch_conv<true>(g, wt, d->cin, d->cig, d->rowtab_bwd, d->cig, d->cin, o, (hipStream_t)stream);
+    return dispatch_conv<false>(g, wt, d->cin, d->cig, d->rowtab_bwd, d->cig, d->cin, o, (hipStream_t)stream);
 }
 
 // ---- conv wgrad -------------------------------------------------------------------------------

@@ -1,6 +1,8 @@
 // HBM-bound kernels of the LRCN path: input prep, LRN, max-pool, bias/column sums, LSTM gate
 // pointwise, temporal fusion, dropout, softmax cross-entropy, global-norm + SGD/Adam.
 // All activations NCHW fp32; lanes always walk the contiguous (w / hw / column) dimension.
+#include <stdlib.h>
+
 #include "common.h"
 
 static inline int grid_for(int64_t work, int threads, int cap) {
@@ -273,6 +275,167 @@ __global__ __launch_bounds__(256) void pool_lrn_bwd_kernel(const float* __restri
     }
 }
 
+// ---- the same fused backward as a CHANNEL STREAM (the form the benchmark layers run) ----------------------------------
+// One thread = one pixel of one image; it walks ALL channels in order, carrying the LRN windows (5 inputs, 5 t-terms,
+// 3 u-terms) in registers, so no channel is re-read or re-computed at chunk edges (the chunked form above reads 24 and
+// evaluates 20 channels per 16 outputs), and the x loads of the next 16 channels are in flight while this 16 are computed:
+// 16 KB per workgroup outstanding at all times -- the chunked form alternated load-wait and compute phases and reached
+// ~40 % of the HBM rate.  The pooled gradient / arg-max of each 16-channel chunk go through LDS (two buffers, one barrier
+// per chunk) as 8-byte {dp, arg} entries; the <= 4 pooling windows of a pixel are two adjacent entries in each of two
+// pooled rows, i.e. two addresses + an immediate.  x loads / dx stores are buffer accesses with a per-thread constant
+// pixel offset and a scalar channel offset: pixels past the plane fail the range check (loads 0, stores dropped).
+// Channel cc enters the x window at iteration cc; t[cc-2] is then computable, and the output of channel cc-4.
+static constexpr uint32_t PW_OOB = 0xF0000000u;   // fails the range check of every resource built below (sizes < 2^31)
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t pw_rsrc(const void* base, int64_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)(uint32_t)bytes, 0x00020000);
+}
+
+template <int CHK, int NST, bool RELU>
+__global__ __launch_bounds__(256) void pool_lrn_bwd_stream_kernel(const float* __restrict__ x, const float* __restrict__ dp,
+                                                                  const uint8_t* __restrict__ arg, float* __restrict__ dx, int C,
+                                                                  int H, int W, int OH, int OW, int64_t ps_n, int ps_c, int ps_h,
+                                                                  int64_t pooled_bytes_f, float alpha, float bias, int halo) {
+    constexpr int BUF = NST * 256 + 16;                               // entries per LDS buffer (+ pad: entries -1 and one-past-the-end are read)
+    __shared__ __attribute__((aligned(16))) uint2 stage[2 * BUF];
+    const int HW = H * W;
+    const int img = blockIdx.y;
+    const int p0 = blockIdx.x * 256, p = p0 + threadIdx.x;
+    const bool valid = p < HW;
+    const int pc = valid ? p : HW - 1;
+    const int py = pc / W, px = pc - py * W;
+    const int r0 = p0 / W, r1 = min(p0 + 255, HW - 1) / W;            // input rows of the band
+    const int oh0 = (r0 >> 1) - 1;                                    // first pooled row that can reach the band
+    const int prow = (r1 >> 1) - oh0 + 1;
+    const int rowlen = prow * OW;
+
+    // ---- per-thread constants of the staging pass: entry e = tid + 256 j  <->  (slab ci, pooled row, pooled column),
+    // packed as ci << 24 | (row * pitch + column); -1 = nothing to fetch
+    int st[NST];
+#pragma unroll
+    for (int j = 0; j < NST; ++j) {
+        const int e = threadIdx.x + 256 * j;
+        const int ci = e / rowlen, rem = e - ci * rowlen;
+        const int rr = rem / OW, ow = rem - rr * OW;
+        const int oh = oh0 + rr;
+        st[j] = (ci < CHK && oh >= 0 && oh < OH) ? (ci << 24) | (oh * ps_h + ow) : -1;
+    }
+    // ---- the pixel's pooling windows (k = 3, s = 2): rows oh = py>>1 (a = 0) and oh - 1 (a = 1), columns ow = px>>1 (b = 0)
+    // and ow - 1 (b = 1).  Addresses: entry (row, ow - 1) of slab 0, +1 entry for b = 0; wloc = the window-local index the
+    // arg-max byte must equal for the window to route its gradient to this pixel (254 = never).
+    int wloc[4];
+    uint32_t rowaddr[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int oh = (py >> 1) - a, lr = (py & 1) + 2 * a;
+        const bool rok = valid && oh >= 0 && oh < OH && lr <= 2;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int ow = (px >> 1) - b, lc = (px & 1) + 2 * b;
+            wloc[a * 2 + b] = (rok && ow >= 0 && ow < OW && lc <= 2) ? lr * 3 + lc : 254;
+        }
+        const int rr = min(max(oh - oh0, 0), prow - 1);               // clamped: unreachable windows still read inside the buffer
+        rowaddr[a] = (uint32_t)(8 + rr * OW + (px >> 1) - 1) * 8u;    // byte offset in a buffer; entry 8 = slab 0, row 0, column 0
+    }
+    const uint32_t slab_bytes = (uint32_t)rowlen * 8u;
+
+    const __amdgpu_buffer_rsrc_t rs_x = pw_rsrc(x + (int64_t)img * C * HW, (int64_t)C * HW * 4);
+    const int wp = W + 2 * halo;
+    const int dplane = (H + 2 * halo) * wp;
+    const __amdgpu_buffer_rsrc_t rs_dx = pw_rsrc(dx + (int64_t)img * C * dplane, (int64_t)C * dplane * 4);
+    const __amdgpu_buffer_rsrc_t rs_dp = pw_rsrc(dp + (int64_t)img * ps_n, pooled_bytes_f);
+    const __amdgpu_buffer_rsrc_t rs_arg = pw_rsrc(arg + (int64_t)img * ps_n, pooled_bytes_f / 4);
+    const uint32_t voff_x = valid ? (uint32_t)p * 4u : PW_OOB;
+    const uint32_t voff_dx = valid ? (uint32_t)((py + halo) * wp + px + halo) * 4u : PW_OOB;
+    const int x_cs = HW * 4, dx_cs = dplane * 4;                      // channel strides in bytes
+
+    float dpv[NST];
+    uint32_t av[NST];
+    auto stage_load = [&](int c0) {                                   // slab ci holds channel c0 - 2 + ci
+#pragma unroll
+        for (int j = 0; j < NST; ++j) {
+            const int c = c0 - 2 + (st[j] >> 24);
+            const bool ok = st[j] >= 0 && c >= 0 && c < C;
+            const int off = c * ps_c + (st[j] & 0xffffff);
+            dpv[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_dp, ok ? off * 4 : (int)PW_OOB, 0, 0));
+            av[j] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(rs_arg, ok ? off : (int)PW_OOB, 0, 0);
+        }
+    };
+    auto stage_write = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < NST; ++j) stage[buf * BUF + 8 + threadIdx.x + 256 * j] = make_uint2(__builtin_bit_cast(uint32_t, dpv[j]), av[j]);
+    };
+    float xa[CHK], xb[CHK];
+    auto x_load = [&](int c0, float (&v)[CHK]) {
+#pragma unroll
+        for (int i = 0; i < CHK; ++i) {
+            const int cc = c0 + i;                                    // uniform; channels past C: the range check answers 0
+            v[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, (int)(cc < C ? voff_x : PW_OOB), cc * x_cs, 0));
+        }
+    };
+
+    float xw0 = 0.f, xw1 = 0.f, xw2 = 0.f, xw3 = 0.f, xw4 = 0.f;      // x[cc-4 .. cc]
+    float tw0 = 0.f, tw1 = 0.f, tw2 = 0.f, tw3 = 0.f, tw4 = 0.f;      // t[cc-6 .. cc-2]
+    float uw0 = 0.f, uw1 = 0.f, uw2 = 0.f;                            // u[cc-4 .. cc-2]
+    const float k2ab = 2.f * alpha * 0.75f;
+    const unsigned char* sbytes = reinterpret_cast<const unsigned char*>(stage);
+
+    // one chunk: no branch inside, so the LDS reads and the math of neighbouring channels interleave freely
+    auto chunk = [&](int c0, int buf, const float (&xin)[CHK]) {
+        const uint32_t b0 = (uint32_t)(buf * BUF) * 8u;
+        uint32_t a0 = b0 + rowaddr[0], a1 = b0 + rowaddr[1];
+#pragma unroll
+        for (int i = 0; i < CHK; ++i) {
+            const int cc = c0 + i;
+            // routed pooling gradient of channel cc - 2 (slab i)
+            const uint2 e00 = *reinterpret_cast<const uint2*>(sbytes + a0 + 8), e01 = *reinterpret_cast<const uint2*>(sbytes + a0);
+            const uint2 e10 = *reinterpret_cast<const uint2*>(sbytes + a1 + 8), e11 = *reinterpret_cast<const uint2*>(sbytes + a1);
+            a0 += slab_bytes;
+            a1 += slab_bytes;
+            float g = 0.f;
+            g += ((int)e00.y == wloc[0]) ? __builtin_bit_cast(float, e00.x) : 0.f;
+            g += ((int)e01.y == wloc[1]) ? __builtin_bit_cast(float, e01.x) : 0.f;
+            g += ((int)e10.y == wloc[2]) ? __builtin_bit_cast(float, e10.x) : 0.f;
+            g += ((int)e11.y == wloc[3]) ? __builtin_bit_cast(float, e11.x) : 0.f;
+            xw0 = xw1; xw1 = xw2; xw2 = xw3; xw3 = xw4; xw4 = xin[i];
+            float s = 0.f;
+            s += xw0 * xw0; s += xw1 * xw1; s += xw2 * xw2; s += xw3 * xw3; s += xw4 * xw4;
+            const float sc = bias + alpha * s;
+            const float rq = __builtin_amdgcn_rsqf(sc);
+            const float pw = rq * __builtin_amdgcn_sqrtf(rq);        // sc^-0.75 (pow_neg's beta = 0.75 form)
+            tw0 = tw1; tw1 = tw2; tw2 = tw3; tw3 = tw4;
+            tw4 = g * xw2 * pw * __builtin_amdgcn_rcpf(sc);
+            uw0 = uw1; uw1 = uw2; uw2 = g * pw;
+            const int oc = cc - 4;                                    // uniform; outside [0, C): the store's range check drops it
+            float a = 0.f;
+            a += tw0; a += tw1; a += tw2; a += tw3; a += tw4;
+            float r = uw0 - k2ab * xw0 * a;
+            if (RELU) r = xw0 > 0.f ? r : 0.f;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, r), rs_dx, (int)((oc >= 0 && oc < C) ? voff_dx : PW_OOB),
+                                                  oc * dx_cs, 0);
+        }
+    };
+
+    const int nchunks = (C + 4 + CHK - 1) / CHK;
+    stage_load(0);
+    x_load(0, xa);
+    stage_write(0);
+    __syncthreads();
+    for (int k = 0; k < nchunks; k += 2) {                            // unrolled by two: the x registers alternate without copies
+        stage_load((k + 1) * CHK);                                    // next chunk's traffic goes out before this chunk's math;
+        x_load((k + 1) * CHK, xb);                                    // past the last chunk every lane fails the channel test
+        chunk(k * CHK, 0, xa);
+        stage_write(1);
+        __syncthreads();
+        if (k + 1 >= nchunks) break;
+        stage_load((k + 2) * CHK);
+        x_load((k + 2) * CHK, xa);
+        chunk((k + 1) * CHK, 1, xb);
+        stage_write(0);
+        __syncthreads();
+    }
+}
+
 extern "C" int vl_pool_lrn_bwd(const float* x, const float* dp, const uint8_t* argmax, float* dx, int n, int c, int h, int w,
                                int p_halo, int radius, float alpha, float beta, float bias, int relu_fused, int dx_halo,
                                vl_stream_t stream) {
@@ -282,8 +445,33 @@ extern "C" int vl_pool_lrn_bwd(const float* x, const float* dp, const uint8_t* a
     const int owp = ow + 2 * p_halo;
     const int64_t pplane = (int64_t)(oh + 2 * p_halo) * owp;
     const int64_t origin = (int64_t)p_halo * owp + p_halo;
-    constexpr int CH = 16, NPIX = 512;
     VL_CHECK(n <= 65535, "vl_pool_lrn_bwd: batch %d exceeds the grid limit", n);
+    {   // channel-stream form: a 256-pixel band x one channel chunk of pooled entries must fit NST * 256 staging slots
+        const int rows = (255 + w - 1) / w + 1;                        // input rows a 256-pixel band can touch
+        const int max_prow = rows / 2 + 2;
+        const int64_t bytes_x = (int64_t)(c + 24) * h * w * 4, bytes_dx = (int64_t)(c + 24) * (h + 2 * dx_halo) * (w + 2 * dx_halo) * 4;
+        const int64_t pooled_f = ((int64_t)c * pplane - origin) * 4;
+        const bool ok = beta == 0.75f && bytes_x < (1ll << 31) && bytes_dx < (1ll << 31) && pooled_f < (1ll << 31) && pplane < (1 << 24) &&
+                        getenv("VL_POOL_LRN_CHUNKED") == nullptr;
+        const dim3 grid(ceil_div((int64_t)h * w, 256), n);
+        const int64_t psn = (int64_t)c * pplane;
+#define VL_PLB_LAUNCH(CHK, NST)                                                                                                     \
+    do {                                                                                                                            \
+        if (relu_fused)                                                                                                             \
+            hipLaunchKernelGGL((pool_lrn_bwd_stream_kernel<CHK, NST, true>), grid, dim3(256), 0, (hipStream_t)stream, x, dp + origin, \
+                               argmax + origin, dx, c, h, w, oh, ow, psn, (int)pplane, owp, pooled_f, alpha, bias, dx_halo);        \
+        else                                                                                                                        \
+            hipLaunchKernelGGL((pool_lrn_bwd_stream_kernel<CHK, NST, false>), grid, dim3(256), 0, (hipStream_t)stream, x, dp + origin, \
+                               argmax + origin, dx, c, h, w, oh, ow, psn, (int)pplane, owp, pooled_f, alpha, bias, dx_halo);        \
+        VL_LAUNCH_CHECK();                                                                                                          \
+        return 0;                                                                                                                   \
+    } while (0)
+        // chunk = 20 channels when C + 4 is a multiple of it (96 and 256 are): no idle tail iterations
+        if (ok && (c + 4) % 20 == 0 && (int64_t)20 * max_prow * ow <= 11 * 256 && getenv("VL_POOL_LRN_CHK16") == nullptr) VL_PLB_LAUNCH(20, 11);
+        if (ok && (int64_t)16 * max_prow * ow <= 9 * 256) VL_PLB_LAUNCH(16, 9);
+#undef VL_PLB_LAUNCH
+    }
+    constexpr int CH = 16, NPIX = 512;
     const int max_prow = ((NPIX + w - 1) / w + 1) / 2 + 3;             // pooled rows one band can touch
     const size_t lds = (((size_t)(CH + 4) * max_prow * ow * (sizeof(float) + 1)) + 15) & ~(size_t)15;
     VL_CHECK(lds <= 64 * 1024, "vl_pool_lrn_bwd: pooled plane too wide (%d) for the LDS staging", ow);
