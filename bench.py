@@ -32,7 +32,28 @@ PEAK_FP32_MFMA_TFLOPS = 157.3              # MI355X_MICROARCH.md: v_mfma_f32_32x
 # (output-channel tile 128: conv2/3/5 forward and conv3 dgrad, whose output channel count is 256)
 DOMINANT = ("conv2.fwd", "conv3.fwd", "conv5.fwd", "conv3.dgrad")
 DOMINANT_SYMBOL = "mfma_contract<128, 128, 16, 2, 2, ConvWeightKX<128, 16>, ConvGather<128, 16, true>, EpiConvNCHW, 1>"
+# algorithmic HBM bytes of those launches per frame: input + weights (per launch) + output, fp32, interiors only
+DOMINANT_ELEMS_PER_FRAME = {"conv2.fwd": 96 * 28 * 28 + 256 * 28 * 28, "conv3.fwd": 256 * 169 + 384 * 169,
+                            "conv5.fwd": 384 * 169 + 256 * 169, "conv3.dgrad": 384 * 169 + 256 * 169}
+DOMINANT_WEIGHT_ELEMS = {"conv2.fwd": 5 * 5 * 48 * 256, "conv3.fwd": 3 * 3 * 256 * 384, "conv5.fwd": 3 * 3 * 192 * 256,
+                         "conv3.dgrad": 3 * 3 * 256 * 384}
 MEAN_BGR = np.array([99.197148, 105.293620, 109.503945], np.float32)
+
+
+def committed_traffic(symbol_prefix):
+    """HBM bytes per launch of the dominant kernel from the PMC passes of tools/profile_round.sh (FETCH_SIZE and WRITE_SIZE
+    cannot be collected inside this process): profiles/r*_bench_n1_traffic.json, newest round first.  None if absent or
+    taken on a different kernel symbol."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_n1_traffic.json")), reverse=True):
+        try:
+            with open(f) as fh:
+                rec = json.load(fh)
+        except (OSError, ValueError):
+            continue
+        if str(rec.get("kernel", "")).startswith(symbol_prefix):
+            return rec, os.path.relpath(f, ROOT)
+    return None, None
 
 
 def cpu_baseline(clips, fpc, num_classes):
@@ -151,6 +172,8 @@ def main():
     achieved = dom_flop / (dom_ms * 1e-3) / 1e12
     stack_flop = sum(2.0 * CONV_MACS[l.split(".")[0]] * n for l in avg)
     stack_ms = sum(avg.values())
+    traffic_rec, traffic_src = committed_traffic(DOMINANT_SYMBOL.rsplit(",", 1)[0])
+    alg_bytes = sum(4.0 * (DOMINANT_ELEMS_PER_FRAME[l] * n + DOMINANT_WEIGHT_ELEMS[l]) for l in DOMINANT) / len(DOMINANT)
     ms_per_step = elapsed / args.steps * 1e3
     value = total_clips * args.steps / elapsed
     rec = {
@@ -162,7 +185,11 @@ def main():
                    "global_batch": total_clips, "clips_per_gpu": clips, "frames_per_clip": args.fpc,
                    "parallelism": "dp%d" % world, "optimizer": "sgd+clip_by_global_norm(10)", "init": "reference (sigma 0.05)"},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                     "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+                     "traffic": traffic_rec["bytes_per_launch"] if (traffic_rec and n == 1024) else None,
+                     "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes)",
+                     "traffic_source": traffic_src if n == 1024 else None,
+                     "algorithmic_bytes_per_launch": alg_bytes,
                      "kernel": DOMINANT_SYMBOL, "launches": list(DOMINANT),
                      "flop_per_launch": dom_flop, "ms_per_launch": round(dom_ms, 4),
                      "conv_stack": {"tflops": round(stack_flop / (stack_ms * 1e-3) / 1e12, 2),

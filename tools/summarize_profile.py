@@ -18,7 +18,7 @@ import os
 import sqlite3
 import sys
 
-DOMINANT = "mfma_contract<128, 128, 16, 2, 2, ConvWeightKX<128, 16>, ConvGather<128, 16, true>, EpiConvNCHW, 1>"
+DOMINANT = "mfma_contract<128, 128, 16, 2, 2, ConvWeightKX<128, 16>, ConvGather<128, 16, true>, EpiConvNCHW"   # prefix of the symbol
 GRAD_FLOATS = 44570341          # flat parameter / gradient buffer of the benchmark config
 
 
@@ -79,12 +79,14 @@ def main():
                 wk = write.get(n, (0, 0.0))[1]
                 kr, kw, note = known.get(n, ("", "", ""))
                 w.writerow([n, c, round(fk, 1), round(wk, 1), int(fk * 1024 * 2), int(wk * 1024), kr, kw, note])
-        if DOMINANT in fetch:
-            fk, wk = fetch[DOMINANT][1], write.get(DOMINANT, (0, 0.0))[1]
+        dom = [n for n in fetch if n.startswith(DOMINANT)]
+        if dom:
+            DOM = dom[0]
+            fk, wk = fetch[DOM][1], write.get(DOM, (0, 0.0))[1]
             cal_r = fetch.get("sumsq_stage1", (0, 0))[1] * 1024 * 2 / (GRAD_FLOATS * 4)
             cal_w = write.get("sgd_apply_kernel", (0, 0))[1] * 1024 / (GRAD_FLOATS * 4)
-            rec = {"kernel": DOMINANT, "read_bytes_per_launch": int(fk * 1024 * 2), "write_bytes_per_launch": int(wk * 1024),
-                   "bytes_per_launch": int(fk * 1024 * 2 + wk * 1024), "launches_averaged": fetch[DOMINANT][0],
+            rec = {"kernel": DOM, "read_bytes_per_launch": int(fk * 1024 * 2), "write_bytes_per_launch": int(wk * 1024),
+                   "bytes_per_launch": int(fk * 1024 * 2 + wk * 1024), "launches_averaged": fetch[DOM][0],
                    "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `bench.py --steps 2 --warmup 1`; "
                              "FETCH_SIZE x2 (gfx950: 128-B requests tallied at 64 B)",
                    "calibration": {"sumsq_stage1 corrected read / known": round(cal_r, 3),
