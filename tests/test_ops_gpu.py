@@ -250,6 +250,32 @@ def test_pool_lrn_bwd_fused(ops, n, h, w, c, ph, dh):
         assert float(dx[:, :, :dh].abs().max()) == 0
 
 
+@pytest.mark.parametrize("n,h,w,c,ph", [(2, 9, 11, 7, 0), (3, 13, 13, 20, 1), (2, 57, 57, 96, 2), (2, 28, 28, 256, 1), (1, 31, 64, 5, 0)])
+def test_lrn_pool_fwd_fused(ops, n, h, w, c, ph):
+    """Fused kernel == lrn followed by max_pool_valid of the oracle (values and first-maximum arg-max), halo untouched."""
+    rng = np.random.default_rng(h * c + w)
+    x = np.maximum(rng.standard_normal((n, h, w, c)) * 30, 0).astype(np.float32)
+    l, _ = O.lrn(x)
+    y, arg = O.max_pool_valid(l)
+    oh, ow = y.shape[1], y.shape[2]
+    p = torch.full((n, c, oh + 2 * ph, ow + 2 * ph), 5.0, device=DEV)
+    ap = torch.full(p.shape, 77, dtype=torch.uint8, device=DEV)
+    ops.lrn_pool_fwd(dev(nchw(x)), p, ap, p_halo=ph)
+    close(nhwc(host(interior(p, ph))), y, rtol=1e-5, atol_rel=1e-6)
+    # arg-max: window-local index of the first maximum; where it differs from the fp64 oracle's, the two candidates must be a
+    # near-tie of the LRN output (the fused kernel rounds the LRN sums in a slightly different order than any other kernel)
+    got_arg = nhwc(host(interior(ap, ph))).astype(np.int64)
+    assert got_arg.min() >= 0 and got_arg.max() <= 8
+    oi, oj = np.meshgrid(np.arange(oh), np.arange(ow), indexing="ij")
+    def window_value(a):                                   # l at the window position a (NHWC)
+        ii, jj = 2 * oi[None, :, :, None] + a // 3, 2 * oj[None, :, :, None] + a % 3
+        return l[np.arange(n)[:, None, None, None], ii, jj, np.arange(c)[None, None, None, :]]
+    diff = np.abs(window_value(got_arg) - window_value(arg.astype(np.int64)))
+    assert (got_arg != arg).mean() < 1e-3 and diff.max() <= 1e-5 * np.abs(l).max()
+    if ph:
+        assert float((p[:, :, :ph] - 5.0).abs().max()) == 0 and int(ap[:, :, :, -ph:].min()) == 77
+
+
 def test_colsum(ops):
     rng = np.random.default_rng(0)
     a = rng.standard_normal((100, 300)).astype(np.float32)

@@ -30,6 +30,7 @@ SIGNATURES = {
     "vl_bias_grad_nchw": (i32, [p, p, p, i32, i32, i32, p]),
     "vl_lrn_fwd": (i32, [p, p, i32, i32, i32, i32, f32, f32, f32, p]),
     "vl_lrn_bwd": (i32, [p, p, p, i32, i32, i32, i32, f32, f32, f32, i32, i32, i32, p]),
+    "vl_lrn_pool_fwd": (i32, [p, p, p, i32, i32, i32, i32, i32, i32, f32, f32, f32, p]),
     "vl_pool_lrn_bwd": (i32, [p, p, p, p, i32, i32, i32, i32, i32, i32, f32, f32, f32, i32, i32, p]),
     "vl_maxpool_fwd": (i32, [p, p, p, i32, i32, i32, i32, i32, i32, i64, i64, i64, i64, p]),
     "vl_maxpool_bwd": (i32, [p, p, p, p, i32, i32, i32, i32, i32, i32, i64, i64, i64, i64, i32, p]),

@@ -506,6 +506,156 @@ extern "C" int vl_lrn_bwd(const float* x, const float* dy, float* dx, int n, int
     return 0;
 }
 
+// ---- fused forward of [LRN -> max_pool 3x3/2 VALID] (alexnet.py:79-98, 120-139) -------------------------------------
+// The LRN output is only ever the pool's input (the backward pass reads the LRN INPUT, vl_pool_lrn_bwd), so it is never
+// written to HBM: lrn1 + pool1 moved 2 x 1.28 + 1.28 + 0.39 GB per step through two kernels; fused it is 1.28 + 0.39 GB.
+// One workgroup = one image x a band of PRB pooled rows (= 2 PRB + 1 input rows); a thread owns PPT pixels of the band and
+// walks ALL channels with the 5-wide LRN window in registers (channel cc enters at iteration cc, LRN output cc - 2 leaves),
+// the next chunk's loads in flight behind the current chunk's math.  Each chunk of CHK LRN outputs goes to LDS (two buffers,
+// one barrier per chunk); the chunk's pooled outputs (<= NSL per thread, their window origins decoded once) take the
+// strict-> first maximum of 9 LDS reads, exactly vl_maxpool_fwd's scan order, and are stored in the pool-output halo layout.
+template <int CHK, int PPT, int NSL>
+__global__ __launch_bounds__(512) void lrn_pool_fwd_kernel(const float* __restrict__ x, float* __restrict__ pout,
+                                                           uint8_t* __restrict__ argout, int C, int H, int W, int OH, int OW, int prb,
+                                                           int pplane, int owp, int p_halo, float alpha, float bias) {
+    extern __shared__ __attribute__((aligned(16))) float lbuf[];      // [2][CHK][npix]
+    const int T = blockDim.x;
+    const int img = blockIdx.y;
+    const int oh_a = blockIdx.x * prb;
+    const int nprow = min(prb, OH - oh_a);                            // pooled rows of this band
+    const int npix = (2 * nprow + 1) * W;                             // input pixels of this band
+    const int p_base = 2 * oh_a * W;
+    const int HW = H * W;
+    const __amdgpu_buffer_rsrc_t rs_x = pw_rsrc(x + (int64_t)img * C * HW, (int64_t)C * HW * 4);
+    const __amdgpu_buffer_rsrc_t rs_p = pw_rsrc(pout + (int64_t)img * C * pplane, (int64_t)C * pplane * 4);
+    const __amdgpu_buffer_rsrc_t rs_a = pw_rsrc(argout + (int64_t)img * C * pplane, (int64_t)C * pplane);
+    uint32_t voff_x[PPT];
+    int lpix[PPT];                                                    // band-local pixel, -1 = none
+#pragma unroll
+    for (int q = 0; q < PPT; ++q) {
+        const int pix = threadIdx.x + q * T;
+        lpix[q] = pix < npix ? pix : -1;
+        voff_x[q] = pix < npix ? (uint32_t)(p_base + pix) * 4u : PW_OOB;
+    }
+    // pooled outputs of a chunk: o = tid + s T  <->  (slab ci, pooled row, pooled column)
+    int s_lds[NSL], s_out[NSL];                                       // LDS float offset of the window origin | ci << 24 | output element offset
+    const int per_slab = nprow * OW;
+#pragma unroll
+    for (int sl = 0; sl < NSL; ++sl) {
+        const int o = threadIdx.x + sl * T;
+        const int ci = o / per_slab, rem = o - ci * per_slab;
+        const int ohl = rem / OW, ow = rem - ohl * OW;
+        const bool ok = ci < CHK;
+        s_lds[sl] = ok ? ci * npix + 2 * ohl * W + 2 * ow : 0;
+        s_out[sl] = ok ? (ci << 24) | ((oh_a + ohl + p_halo) * owp + ow + p_halo) : -1;
+    }
+    const int x_cs = HW * 4;
+    float xa[PPT][CHK], xb[PPT][CHK];
+    auto x_load = [&](int c0, float (&v)[PPT][CHK]) {
+#pragma unroll
+        for (int i = 0; i < CHK; ++i) {
+            const int cc = c0 + i;                                    // uniform; channels past C: the range check answers 0
+#pragma unroll
+            for (int q = 0; q < PPT; ++q)
+                v[q][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, (int)(cc < C ? voff_x[q] : PW_OOB), cc * x_cs, 0));
+        }
+    };
+    float xw[PPT][5];
+#pragma unroll
+    for (int q = 0; q < PPT; ++q)
+#pragma unroll
+        for (int d = 0; d < 5; ++d) xw[q][d] = 0.f;
+
+    auto chunk = [&](int c0, int buf, const float (&xin)[PPT][CHK]) {
+        float* lb = lbuf + buf * CHK * npix;
+        // LRN outputs of channels c0 - 2 .. c0 + CHK - 3 -> slabs 0 .. CHK - 1
+#pragma unroll
+        for (int i = 0; i < CHK; ++i) {
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) {
+                xw[q][0] = xw[q][1]; xw[q][1] = xw[q][2]; xw[q][2] = xw[q][3]; xw[q][3] = xw[q][4]; xw[q][4] = xin[q][i];
+                float sq = 0.f;
+#pragma unroll
+                for (int d = 0; d < 5; ++d) sq += xw[q][d] * xw[q][d];
+                const float sc = bias + alpha * sq;
+                const float rq = __builtin_amdgcn_rsqf(sc);
+                const float l = xw[q][2] * (rq * __builtin_amdgcn_sqrtf(rq));   // x * sc^-0.75 (pow_neg's beta = 0.75 form)
+                if (lpix[q] >= 0) lb[i * npix + lpix[q]] = l;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int sl = 0; sl < NSL; ++sl) {
+            const int c = c0 - 2 + (s_out[sl] >> 24);
+            if (s_out[sl] >= 0 && c >= 0 && c < C) {
+                const float* wp = lb + s_lds[sl];
+                float best = -INFINITY;
+                int bi = 0;
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const float v = wp[i * W + j];
+                        if (v > best) {                               // strict: the first maximum in scan order wins
+                            best = v;
+                            bi = i * 3 + j;
+                        }
+                    }
+                const int off = c * pplane + (s_out[sl] & 0xffffff);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, best), rs_p, off * 4, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b8((uint8_t)bi, rs_a, off, 0, 0);
+            }
+        }
+    };
+    const int nchunks = (C + 2 + CHK - 1) / CHK;
+    x_load(0, xa);
+    for (int k = 0; k < nchunks; k += 2) {                            // unrolled by two: the x registers alternate without copies
+        x_load((k + 1) * CHK, xb);
+        chunk(k * CHK, 0, xa);
+        if (k + 1 >= nchunks) break;
+        x_load((k + 2) * CHK, xa);
+        chunk((k + 1) * CHK, 1, xb);
+    }
+}
+
+extern "C" int vl_lrn_pool_fwd(const float* x, float* p, uint8_t* argmax, int n, int c, int h, int w, int p_halo, int radius,
+                               float alpha, float beta, float bias, vl_stream_t stream) {
+    VL_CHECK(x && p && argmax && n > 0 && c > 0 && h >= 3 && w >= 3 && p_halo >= 0, "vl_lrn_pool_fwd: bad argument");
+    VL_CHECK(radius == 2 && beta == 0.75f, "vl_lrn_pool_fwd: only depth_radius 2, beta 0.75 are built (alexnet.py:81-84)");
+    VL_CHECK(n <= 65535, "vl_lrn_pool_fwd: batch %d exceeds the grid limit", n);
+    const int oh = (h - 3) / 2 + 1, ow = (w - 3) / 2 + 1;
+    const int owp = ow + 2 * p_halo;
+    const int64_t pplane = (int64_t)(oh + 2 * p_halo) * owp;
+    VL_CHECK((int64_t)(c + 16) * h * w * 4 < (1ll << 31) && (int64_t)c * pplane * 4 < (1ll << 31) && pplane < (1 << 24),
+             "vl_lrn_pool_fwd: image too large for 32-bit buffer offsets");
+    constexpr int CHK = 8, PPT = 3, NSL = 6;
+    // band = prb pooled rows: the largest that fits PPT pixels per thread of a <= 512-thread workgroup, NSL outputs per thread
+    // and 64 KB of LDS; then the smallest thread count (multiple of 64) that still covers it
+    int prb = 0, threads = 0;
+    for (int cand = oh; cand >= 1 && !prb; --cand) {
+        const int npix = (2 * cand + 1) * w;
+        const int need_px = ceil_div(npix, PPT), need_out = ceil_div((int64_t)CHK * cand * ow, NSL);
+        int t = ceil_div(need_px > need_out ? need_px : need_out, 64) * 64;
+        if (t <= 512 && (size_t)2 * CHK * npix * sizeof(float) <= 64 * 1024) {
+            prb = cand;
+            threads = t < 64 ? 64 : t;
+        }
+    }
+    VL_CHECK(prb > 0, "vl_lrn_pool_fwd: plane too wide (%d) for one band of pooled rows", w);
+    // balance the bands (e.g. 28 pooled rows, at most 5 per band -> 6 bands of 5,5,5,5,4,4 rather than 5,5,5,5,5,3)
+    const int bands = ceil_div(oh, prb);
+    prb = ceil_div(oh, bands);
+    {
+        const int need_px = ceil_div((2 * prb + 1) * w, PPT), need_out = ceil_div((int64_t)CHK * prb * ow, NSL);
+        threads = ceil_div(need_px > need_out ? need_px : need_out, 64) * 64;
+    }
+    const size_t lds = (size_t)2 * CHK * (2 * prb + 1) * w * sizeof(float);
+    hipLaunchKernelGGL((lrn_pool_fwd_kernel<CHK, PPT, NSL>), dim3(bands, n), dim3(threads), lds, (hipStream_t)stream, x, p, argmax, c, h,
+                       w, oh, ow, prb, (int)pplane, owp, p_halo, alpha, bias);
+    VL_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---- max-pool VALID (alexnet.py:91-98) --------------------------------------------------------
 // Index decode uses 32-bit magic-number division (total element counts are < 2^31, checked on the host);
 // K, S > 0 are compile-time for the 3x3/2 case the reference uses, 0 = runtime k, s.

@@ -184,9 +184,6 @@ class LRCNEngine:
                 L["dy"] = zbuf(N, co, conv.oh, conv.ow, L["dy_halo"])
             out, out_halo = L["y"], L["y_halo"]
             h, w, c = conv.oh, conv.ow, co
-            if lrn:
-                L["l"] = buf(N, c, h, w)
-                out, out_halo = L["l"], 0
             if pool:
                 ph, pw = ops.pool_out(h), ops.pool_out(w)
                 L["hwc"] = name == "conv5"       # pool5 writes the (h, w, c)-flat order fc6 reads (alexnet.py:228)
@@ -342,10 +339,11 @@ class LRCNEngine:
             name = L["name"]
             self._run(name + ".fwd", L["conv"].fwd, x, P["dcnn/%sW" % name], P["dcnn/%sb" % name], L["y"][:n], relu=True)
             x = L["y"][:n]
-            if L["lrn"]:
-                ops.lrn_fwd(x, L["l"][:n], **LRN)
-                x = L["l"][:n]
-            if L["pool"]:
+            if L["lrn"] and L["pool"]:
+                # LRN + pool in one pass: the LRN output is only ever the pool's input and is never stored
+                ops.lrn_pool_fwd(x, L["p"][:n], L["arg"][:n], p_halo=L["p_halo"], **LRN)
+                x = L["p"][:n]
+            elif L["pool"]:
                 ops.maxpool_fwd(x, L["p"][:n], L["arg"][:n], hwc=L["hwc"], y_halo=L["p_halo"])
                 x = L["p"][:n]
         ops.gemm(x, P["dcnn/fc6W"], self.f6, n, FC_DIM, self.flat_dim, bias=P["dcnn/fc6b"], relu=True, ws=self.ws)

@@ -193,6 +193,16 @@ def maxpool_bwd(dy, argmax, dx, relu_mask=None, k=3, s=2, hwc=False, dy_halo=0, 
               dx_halo, stream())
 
 
+def lrn_pool_fwd(x, p, argmax, p_halo=0, radius=2, alpha=2e-5, beta=0.75, bias=1.0):
+    """Fused LRN + maxpool(3,2) forward; p / argmax have the pool-output layout (p_halo); the LRN output is not stored."""
+    _f32(x, p); _dense(x, p, argmax)
+    n, c, h, w = x.shape
+    want = (n, c, pool_out(h) + 2 * p_halo, pool_out(w) + 2 * p_halo)
+    if tuple(p.shape) != want or tuple(argmax.shape) != want:
+        raise _ffi.VltfError("lrn_pool_fwd: shape mismatch x=%s p=%s argmax=%s" % (tuple(x.shape), tuple(p.shape), tuple(argmax.shape)))
+    _ffi.call("vl_lrn_pool_fwd", _p(x), _p(p), _p(argmax), n, c, h, w, p_halo, radius, alpha, beta, bias, stream())
+
+
 def pool_lrn_bwd(x, dp, argmax, dx, p_halo=0, dx_halo=0, radius=2, alpha=2e-5, beta=0.75, bias=1.0, relu_fused=True):
     """Fused maxpool(3,2) backward + LRN backward (+ReluGrad); dp/argmax have the pool-output layout (p_halo)."""
     _f32(x, dp, dx); _dense(x, dp, argmax, dx)
