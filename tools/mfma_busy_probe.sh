@@ -1,5 +1,7 @@
+# Effective clock (GRBM_GUI_ACTIVE / 8 / duration) and matrix-pipe utilisation (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / cycles)
+# of single conv kernels at the benchmark size.  Run on the GPU box from the repo root: bash tools/mfma_busy_probe.sh
 set -eo pipefail
-out=gpurun_out/w7
+out=gpurun_out/mfma_busy
 mkdir -p $out
 export TMPDIR=/tmp
 for k in "conv3 fwd" "conv3 wgrad" "conv2 dgrad" "conv2 wgrad"; do
@@ -8,7 +10,7 @@ for k in "conv3 fwd" "conv3 wgrad" "conv2 dgrad" "conv2 wgrad"; do
 done
 python3 - <<'P'
 import sqlite3,glob
-for d in sorted(glob.glob('gpurun_out/w7/*/')):
+for d in sorted(glob.glob('gpurun_out/mfma_busy/*/')):
     c=sqlite3.connect(glob.glob(d+'*_results.db')[0])
     q="select kernel_name, counter_name, avg(value), avg(duration), count(*) from counters_collection where (kernel_name like '%mfma_contract%' or kernel_name like '%wgrad%') group by kernel_name, counter_name"
     res={}
