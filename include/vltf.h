@@ -43,12 +43,13 @@ int vl_device_count(void);
  * must have been zeroed once: it is conv1's SAME padding, see vl_conv_set_halo).  crop_y/crop_x: int32[n] top-left crop offsets
  * (center: floor((raw-want)/2), dataset_.py:572-573); mirror: uint8[n] flips the W axis
  * (dataset_.py:497-499); mean_bgr: float[3] subtracted per channel (dataset_.py:521-530), may be NULL.
- * crop_y, crop_x, mirror may be NULL (= 0). */
+ * crop_y, crop_x, mirror may be NULL (= 0).  dst_phase = 1, or the consuming conv's vl_conv_x_phase(): dst is then the
+ * column-phase-split layout [n][3][phase][out_h + 2*dst_halo][ceil((out_w + 2*dst_halo) / phase)]. */
 int vl_input_prep_u8(const uint8_t* src, float* dst, int n, int raw_h, int raw_w, int out_h, int out_w,
                      const int32_t* crop_y, const int32_t* crop_x, const uint8_t* mirror,
-                     const float* mean_bgr, int dst_halo, vl_stream_t stream);
-/* The reference's own feed format: fp32 NHWC placeholder (models/model.py:54) -> NCHW (+halo). */
-int vl_nhwc_to_nchw(const float* src, float* dst, int n, int h, int w, int c, int dst_halo, vl_stream_t stream);
+                     const float* mean_bgr, int dst_halo, int dst_phase, vl_stream_t stream);
+/* The reference's own feed format: fp32 NHWC placeholder (models/model.py:54) -> NCHW (+halo, dst_phase as above). */
+int vl_nhwc_to_nchw(const float* src, float* dst, int n, int h, int w, int c, int dst_halo, int dst_phase, vl_stream_t stream);
 int vl_nchw_to_nhwc(const float* src, float* dst, int n, int c, int h, int w, vl_stream_t stream);
 
 /* ---- convolution: dcnn.conv (alexnet.py:15-31) = tf.nn.conv2d 'SAME' per group + bias_add ------
@@ -66,6 +67,13 @@ int vl_conv_out_hw(const vl_conv_desc* d, int* oh, int* ow);
  *   dx_halo: layout of dx written by vl_conv_dgrad
  * Default 0 everywhere (dense NCHW; bounds-tested gather).  Rebuilds the index tables (setup time only). */
 int vl_conv_set_halo(vl_conv_desc* d, int x_halo, int y_halo, int dy_halo, int dx_halo);
+/* Column-phase-split x for a strided conv in the padded layout (conv1, stride 4): x is stored
+ * [n][c][phase = stride][H + 2p][ceil((W + 2p) / stride)], physical column iw at [iw % stride][iw / stride].  The taps of
+ * consecutive output columns are then CONSECUTIVE addresses (a 64-lane gather touches 2 cache lines instead of 8), for
+ * vl_conv_fwd and vl_conv_wgrad alike.  on = 0 restores plain [n][c][H + 2p][W + 2p].  Call after vl_conv_set_halo; no-op
+ * for stride 1.  vl_conv_x_phase returns the phase count in force (1 = plain). */
+int vl_conv_set_x_phase_split(vl_conv_desc* d, int on);
+int vl_conv_x_phase(const vl_conv_desc* d);
 /* y[n][cout][oh][ow] = conv(x[n][cin][h][w], w_hwio) + bias, optional fused ReLU (alexnet.py:77). */
 int vl_conv_fwd(const vl_conv_desc* d, const float* x, const float* w_hwio, const float* bias, float* y,
                 int n, int relu, vl_stream_t stream);

@@ -152,6 +152,24 @@ def test_conv_fwd_bwd(ops, padded, n, h, w, cin, cout, k, s, g):
     else:
         with pytest.raises(Exception):
             conv.wgrad(xd, dyd, dw, ws, db=db)
+    if padded and s > 1:
+        # the same conv with x stored column-phase-split (what the engine feeds conv1): identical results
+        ph = conv.set_x_phase_split(True)
+        assert ph == s
+        xp = pad_nchw(nchw(x), xh)
+        wq = -(-xp.shape[3] // ph)
+        xp = np.pad(xp, ((0, 0), (0, 0), (0, 0), (0, wq * ph - xp.shape[3])))
+        xps = dev(np.ascontiguousarray(xp.reshape(n, cin, xp.shape[2], wq, ph).transpose(0, 1, 4, 2, 3)).reshape(n, cin * ph, xp.shape[2], wq))
+        assert tuple(xps.shape) == conv.x_shape(n)
+        y2 = torch.zeros_like(y)
+        conv.fwd(xps, wd, bd, y2, relu=True)
+        assert torch.equal(y2, y)
+        dw2, db3 = torch.empty_like(wd), torch.empty(cout, device=DEV)
+        conv.wgrad(xps, dyd, dw2, ws, db=db3 if conv.fuses_bias() else None)
+        close(host(dw2), dwo, msg="conv wgrad (phase-split x)")
+        with pytest.raises(Exception):
+            conv.fwd(xd, wd, bd, y2, relu=True)                      # the plain layout no longer matches the descriptor
+        conv.set_x_phase_split(False)
     if s == 1:
         wtt = torch.empty(wd.numel(), device=DEV)
         conv.wt_transpose(wd, wtt)
@@ -295,6 +313,15 @@ def test_input_prep(ops):
     mean = np.array([99.197148, 105.293620, 109.503945], np.float32)
     dst = torch.empty((n, 3, oh, ow), device=DEV)
     ops.input_prep_u8(dev(src, torch.uint8), dst, dev(cy, torch.int32), dev(cx, torch.int32), dev(mir, torch.uint8), dev(mean))
+    # halo 4 + column-phase-split destination (conv1's input layout): same values at [c][iw % 4][ih][iw // 4]
+    halo, ph = 4, 4
+    shp = ops.phase_split_shape(n, 3, oh, ow, halo, ph)
+    dps = torch.zeros(shp, device=DEV)
+    ops.input_prep_u8(dev(src, torch.uint8), dps, dev(cy, torch.int32), dev(cx, torch.int32), dev(mir, torch.uint8), dev(mean),
+                      halo=halo, phase=ph, out_hw=(oh, ow))
+    back = host(dps).reshape(n, 3, ph, oh + 2 * halo, shp[3]).transpose(0, 1, 3, 4, 2).reshape(n, 3, oh + 2 * halo, shp[3] * ph)
+    assert np.array_equal(back[:, :, halo:halo + oh, halo:halo + ow], host(dst))
+    assert np.all(back[:, :, :halo] == 0) and np.all(back[:, :, :, :halo] == 0) and np.all(back[:, :, :, halo + ow:] == 0)
     want = np.stack([O.process_image(src[i], (oh, ow, 3), (cy[i], cx[i]), mean, bool(mir[i])) for i in range(n)])
     np.testing.assert_array_equal(nhwc(host(dst)), want)          # bit exact: u8 -> f32 minus f32
     ops.input_prep_u8(dev(src, torch.uint8)[:, :oh, :ow].contiguous(), dst)

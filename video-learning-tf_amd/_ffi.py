@@ -14,13 +14,15 @@ SIGNATURES = {
     "vl_last_error": (C.c_char_p, []),
     "vl_version": (i32, []),
     "vl_device_count": (i32, []),
-    "vl_input_prep_u8": (i32, [p, p, i32, i32, i32, i32, i32, p, p, p, p, i32, p]),
-    "vl_nhwc_to_nchw": (i32, [p, p, i32, i32, i32, i32, i32, p]),
+    "vl_input_prep_u8": (i32, [p, p, i32, i32, i32, i32, i32, p, p, p, p, i32, i32, p]),
+    "vl_nhwc_to_nchw": (i32, [p, p, i32, i32, i32, i32, i32, i32, p]),
     "vl_nchw_to_nhwc": (i32, [p, p, i32, i32, i32, i32, p]),
     "vl_conv_create": (i32, [C.POINTER(p), i32, i32, i32, i32, i32, i32, i32, i32]),
     "vl_conv_destroy": (None, [p]),
     "vl_conv_out_hw": (i32, [p, C.POINTER(i32), C.POINTER(i32)]),
     "vl_conv_set_halo": (i32, [p, i32, i32, i32, i32]),
+    "vl_conv_set_x_phase_split": (i32, [p, i32]),
+    "vl_conv_x_phase": (i32, [p]),
     "vl_conv_fwd": (i32, [p, p, p, p, p, i32, i32, p]),
     "vl_conv_wt_transpose": (i32, [p, p, p, p]),
     "vl_conv_dgrad": (i32, [p, p, p, p, p, i32, p]),

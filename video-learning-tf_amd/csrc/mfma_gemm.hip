@@ -42,6 +42,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef const __attribute__((address_space(4))) int* const_int_ptr;
 __device__ __forceinline__ const_int_ptr as_const(const int* p) { return (const_int_ptr)(uintptr_t)p; }
 static constexpr int NT = 256;  // threads per workgroup
+static constexpr int KBLK = 16;  // channel block of the conv reduction order (build_ktabs) = the reduction tile of launch_conv
 
 // Byte offset that fails the buffer range check of every resource we build (num_records < 0xE0000000);
 // adding any per-element offset < 2^28 to it still fails and does not wrap.
@@ -220,6 +221,8 @@ struct ConvGeom {
     int M;               // n * OH * OW output pixels
     int H, W;            // logical input plane
     int halo, Wp;        // physical row pitch
+    int col_mul, col_add; // padded mode: physical column of output column ow, tap 0 = ow * col_mul + col_add
+                         // (stride, halo - pad_left; or 1, 0 when x is stored column-phase-split, see vl_conv_set_x_phase_split)
     int stride, pt, pl;
     int OHW, OW;
     FastDiv dOHW, dOW;
@@ -260,7 +263,8 @@ struct ConvGather {
         // checked mode may point up to (pt, pl) before the plane origin: bias the base so offsets stay >= 0
         const int bias = PADDED ? 0 : P.pt * P.Wp + P.pl;
         rsrc = make_rsrc(P.x + (int64_t)zg * P.grp_stride - bias, (P.total - (int64_t)zg * P.grp_stride + bias) * 4);
-        const int64_t o = (int64_t)n * P.img_stride + (int64_t)(ih0 + P.halo) * P.Wp + (iw0 + P.halo) + bias;
+        const int colp = PADDED ? (int)ow * P.col_mul + P.col_add : iw0 + P.halo;
+        const int64_t o = (int64_t)n * P.img_stride + (int64_t)(ih0 + P.halo) * P.Wp + colp + bias;
         voff = vm ? (uint32_t)o * 4u : OOB_OFF;
         if (!vm) ih0 = 1 << 28;   // checked mode: every row test fails
         const int row0 = __builtin_amdgcn_readfirstlane((int)threadIdx.x / BX) * NLD;
@@ -714,7 +718,7 @@ __global__ __launch_bounds__(NT, 1) void wgrad_dma_kernel(const ConvGeom g, cons
         const uint32_t p = mm - n * g.OHW;
         const uint32_t oh = fd_div(p, g.dOW);
         const uint32_t ow = p - oh * g.OW;
-        const int ih0 = (int)oh * g.stride - g.pt + g.halo, iw0 = (int)ow * g.stride - g.pl + g.halo;
+        const int ih0 = (int)oh * g.stride - g.pt + g.halo, iw0 = (int)ow * g.col_mul + g.col_add;
         const uint32_t vx = (uint32_t)((int64_t)n * g.img_stride + (int64_t)ih0 * g.Wp + iw0) * 4u;
         const uint32_t vd = (uint32_t)((int64_t)n * dy_img + (int64_t)(oh + d.halo) * d.OWp + ow + d.halo) * 4u;
         voff_x = vm ? vx : OOB_OFF;                       // pixels past M: range check fails, the DMA writes 0
@@ -859,6 +863,199 @@ __global__ __launch_bounds__(NT, 1) void wgrad_dma_kernel(const ConvGeom g, cons
     }
 }
 
+// ---- conv forward / dgrad, LDS-DMA form (padded layout, 128 x 128 tiles) -----------------------------------------
+// The same pipeline as wgrad_dma_kernel applied to y[co][pixel] = sum_r W[r][co] * im2col[r][pixel]: one workgroup per
+// CU, 64-deep reduction stages (= four 16-row blocks of the permuted order), two LDS buffers of 64 KB, operand rows
+// fetched global -> LDS by `buffer_load_dword ... lds`, one fetch in the shadow of each MFMA of a stage's first half,
+// vmcnt(0) + one barrier per stage (128 MFMAs per wave) instead of one per 16-row tile (32 MFMAs).
+// Both operands land in LDS as [r][x] rows (the DMA writes a wave's 64 lanes to consecutive dwords): a weight row is 64
+// consecutive output channels, an im2col row is the tile's 64 consecutive pixels of one (tap, channel).  A wave's two
+// 32-wide MFMA tiles along x are the EVEN and the ODD elements of its 64-wide block, so lane l reads the adjacent pair
+// x = 2 (l & 31), +1 with one ds_read_b64 -- half the LDS instructions of two b32 reads, conflict free (the two lane
+// halves read different rows r).  Accumulator (a, b, q) of lane l is therefore y[co = 64 wm + 2 i + a][pixel = 64 wn + 2 j + b]
+// with i = (q&3) + 8 (q>>2) + 4 (l>>5), j = l & 31.
+struct ConvDmaParams {
+    const float* w;          // [K][w_ld] weights (HWIO forward, flipped/transposed for dgrad)
+    int64_t w_ld;
+    int64_t w_grp_stride;    // elements between groups (column block)
+    int64_t w_bytes;         // bytes from w to the end of the weight tensor
+    const int* row_tab;      // first weight row of every 16-row block of the reduction order
+    int nblk;                // ceil(K / 16) blocks
+};
+
+template <int SR>   // reduction rows per stage: 64 (one workgroup per CU) or 32 (two: one's epilogue under the other's MFMAs)
+__global__ __launch_bounds__(NT, 64 / SR) void conv_dma_kernel(const ConvDmaParams pa, const ConvGeom g, const EpiConvNCHW::Params pe,
+                                                               int tiles_i) {
+    constexpr int BM = 128, BN = 128;
+    constexpr int ABUF = SR * BM, BUF = SR * (BM + BN);               // floats: A tile, whole buffer
+    constexpr int RW = SR / 4;                                        // rows of a stage each wave fetches (within ONE 16-row block)
+    constexpr int NF = RW * 4;                                        // row fetches per wave per stage: RW rows x (2 A + 2 B halves)
+    constexpr int NT2 = SR / 4;                                       // t-steps (two MFMA steps = four reduction rows each)
+    constexpr int FPM = 1;                                            // fetches per MFMA shadow (2 measured equal: latency is not the limit)
+    static_assert(SR == 64 || SR == 32, "stage depth");
+    extern __shared__ __attribute__((aligned(16))) float ldsc[];
+    const int bid = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int ti_blk = bid % tiles_i, tj_blk = bid / tiles_i;
+    const int zg = blockIdx.y;
+    const int i0 = ti_blk * BM, j0 = tj_blk * BN;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // ---- per-lane source offsets, fixed for the workgroup: weight column (co) and im2col pixel of each 64-wide half
+    const i32x4 rs_w = rsrc_words(pa.w + (int64_t)zg * pa.w_grp_stride, pa.w_bytes - (int64_t)zg * pa.w_grp_stride * 4);
+    const i32x4 rs_x = rsrc_words(g.x + (int64_t)zg * g.grp_stride, (g.total - (int64_t)zg * g.grp_stride) * 4);
+    uint32_t voff_a[2], voff_b[2];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+        const int co = i0 + hf * 64 + lane;
+        voff_a[hf] = co < pe.Cog ? (uint32_t)co * 4u : OOB_OFF;
+        const int m = j0 + hf * 64 + lane;
+        const bool vm = m < g.M;
+        const uint32_t mm = vm ? m : 0;
+        const uint32_t n = fd_div(mm, g.dOHW);
+        const uint32_t p = mm - n * g.OHW;
+        const uint32_t oh = fd_div(p, g.dOW);
+        const uint32_t ow = p - oh * g.OW;
+        const int ih0 = (int)oh * g.stride - g.pt + g.halo, iw0 = (int)ow * g.col_mul + g.col_add;
+        voff_b[hf] = vm ? (uint32_t)((int64_t)n * g.img_stride + (int64_t)ih0 * g.Wp + iw0) * 4u : OOB_OFF;
+    }
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)ldsc;
+    const int ld_bytes = (int)(pa.w_ld * 4);
+
+    // this wave fetches the stage's block `wave` (16 rows): their im2col offsets sit in SGPRs (see wgrad_dma_kernel)
+    int tabv[RW];
+    int row0 = 0;
+    bool blk_ok = false;
+    const int wrow = wave * RW;                                       // first stage row of this wave
+    auto load_table = [&](int st) {
+        const int k0 = st * SR + wrow;                                // position in the reduction order
+        const const_int_ptr tt = as_const(g.ktab) + k0 + st * g.zero;
+#pragma unroll
+        for (int f = 0; f < RW; ++f) tabv[f] = tt[f];
+        row0 = as_const(pa.row_tab)[k0 / KBLK + st * g.zero] + k0 % KBLK;
+        blk_ok = k0 / KBLK < pa.nblk;                                 // blocks past K: both operands fetch zeros
+    };
+    auto pin_table = [&]() {
+#pragma unroll
+        for (int f = 0; f < RW; ++f) asm volatile("" : "+s"(tabv[f]));
+        asm volatile("" : "+s"(row0));
+    };
+    // fetch f (0..63) of a stage into buffer nb: row rr = f >> 2 of the wave's block; f & 3 = {A half 0, A half 1, B half 0, B half 1}
+    auto dma = [&](const int nb, const int f, int st) {
+        const int rr = f >> 2, kind = f & 3, hf = kind & 1;
+        const int z = st * g.zero;
+        const uint32_t row_lds = lds0 + (uint32_t)(nb * BUF + (wrow + rr) * 128 + hf * 64 + z) * 4u;
+        if (kind < 2) lds_dma_row(rs_w, row_lds, blk_ok ? voff_a[hf] : OOB_OFF, (row0 + rr) * ld_bytes);
+        else lds_dma_row(rs_x, row_lds + ABUF * 4u, blk_ok ? voff_b[hf] : OOB_OFF, tabv[rr]);
+    };
+    auto finish_stage = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
+
+    const int nstages = (pa.nblk * KBLK + SR - 1) / SR;
+    load_table(0);
+    pin_table();
+#pragma unroll
+    for (int f = 0; f < NF; ++f) dma(0, f, 0);
+    load_table(1);
+    pin_table();
+    finish_stage();
+
+    // lane half h = lane >> 5 consumes row 2 s + h at MFMA step s
+    const float* fa = ldsc + (lane >> 5) * 128 + wm * 64 + 2 * (lane & 31);
+    const float* fb = ldsc + ABUF + (lane >> 5) * 128 + wn * 64 + 2 * (lane & 31);
+
+    auto stage = [&](const int cur, int st_next) {                    // MFMAs on buffer cur while stage st_next streams into the other
+        float2 af[2], bf[2], an[2], bn[2];
+        af[0] = *reinterpret_cast<const float2*>(fa + cur * BUF);
+        bf[0] = *reinterpret_cast<const float2*>(fb + cur * BUF);
+        af[1] = *reinterpret_cast<const float2*>(fa + cur * BUF + 256);
+        bf[1] = *reinterpret_cast<const float2*>(fb + cur * BUF + 256);
+#pragma unroll
+        for (int t = 0; t < NT2; ++t) {                               // t = two MFMA steps = four reduction rows
+            if (t + 1 < NT2) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    an[u] = *reinterpret_cast<const float2*>(fa + cur * BUF + (2 * (t + 1) + u) * 256);
+                    bn[u] = *reinterpret_cast<const float2*>(fb + cur * BUF + (2 * (t + 1) + u) * 256);
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const int u = m >> 2, a = (m >> 1) & 1, b = m & 1;
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a ? af[u].y : af[u].x, b ? bf[u].y : bf[u].x, acc[a][b], 0, 0, 0);
+                const int f = (t * 8 + m) * FPM;                     // FPM fetches in the shadow of each of the first NF / FPM MFMAs
+                if (f < NF) {
+#pragma unroll
+                    for (int e = 0; e < FPM; ++e) dma(cur ^ 1, f + e, st_next);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            // the table of the stage after next: read once this stage's fetches (t < NF / 8) no longer need the current one
+            static_assert(NF / FPM / 8 <= NT2 - 4, "fetches must end before the table is replaced");
+            if (t == NT2 - 4) {
+                load_table(st_next + 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (t == NT2 - 2) {
+                pin_table();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                af[u] = an[u];
+                bf[u] = bn[u];
+            }
+        }
+        finish_stage();
+    };
+    int st = 0;
+    for (; st + 1 < nstages; st += 2) {
+        stage(0, st + 1);
+        stage(1, st + 2);
+    }
+    if (nstages & 1) stage(0, st + 1);
+
+    // ---- epilogue: NCHW (+ halo), bias, ReLU, ReluGrad mask
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int m = j0 + wn * 64 + 2 * (lane & 31) + b;
+        if (m >= pe.M) continue;
+        const uint32_t n = fd_div((uint32_t)m, pe.dOHW);
+        const uint32_t p = m - n * pe.OHW;
+        const uint32_t oh = fd_div(p, pe.dOW);
+        const uint32_t ow = p - oh * pe.OW;
+        const int64_t c0 = (int64_t)n * pe.Cout_total + (int64_t)zg * pe.Cog;
+        const int64_t ybase = c0 * pe.y_plane + (int64_t)(oh + pe.y_halo) * pe.y_wp + ow + pe.y_halo;
+        const int64_t mbase = c0 * pe.m_plane + (int64_t)(oh + pe.m_halo) * pe.m_wp + ow + pe.m_halo;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int i = (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+                const int co = i0 + wm * 64 + 2 * i + a;
+                if (co < pe.Cog) {
+                    float v = acc[a][b][q];
+                    if (pe.bias) v += pe.bias[zg * pe.Cog + co];
+                    if (pe.relu) v = fmaxf(v, 0.f);
+                    if (pe.mask) v = pe.mask[mbase + (int64_t)co * pe.m_plane] > 0.f ? v : 0.f;
+                    pe.y[ybase + (int64_t)co * pe.y_plane] = v;
+                }
+            }
+        }
+    }
+}
+
 // out[e] = sum_s slab[s][e] (+bias[e % n_cols]) (relu) (mask) : deterministic split reduction.
 __global__ void reduce_slabs_kernel(const float* __restrict__ ws, float* __restrict__ out, int64_t count, int splits,
                                     int64_t slab_stride, const float* __restrict__ bias, int ncols, int64_t ldc,
@@ -887,6 +1084,7 @@ struct vl_conv_desc {
     int K;    // kh*kw*cig
     int Kd;   // kh*kw*cog (dgrad reduction length)
     int x_halo, y_halo, dy_halo, dx_halo;
+    int x_phase;      // 1, or = stride: x is stored column-phase-split (vl_conv_set_x_phase_split)
     int2* ktab2_fwd;  // natural order, checked mode: {byte offset, kh << 16 | kw} (device), halo-aware
     int* ktab_fwd;    // natural order, padded mode: byte offset
     // forward / dgrad run their reduction in the permuted order (build_ktabs): gather tables in that order + first weight
@@ -917,7 +1115,6 @@ static void tf_same_pad(int in, int k, int s, int* out, int* before, int* after)
 //              In natural order a tile sweeps ALL cg channels before the next tap returns to them; with 128 workgroups
 //              per XCD that is a 7-19 MB working set against a 4 MB L2 (measured: conv2 dgrad fetched 19 GB per launch,
 //              18x its input, at 4 TB/s -- HBM-bound).  Each 16-row tile is still 16 CONSECUTIVE weight rows.
-static constexpr int KBLK = 16;   // = the reduction tile of launch_conv
 
 static void k_to_row(int k, int kh, int kw, int cg, bool permuted, int* ky, int* kx, int* c) {
     if (permuted) {
@@ -949,10 +1146,14 @@ static int upload(T** dev, const T* host, size_t count) {
 //   dev1[k] = byte offset of tap k                        (padded mode)
 //   dev2[k] = {byte offset, ky << 16 | kx}                (checked mode)
 //   rowtab[t] = first HWIO weight row of reduction tile t (16 consecutive rows), when rowtab != null
-static int build_ktabs(int** dev1, int2** dev2, int** rowtab, int kh, int kw, int cg, int H, int W, int halo, bool permuted) {
+//   phase > 1 (padded mode only): the tensor is stored column-phase-split, [c][phase][H + 2 halo][ceil((W + 2 halo) / phase)]
+//   with physical column iw at [iw % phase][iw / phase]; tap kx of output column ow is physical column ow * phase + kx +
+//   col_shift, so its phase and its offset within the phase plane depend on the tap only -> still "table entry + pixel".
+static int build_ktabs(int** dev1, int2** dev2, int** rowtab, int kh, int kw, int cg, int H, int W, int halo, bool permuted,
+                       int phase = 1, int col_shift = 0) {
     const int K = kh * kw * cg;
     const int pad = ((K + 127) / 128) * 128 + 256;
-    const int Wp = W + 2 * halo;
+    const int Wp = phase > 1 ? (W + 2 * halo + phase - 1) / phase : W + 2 * halo;
     const int64_t Pp = (int64_t)(H + 2 * halo) * Wp;
     const int ntiles = pad / KBLK;
     int* h1 = (int*)malloc(sizeof(int) * pad);
@@ -968,7 +1169,8 @@ static int build_ktabs(int** dev1, int2** dev2, int** rowtab, int kh, int kw, in
         if (k < K) {
             int ky, kx, c;
             k_to_row(k, kh, kw, cg, permuted, &ky, &kx, &c);
-            const int64_t off = ((int64_t)c * Pp + (int64_t)ky * Wp + kx) * 4;
+            int64_t off = ((int64_t)c * Pp + (int64_t)ky * Wp + kx) * 4;
+            if (phase > 1) off = (((int64_t)c * phase + (kx + col_shift) % phase) * Pp + (int64_t)ky * Wp + (kx + col_shift) / phase) * 4;
             h1[k] = (int)off;
             h2[k].x = (int)off;
             h2[k].y = (ky << 16) | kx;
@@ -990,10 +1192,13 @@ static int build_ktabs(int** dev1, int2** dev2, int** rowtab, int kh, int kw, in
 }
 
 static int rebuild_tables(vl_conv_desc* d) {
-    int rc = build_ktabs(&d->ktab_fwd, &d->ktab2_fwd, nullptr, d->kh, d->kw, d->cig, d->h, d->w, d->x_halo, false);
-    if (rc == 0)
-        rc = build_ktabs(&d->ptab_fwd, &d->ptab2_fwd, &d->rowtab_fwd, d->kh, d->kw, d->cig, d->h, d->w, d->x_halo, d->cig % KBLK == 0);
     d->fwd_padded = d->x_halo >= d->pt && d->x_halo >= d->pb && d->x_halo >= d->pl && d->x_halo >= d->pr;
+    if (!d->fwd_padded) d->x_phase = 1;   // the phase-split layout exists in the padded layout only
+    const int ph = d->x_phase > 1 ? d->x_phase : 1, shift = d->x_halo - d->pl;
+    int rc = build_ktabs(&d->ktab_fwd, &d->ktab2_fwd, nullptr, d->kh, d->kw, d->cig, d->h, d->w, d->x_halo, false, ph, shift);
+    if (rc == 0)
+        rc = build_ktabs(&d->ptab_fwd, &d->ptab2_fwd, &d->rowtab_fwd, d->kh, d->kw, d->cig, d->h, d->w, d->x_halo, d->cig % KBLK == 0, ph,
+                         shift);
     if (rc == 0 && d->stride == 1) {
         rc = build_ktabs(&d->ptab_bwd, &d->ptab2_bwd, &d->rowtab_bwd, d->kh, d->kw, d->cog, d->oh, d->ow, d->dy_halo, d->cog % KBLK == 0);
         // dgrad pads dy by K-1-pad before and by the forward pad-before after
@@ -1035,6 +1240,16 @@ extern "C" int vl_conv_set_halo(vl_conv_desc* d, int x_halo, int y_halo, int dy_
     VL_CHECK(rebuild_tables(d) == 0, "vl_conv_set_halo: device table allocation failed");
     return 0;
 }
+
+extern "C" int vl_conv_set_x_phase_split(vl_conv_desc* d, int on) {
+    VL_CHECK(d, "vl_conv_set_x_phase_split: null descriptor");
+    VL_CHECK(!on || d->fwd_padded, "vl_conv_set_x_phase_split: needs the padded x layout (set the halo first)");
+    d->x_phase = (on && d->stride > 1) ? d->stride : 1;
+    VL_CHECK(rebuild_tables(d) == 0, "vl_conv_set_x_phase_split: device table allocation failed");
+    return 0;
+}
+
+extern "C" int vl_conv_x_phase(const vl_conv_desc* d) { return d && d->x_phase > 1 ? d->x_phase : 1; }
 
 extern "C" void vl_conv_destroy(vl_conv_desc* d) {
     if (!d) return;
@@ -1087,25 +1302,56 @@ static int launch_conv(const ConvGeom& g, const float* w, int64_t w_ld, int w_gr
     return 0;
 }
 
+static int launch_conv_dma(const ConvGeom& g, const float* w, int64_t w_ld, int w_grp_stride, const int* row_tab, int Cog,
+                           int Cout_total, const ConvOut& o, hipStream_t s) {
+    constexpr int BM = 128, BN = 128, SR = 32;
+    constexpr size_t lds = (size_t)2 * SR * (BM + BN) * sizeof(float);   // 64 KB: two workgroups per CU
+    ConvDmaParams pa{w, w_ld, (int64_t)w_grp_stride, (int64_t)g.K * w_ld * 4, row_tab, ceil_div(g.K, KBLK)};
+    EpiConvNCHW::Params pe;
+    pe.y = o.y; pe.bias = o.bias; pe.mask = o.mask; pe.relu = o.relu;
+    pe.Cog = Cog; pe.Cout_total = Cout_total; pe.OHW = g.OHW; pe.OW = g.OW; pe.M = g.M;
+    pe.dOHW = g.dOHW; pe.dOW = g.dOW;
+    pe.y_halo = o.y_halo; pe.y_wp = o.OW + 2 * o.y_halo; pe.y_plane = (int64_t)(o.OH + 2 * o.y_halo) * pe.y_wp;
+    pe.m_halo = o.m_halo; pe.m_wp = o.OW + 2 * o.m_halo; pe.m_plane = (int64_t)(o.OH + 2 * o.m_halo) * pe.m_wp;
+    static bool attr_set = false;
+    if (!attr_set) {
+        VL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dma_kernel<SR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const int tiles_i = ceil_div(Cog, BM), tiles_j = ceil_div(g.M, BN);
+    dim3 grid(tiles_i * tiles_j, (unsigned)(Cout_total / Cog), 1);
+    hipLaunchKernelGGL(conv_dma_kernel<SR>, grid, dim3(NT), lds, s, pa, g, pe, tiles_i);
+    VL_LAUNCH_CHECK();
+    return 0;
+}
+
 template <bool PADDED>
 static int dispatch_conv(const ConvGeom& g, const float* w, int64_t w_ld, int w_grp_stride, const int* row_tab, int Cog,
                          int Cout_total, const ConvOut& o, hipStream_t s) {
     // output-channel tile: 128 when it divides well, else 96 (conv1: 96, conv4: 192) or 64 (conv2 dgrad: 48)
     const int w128 = ceil_div(Cog, 128) * 128, w96 = ceil_div(Cog, 96) * 96, w64 = ceil_div(Cog, 64) * 64;
-    if (w128 <= w96 && w128 <= w64) return launch_conv<128, 2, 2, PADDED>(g, w, w_ld, w_grp_stride, row_tab, Cog, Cout_total, o, s);
+    if (w128 <= w96 && w128 <= w64) {
+        // 128-wide tiles in the padded layout with a 16-blocked reduction (K % 16 == 0): the LDS-DMA kernel
+        if (PADDED && g.K % KBLK == 0 && (int64_t)g.K * w_ld * 4 < MAX_BUF_BYTES && getenv("VL_CONV_STAGED") == nullptr)
+            return launch_conv_dma(g, w, w_ld, w_grp_stride, row_tab, Cog, Cout_total, o, s);
+        return launch_conv<128, 2, 2, PADDED>(g, w, w_ld, w_grp_stride, row_tab, Cog, Cout_total, o, s);
+    }
     if (w96 <= w64) return launch_conv<96, 1, 4, PADDED>(g, w, w_ld, w_grp_stride, row_tab, Cog, Cout_total, o, s);
     return launch_conv<64, 1, 4, PADDED>(g, w, w_ld, w_grp_stride, row_tab, Cog, Cout_total, o, s);
 }
 
 static void fill_geom(ConvGeom& g, const float* x, int n, int cin_total, int cig, int H, int W, int halo, int OH, int OW,
-                      int stride, int pt, int pl, int K, const int* tab, const int2* tab2) {
+                      int stride, int pt, int pl, int K, const int* tab, const int2* tab2, int phase = 1) {
     g.x = x; g.ktab = tab; g.ktab2 = tab2; g.K = K; g.M = n * OH * OW; g.H = H; g.W = W;
-    g.halo = halo; g.Wp = W + 2 * halo;
+    g.halo = halo;
+    g.Wp = phase > 1 ? (W + 2 * halo + phase - 1) / phase : W + 2 * halo;
+    g.col_mul = phase > 1 ? 1 : stride;
+    g.col_add = phase > 1 ? 0 : halo - pl;
     g.stride = stride; g.pt = pt; g.pl = pl; g.OHW = OH * OW; g.OW = OW;
     g.dOHW = make_fastdiv(g.OHW); g.dOW = make_fastdiv(g.OW);
     const int64_t Pp = (int64_t)(H + 2 * halo) * g.Wp;
-    g.img_stride = (int64_t)cin_total * Pp;
-    g.grp_stride = (int64_t)cig * Pp;
+    g.img_stride = (int64_t)cin_total * phase * Pp;
+    g.grp_stride = (int64_t)cig * phase * Pp;
     g.total = g.img_stride * n;
     g.zero = 0;
 }
@@ -1115,7 +1361,8 @@ extern "C" int vl_conv_fwd(const vl_conv_desc* d, const float* x, const float* w
     VL_CHECK(d && x && w && y, "vl_conv_fwd: null argument");
     VL_CHECK(n > 0 && (int64_t)n * d->oh * d->ow < (1ll << 31), "vl_conv_fwd: bad batch %d", n);
     ConvGeom g;
-    fill_geom(g, x, n, d->cin, d->cig, d->h, d->w, d->x_halo, d->oh, d->ow, d->stride, d->pt, d->pl, d->K, d->ptab_fwd, d->ptab2_fwd);
+    fill_geom(g, x, n, d->cin, d->cig, d->h, d->w, d->x_halo, d->oh, d->ow, d->stride, d->pt, d->pl, d->K, d->ptab_fwd, d->ptab2_fwd,
+              d->x_phase > 1 ? d->x_phase : 1);
     VL_CHECK(g.total * 4 < MAX_BUF_BYTES, "vl_conv_fwd: input of %lld elements exceeds the buffer-offset range", (long long)g.total);
     ConvOut o{y, bias, nullptr, relu, d->y_halo, 0, d->oh, d->ow};
     // HWIO weights are the [K][Cout_total] GEMM operand as they stand; group g = column block g*cog.
@@ -1290,7 +1537,8 @@ extern "C" int vl_conv_wgrad(const vl_conv_desc* d, const float* x, const float*
     VL_CHECK(splits == 1 || (ws && ws_bytes >= vl_conv_wgrad_ws_bytes(d, n)), "vl_conv_wgrad: workspace too small (%zu < %zu)",
              ws_bytes, vl_conv_wgrad_ws_bytes(d, n));
     ConvGeom g;
-    fill_geom(g, x, n, d->cin, d->cig, d->h, d->w, d->x_halo, d->oh, d->ow, d->stride, d->pt, d->pl, d->K, d->ktab_fwd, d->ktab2_fwd);
+    fill_geom(g, x, n, d->cin, d->cig, d->h, d->w, d->x_halo, d->oh, d->ow, d->stride, d->pt, d->pl, d->K, d->ktab_fwd, d->ktab2_fwd,
+              d->x_phase > 1 ? d->x_phase : 1);
     const int64_t dy_total = (int64_t)n * d->cout * (d->oh + 2 * d->dy_halo) * (d->ow + 2 * d->dy_halo);
     VL_CHECK(g.total * 4 < MAX_BUF_BYTES && dy_total * 4 < MAX_BUF_BYTES, "vl_conv_wgrad: operand exceeds the buffer-offset range");
     hipStream_t s = (hipStream_t)stream;

@@ -15,9 +15,10 @@ static inline int grid_for(int64_t work, int threads, int cap) {
 // ---- input prep (dataset_.py:481-501) ---------------------------------------------------------
 __global__ void input_prep_u8_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst, int n, int rh, int rw, int oh,
                                      int ow, const int32_t* __restrict__ cy, const int32_t* __restrict__ cx,
-                                     const uint8_t* __restrict__ mir, const float* __restrict__ mean, int halo) {
+                                     const uint8_t* __restrict__ mir, const float* __restrict__ mean, int halo, int phase) {
+    // phase > 1: column-phase-split destination [c][phase][oh + 2 halo][ceil((ow + 2 halo) / phase)] (vl_conv_set_x_phase_split)
     const int64_t plane = (int64_t)oh * ow, total = plane * n;
-    const int wp = ow + 2 * halo;
+    const int wp = (ow + 2 * halo + phase - 1) / phase;
     const int64_t pp = (int64_t)(oh + 2 * halo) * wp;
     const float m0 = mean ? mean[0] : 0.f, m1 = mean ? mean[1] : 0.f, m2 = mean ? mean[2] : 0.f;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
@@ -27,21 +28,22 @@ __global__ void input_prep_u8_kernel(const uint8_t* __restrict__ src, float* __r
         const int sy = y + (cy ? cy[img] : 0);
         const int sx = ((mir && mir[img]) ? ow - 1 - x : x) + (cx ? cx[img] : 0);
         const uint8_t* s = src + (((int64_t)img * rh + sy) * rw + sx) * 3;
-        float* d = dst + (int64_t)img * 3 * pp + (int64_t)(y + halo) * wp + x + halo;
+        const int xc = x + halo;
+        float* d = dst + ((int64_t)img * 3 * phase + xc % phase) * pp + (int64_t)(y + halo) * wp + xc / phase;
         d[0] = (float)s[0] - m0;
-        d[pp] = (float)s[1] - m1;
-        d[2 * pp] = (float)s[2] - m2;
+        d[phase * pp] = (float)s[1] - m1;
+        d[2 * phase * pp] = (float)s[2] - m2;
     }
 }
 
 extern "C" int vl_input_prep_u8(const uint8_t* src, float* dst, int n, int raw_h, int raw_w, int out_h, int out_w,
                                 const int32_t* crop_y, const int32_t* crop_x, const uint8_t* mirror, const float* mean_bgr,
-                                int dst_halo, vl_stream_t stream) {
-    VL_CHECK(src && dst && dst_halo >= 0, "vl_input_prep_u8: bad argument");
+                                int dst_halo, int dst_phase, vl_stream_t stream) {
+    VL_CHECK(src && dst && dst_halo >= 0 && dst_phase >= 1, "vl_input_prep_u8: bad argument");
     VL_CHECK(n > 0 && out_h > 0 && out_w > 0 && out_h <= raw_h && out_w <= raw_w, "vl_input_prep_u8: bad shape");
     const int64_t total = (int64_t)n * out_h * out_w;
     hipLaunchKernelGGL(input_prep_u8_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, (hipStream_t)stream, src, dst, n,
-                       raw_h, raw_w, out_h, out_w, crop_y, crop_x, mirror, mean_bgr, dst_halo);
+                       raw_h, raw_w, out_h, out_w, crop_y, crop_x, mirror, mean_bgr, dst_halo, dst_phase);
     VL_LAUNCH_CHECK();
     return 0;
 }
@@ -59,23 +61,25 @@ __global__ void permute3_kernel(const float* __restrict__ src, float* __restrict
 }
 
 __global__ void nhwc_to_nchw_halo_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, int h, int w, int c,
-                                         int halo) {
+                                         int halo, int phase) {
     const int64_t total = (int64_t)n * c * h * w;
-    const int wp = w + 2 * halo;
+    const int wp = (w + 2 * halo + phase - 1) / phase;
     const int64_t pp = (int64_t)(h + 2 * halo) * wp;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int x = (int)(e % w);
         const int y = (int)((e / w) % h);
         const int ch = (int)((e / ((int64_t)w * h)) % c);
         const int64_t img = e / ((int64_t)w * h * c);
-        dst[(img * c + ch) * pp + (int64_t)(y + halo) * wp + x + halo] = src[((img * h + y) * w + x) * c + ch];
+        const int xc = x + halo;
+        dst[((img * c + ch) * phase + xc % phase) * pp + (int64_t)(y + halo) * wp + xc / phase] = src[((img * h + y) * w + x) * c + ch];
     }
 }
 
-extern "C" int vl_nhwc_to_nchw(const float* src, float* dst, int n, int h, int w, int c, int dst_halo, vl_stream_t stream) {
-    VL_CHECK(src && dst && n > 0 && h > 0 && w > 0 && c > 0 && dst_halo >= 0, "vl_nhwc_to_nchw: bad argument");
+extern "C" int vl_nhwc_to_nchw(const float* src, float* dst, int n, int h, int w, int c, int dst_halo, int dst_phase,
+                               vl_stream_t stream) {
+    VL_CHECK(src && dst && n > 0 && h > 0 && w > 0 && c > 0 && dst_halo >= 0 && dst_phase >= 1, "vl_nhwc_to_nchw: bad argument");
     hipLaunchKernelGGL(nhwc_to_nchw_halo_kernel, dim3(grid_for((int64_t)n * h * w * c, 256, 8192)), dim3(256), 0, (hipStream_t)stream,
-                       src, dst, n, h, w, c, dst_halo);
+                       src, dst, n, h, w, c, dst_halo, dst_phase);
     VL_LAUNCH_CHECK();
     return 0;
 }

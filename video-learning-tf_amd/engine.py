@@ -168,7 +168,11 @@ class LRCNEngine:
         pads = [cv.same_pad() for cv in convs]
         h, w, c = cfg.image_shape
         self.x0_halo = pads[0]
-        self.x0 = zbuf(N, c, h, w, self.x0_halo)
+        # conv1 is strided: its input is stored column-phase-split so that the taps of consecutive output columns are
+        # consecutive addresses (vl_conv_set_x_phase_split); x0 is only ever read by conv1 (forward and wgrad)
+        convs[0].set_halo(pads[0], 0, 0, 0)
+        self.x0_phase = convs[0].set_x_phase_split(True) if pads[0] > 0 else 1
+        self.x0 = torch.zeros(ops.phase_split_shape(N, c, h, w, self.x0_halo, self.x0_phase), device=dev)
         self.layers = []
         max_w = 0
         ws_bytes = 4
@@ -321,14 +325,15 @@ class LRCNEngine:
         if mean_bgr is not None:
             self.mean_dev.copy_(torch.as_tensor(np.asarray(mean_bgr, np.float32)), non_blocking=True)
             mean = self.mean_dev
-        ops.input_prep_u8(frames_u8, self.x0[:n], crop_y, crop_x, mirror, mean, halo=self.x0_halo)
+        ops.input_prep_u8(frames_u8, self.x0[:n], crop_y, crop_x, mirror, mean, halo=self.x0_halo, phase=self.x0_phase,
+                          out_hw=self.cfg.image_shape[:2])
         return n, b
 
     def feed_f32_nhwc(self, frames):
         """The reference's placeholder format: float32 NHWC, already cropped / mean-subtracted (model.py:54)."""
         n = frames.shape[0]
         b = self._check_frames(n)
-        ops.nhwc_to_nchw(frames, self.x0[:n], halo=self.x0_halo)
+        ops.nhwc_to_nchw(frames, self.x0[:n], halo=self.x0_halo, phase=self.x0_phase)
         return n, b
 
     # ---- forward -------------------------------------------------------------------------------

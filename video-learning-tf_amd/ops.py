@@ -32,25 +32,37 @@ def _dense(*ts):
 
 
 # ---- input ---------------------------------------------------------------------------------------
-def input_prep_u8(src, dst, crop_y=None, crop_x=None, mirror=None, mean_bgr=None, halo=0):
-    """src uint8 [n, raw_h, raw_w, 3] (HWC, BGR) -> dst f32 [n, 3, out_h + 2 halo, out_w + 2 halo] (dataset_.py:481-501)."""
+def phase_split_shape(n, c, h, w, halo, phase):
+    """Shape of an activation tensor with a zero halo, plain (phase 1) or column-phase-split (vl_conv_set_x_phase_split)."""
+    if phase <= 1:
+        return (n, c, h + 2 * halo, w + 2 * halo)
+    return (n, c * phase, h + 2 * halo, -(-(w + 2 * halo) // phase))
+
+
+def input_prep_u8(src, dst, crop_y=None, crop_x=None, mirror=None, mean_bgr=None, halo=0, phase=1, out_hw=None):
+    """src uint8 [n, raw_h, raw_w, 3] (HWC, BGR) -> dst f32 [n, 3, out_h + 2 halo, out_w + 2 halo] (dataset_.py:481-501);
+    phase > 1: dst is phase_split_shape(n, 3, *out_hw, halo, phase) and out_hw must be given."""
     if src.dtype != torch.uint8 or not src.is_cuda:
         raise _ffi.VltfError("input_prep_u8: src must be a device uint8 tensor")
     _f32(dst, mean_bgr)
     _dense(src, dst, crop_y, crop_x, mirror, mean_bgr)
     n, rh, rw, c = src.shape
-    if c != 3 or dst.shape[0] != n or dst.shape[1] != 3:
+    if out_hw is None:
+        if phase > 1:
+            raise _ffi.VltfError("input_prep_u8: out_hw is required with a phase-split destination")
+        out_hw = (dst.shape[2] - 2 * halo, dst.shape[3] - 2 * halo)
+    if c != 3 or tuple(dst.shape) != phase_split_shape(n, 3, out_hw[0], out_hw[1], halo, phase):
         raise _ffi.VltfError("input_prep_u8: shape mismatch %s -> %s" % (tuple(src.shape), tuple(dst.shape)))
-    _ffi.call("vl_input_prep_u8", _p(src), _p(dst), n, rh, rw, dst.shape[2] - 2 * halo, dst.shape[3] - 2 * halo, _p(crop_y),
-              _p(crop_x), _p(mirror), _p(mean_bgr), halo, stream())
+    _ffi.call("vl_input_prep_u8", _p(src), _p(dst), n, rh, rw, out_hw[0], out_hw[1], _p(crop_y), _p(crop_x), _p(mirror),
+              _p(mean_bgr), halo, phase, stream())
 
 
-def nhwc_to_nchw(src, dst, halo=0):
+def nhwc_to_nchw(src, dst, halo=0, phase=1):
     _f32(src, dst); _dense(src, dst)
     n, h, w, c = src.shape
-    if tuple(dst.shape) != (n, c, h + 2 * halo, w + 2 * halo):
+    if tuple(dst.shape) != phase_split_shape(n, c, h, w, halo, phase):
         raise _ffi.VltfError("nhwc_to_nchw: shape mismatch %s -> %s (halo %d)" % (tuple(src.shape), tuple(dst.shape), halo))
-    _ffi.call("vl_nhwc_to_nchw", _p(src), _p(dst), n, h, w, c, halo, stream())
+    _ffi.call("vl_nhwc_to_nchw", _p(src), _p(dst), n, h, w, c, halo, phase, stream())
 
 
 def nchw_to_nhwc(src, dst):
@@ -86,9 +98,19 @@ class Conv:
         """Declare the zero-halo layouts of x / y / dy / dx (include/vltf.h: vl_conv_set_halo)."""
         _ffi.call("vl_conv_set_halo", self._d, x_halo, y_halo, dy_halo, dx_halo)
         self.x_halo, self.y_halo, self.dy_halo, self.dx_halo = x_halo, y_halo, dy_halo, dx_halo
+        self.x_phase = int(_ffi.lib().vl_conv_x_phase(self._d))
+
+    def set_x_phase_split(self, on=True):
+        """Store x column-phase-split (strided convs in the padded layout; include/vltf.h).  Returns the phase count."""
+        _ffi.call("vl_conv_set_x_phase_split", self._d, int(on))
+        self.x_phase = int(_ffi.lib().vl_conv_x_phase(self._d))
+        return self.x_phase
 
     def _shape(self, n, c, h, w, halo):
         return (n, c, h + 2 * halo, w + 2 * halo)
+
+    def x_shape(self, n):
+        return phase_split_shape(n, self.cin, self.h, self.w, self.x_halo, getattr(self, "x_phase", 1))
 
     def __del__(self):
         try:
@@ -101,8 +123,7 @@ class Conv:
     def fwd(self, x, w, bias, y, relu=True):
         _f32(x, w, bias, y); _dense(x, w, bias, y)
         n = x.shape[0]
-        if tuple(x.shape) != self._shape(n, self.cin, self.h, self.w, self.x_halo) or \
-                tuple(y.shape) != self._shape(n, self.cout, self.oh, self.ow, self.y_halo):
+        if tuple(x.shape) != self.x_shape(n) or tuple(y.shape) != self._shape(n, self.cout, self.oh, self.ow, self.y_halo):
             raise _ffi.VltfError("conv.fwd: shape mismatch x=%s y=%s (halos %d, %d)" % (tuple(x.shape), tuple(y.shape),
                                                                                         self.x_halo, self.y_halo))
         _ffi.call("vl_conv_fwd", self._d, _p(x), _p(w), _p(bias), _p(y), n, int(relu), stream())
@@ -130,8 +151,7 @@ class Conv:
         """dw (and, when fuses_bias(), db = sum of dy over n,h,w in the same pass)."""
         _f32(x, dy, dw, db); _dense(x, dy, dw, ws, db)
         n = x.shape[0]
-        if tuple(x.shape) != self._shape(n, self.cin, self.h, self.w, self.x_halo) or \
-                tuple(dy.shape) != self._shape(n, self.cout, self.oh, self.ow, self.dy_halo):
+        if tuple(x.shape) != self.x_shape(n) or tuple(dy.shape) != self._shape(n, self.cout, self.oh, self.ow, self.dy_halo):
             raise _ffi.VltfError("conv.wgrad: shape mismatch x=%s dy=%s" % (tuple(x.shape), tuple(dy.shape)))
         nbytes = 0 if ws is None else ws.numel() * ws.element_size()
         _ffi.call("vl_conv_wgrad", self._d, _p(x), _p(dy), _p(dw), _p(db), _p(ws), nbytes, x.shape[0], stream())
