@@ -28,10 +28,10 @@ import torch
 CONV_MACS = {"conv1": 113221152, "conv2": 240844800, "conv3": 149520384, "conv4": 112140288, "conv5": 74760192}
 CLIP_TRAIN_FLOP = 2 * 33357755136          # T = 16, fc6 encode
 PEAK_FP32_MFMA_TFLOPS = 157.3              # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-# launches that share the single-kernel symbol mfma_contract<128,128,16,2,2,DenseKX,ConvGather,EpiConvNCHW>
-# (output-channel tile 128: conv2/3/5 forward and conv3 dgrad, whose output channel count is 256)
+# launches that share the single-kernel symbol conv_dma_kernel<32> (output-channel tile 128, LDS-DMA operand rows:
+# conv2/3/5 forward and conv3 dgrad, whose output channel count is 256)
 DOMINANT = ("conv2.fwd", "conv3.fwd", "conv5.fwd", "conv3.dgrad")
-DOMINANT_SYMBOL = "mfma_contract<128, 128, 16, 2, 2, ConvWeightKX<128, 16>, ConvGather<128, 16, true>, EpiConvNCHW, 1>"
+DOMINANT_SYMBOL = "conv_dma_kernel<32>"
 # algorithmic HBM bytes of those launches per frame: input + weights (per launch) + output, fp32, interiors only
 DOMINANT_ELEMS_PER_FRAME = {"conv2.fwd": 96 * 28 * 28 + 256 * 28 * 28, "conv3.fwd": 256 * 169 + 384 * 169,
                             "conv5.fwd": 384 * 169 + 256 * 169, "conv3.dgrad": 384 * 169 + 256 * 169}
@@ -172,7 +172,7 @@ def main():
     achieved = dom_flop / (dom_ms * 1e-3) / 1e12
     stack_flop = sum(2.0 * CONV_MACS[l.split(".")[0]] * n for l in avg)
     stack_ms = sum(avg.values())
-    traffic_rec, traffic_src = committed_traffic(DOMINANT_SYMBOL.rsplit(",", 1)[0])
+    traffic_rec, traffic_src = committed_traffic(DOMINANT_SYMBOL)
     alg_bytes = sum(4.0 * (DOMINANT_ELEMS_PER_FRAME[l] * n + DOMINANT_WEIGHT_ELEMS[l]) for l in DOMINANT) / len(DOMINANT)
     ms_per_step = elapsed / args.steps * 1e3
     value = total_clips * args.steps / elapsed

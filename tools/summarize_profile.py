@@ -18,7 +18,7 @@ import os
 import sqlite3
 import sys
 
-DOMINANT = "mfma_contract<128, 128, 16, 2, 2, ConvWeightKX<128, 16>, ConvGather<128, 16, true>, EpiConvNCHW"   # prefix of the symbol
+DOMINANT = "conv_dma_kernel<32>"   # prefix of the dominant kernel symbol (bench.py DOMINANT_SYMBOL)
 GRAD_FLOATS = 44570341          # flat parameter / gradient buffer of the benchmark config
 
 

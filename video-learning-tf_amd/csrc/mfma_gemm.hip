@@ -869,11 +869,12 @@ __global__ __launch_bounds__(NT, 1) void wgrad_dma_kernel(const ConvGeom g, cons
 // fetched global -> LDS by `buffer_load_dword ... lds`, one fetch in the shadow of each MFMA of a stage's first half,
 // vmcnt(0) + one barrier per stage (128 MFMAs per wave) instead of one per 16-row tile (32 MFMAs).
 // Both operands land in LDS as [r][x] rows (the DMA writes a wave's 64 lanes to consecutive dwords): a weight row is 64
-// consecutive output channels, an im2col row is the tile's 64 consecutive pixels of one (tap, channel).  A wave's two
-// 32-wide MFMA tiles along x are the EVEN and the ODD elements of its 64-wide block, so lane l reads the adjacent pair
-// x = 2 (l & 31), +1 with one ds_read_b64 -- half the LDS instructions of two b32 reads, conflict free (the two lane
-// halves read different rows r).  Accumulator (a, b, q) of lane l is therefore y[co = 64 wm + 2 i + a][pixel = 64 wn + 2 j + b]
-// with i = (q&3) + 8 (q>>2) + 4 (l>>5), j = l & 31.
+// consecutive output channels, an im2col row is the tile's 64 consecutive pixels of one (tap, channel).  Along the channel
+// axis a wave's two 32-wide MFMA tiles are the EVEN and the ODD channels of its 64-wide block, so lane l reads the adjacent
+// pair co = 2 (l & 31), +1 with one ds_read_b64 (conflict free: the two lane halves read different rows r).  Along the
+// pixel axis the tiles are the two contiguous 32-pixel halves (two b32 reads): an even/odd split there made every output
+// store a stride-2 half-filled line and doubled the kernel's HBM write traffic (measured 747 vs 360 MB algorithmic).
+// Accumulator (a, b, q) of lane l is y[co = 64 wm + 2 i + a][pixel = 64 wn + 32 b + j], i = (q&3) + 8 (q>>2) + 4 (l>>5), j = l & 31.
 struct ConvDmaParams {
     const float* w;          // [K][w_ld] weights (HWIO forward, flipped/transposed for dgrad)
     int64_t w_ld;
@@ -973,21 +974,25 @@ __global__ __launch_bounds__(NT, 64 / SR) void conv_dma_kernel(const ConvDmaPara
 
     // lane half h = lane >> 5 consumes row 2 s + h at MFMA step s
     const float* fa = ldsc + (lane >> 5) * 128 + wm * 64 + 2 * (lane & 31);
-    const float* fb = ldsc + ABUF + (lane >> 5) * 128 + wn * 64 + 2 * (lane & 31);
+    const float* fb = ldsc + ABUF + (lane >> 5) * 128 + wn * 64 + (lane & 31);
 
     auto stage = [&](const int cur, int st_next) {                    // MFMAs on buffer cur while stage st_next streams into the other
         float2 af[2], bf[2], an[2], bn[2];
+        auto read_b = [&](int step) {                                 // pixel tiles: [0, 32) and [32, 64) of the wave's block
+            const float* q = fb + cur * BUF + step * 256;
+            return float2{q[0], q[32]};
+        };
         af[0] = *reinterpret_cast<const float2*>(fa + cur * BUF);
-        bf[0] = *reinterpret_cast<const float2*>(fb + cur * BUF);
+        bf[0] = read_b(0);
         af[1] = *reinterpret_cast<const float2*>(fa + cur * BUF + 256);
-        bf[1] = *reinterpret_cast<const float2*>(fb + cur * BUF + 256);
+        bf[1] = read_b(1);
 #pragma unroll
         for (int t = 0; t < NT2; ++t) {                               // t = two MFMA steps = four reduction rows
             if (t + 1 < NT2) {
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     an[u] = *reinterpret_cast<const float2*>(fa + cur * BUF + (2 * (t + 1) + u) * 256);
-                    bn[u] = *reinterpret_cast<const float2*>(fb + cur * BUF + (2 * (t + 1) + u) * 256);
+                    bn[u] = read_b(2 * (t + 1) + u);
                 }
             }
 #pragma unroll
@@ -1029,7 +1034,7 @@ __global__ __launch_bounds__(NT, 64 / SR) void conv_dma_kernel(const ConvDmaPara
     // ---- epilogue: NCHW (+ halo), bias, ReLU, ReluGrad mask
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-        const int m = j0 + wn * 64 + 2 * (lane & 31) + b;
+        const int m = j0 + wn * 64 + 32 * b + (lane & 31);
         if (m >= pe.M) continue;
         const uint32_t n = fd_div((uint32_t)m, pe.dOHW);
         const uint32_t p = m - n * pe.OHW;
