@@ -1307,10 +1307,180 @@ static int launch_conv(const ConvGeom& g, const float* w, int64_t w_ld, int w_gr
     return 0;
 }
 
+// ---- the same for a 48-channel output tile, on v_mfma_f32_16x16x4_f32 ------------------------------------------------
+// conv2's dgrad produces 48 input channels per group: on 32x32 MFMA tiles that is a 64-row tile with 25 % of the matrix
+// work wasted (its pipe was 93 % busy and still only 0.69 of peak).  The 16x16x4 MFMA has the same rate (64 FLOP/clk/SIMD)
+// and tiles 48 = 3 x 16 exactly.  Four waves side by side, each 48 channels x 32 pixels = 3 x 2 tiles of 16 x 16 (6 independent
+// accumulators of 4 registers).  Operand rows arrive by LDS-DMA exactly as above (a weight row = 48 of 64 lanes); LDS row
+// strides 80 / 144 floats (= 16 mod 32) keep the four 16-lane groups of a fragment read -- lane group g reads row 4 s + g --
+// on disjoint banks.  Lane l holds A[co = l & 15][r = l >> 4], B[r = l >> 4][pixel = l & 15]; D register q is
+// y[co = 4 (l >> 4) + q][pixel = l & 15].
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(NT, 2) void conv_dma48_kernel(const ConvDmaParams pa, const ConvGeom g, const EpiConvNCHW::Params pe,
+                                                           int tiles_i) {
+    constexpr int BM = 48, BN = 128, SR = 32;
+    constexpr int SA = 80, SB = 144;                                  // LDS row strides (floats)
+    constexpr int ABUF = SR * SA, BUF = SR * (SA + SB);
+    constexpr int RW = SR / 4, NF = RW * 3, NSTEP = SR / 4;           // rows per wave, fetches per wave (1 A + 2 B per row), k4-steps
+    extern __shared__ __attribute__((aligned(16))) float ldsc[];
+    const int bid = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int ti_blk = bid % tiles_i, tj_blk = bid / tiles_i;
+    const int zg = blockIdx.y;
+    const int i0 = ti_blk * BM, j0 = tj_blk * BN;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    const i32x4 rs_w = rsrc_words(pa.w + (int64_t)zg * pa.w_grp_stride, pa.w_bytes - (int64_t)zg * pa.w_grp_stride * 4);
+    const i32x4 rs_x = rsrc_words(g.x + (int64_t)zg * g.grp_stride, (g.total - (int64_t)zg * g.grp_stride) * 4);
+    const uint32_t voff_a = (lane < BM && i0 + lane < pe.Cog) ? (uint32_t)(i0 + lane) * 4u : OOB_OFF;
+    uint32_t voff_b[2];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+        const int m = j0 + hf * 64 + lane;
+        const bool vm = m < g.M;
+        const uint32_t mm = vm ? m : 0;
+        const uint32_t n = fd_div(mm, g.dOHW);
+        const uint32_t p = mm - n * g.OHW;
+        const uint32_t oh = fd_div(p, g.dOW);
+        const uint32_t ow = p - oh * g.OW;
+        const int ih0 = (int)oh * g.stride - g.pt + g.halo, iw0 = (int)ow * g.col_mul + g.col_add;
+        voff_b[hf] = vm ? (uint32_t)((int64_t)n * g.img_stride + (int64_t)ih0 * g.Wp + iw0) * 4u : OOB_OFF;
+    }
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)ldsc;
+    const int ld_bytes = (int)(pa.w_ld * 4);
+
+    int tabv[RW];
+    int row0 = 0;
+    bool blk_ok = false;
+    const int wrow = wave * RW;
+    auto load_table = [&](int st) {
+        const int k0 = st * SR + wrow;
+        const const_int_ptr tt = as_const(g.ktab) + k0 + st * g.zero;
+#pragma unroll
+        for (int f = 0; f < RW; ++f) tabv[f] = tt[f];
+        row0 = as_const(pa.row_tab)[k0 / KBLK + st * g.zero] + k0 % KBLK;
+        blk_ok = k0 / KBLK < pa.nblk;
+    };
+    auto pin_table = [&]() {
+#pragma unroll
+        for (int f = 0; f < RW; ++f) asm volatile("" : "+s"(tabv[f]));
+        asm volatile("" : "+s"(row0));
+    };
+    auto dma = [&](const int nb, const int f, int st) {                // f = 3 rr + {0: weight row, 1/2: im2col halves}
+        const int rr = f / 3, kind = f % 3;
+        const int z = st * g.zero;
+        if (kind == 0) {
+            lds_dma_row(rs_w, lds0 + (uint32_t)(nb * BUF + (wrow + rr) * SA + z) * 4u, blk_ok ? voff_a : OOB_OFF, (row0 + rr) * ld_bytes);
+        } else {
+            const int hf = kind - 1;
+            lds_dma_row(rs_x, lds0 + (uint32_t)(nb * BUF + ABUF + (wrow + rr) * SB + hf * 64 + z) * 4u, blk_ok ? voff_b[hf] : OOB_OFF,
+                        tabv[rr]);
+        }
+    };
+    auto finish_stage = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+
+    f32x4 acc[3][2];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[a][b][q] = 0.f;
+
+    const int nstages = (pa.nblk * KBLK + SR - 1) / SR;
+    load_table(0);
+    pin_table();
+#pragma unroll
+    for (int f = 0; f < NF; ++f) dma(0, f, 0);
+    load_table(1);
+    pin_table();
+    finish_stage();
+
+    const float* fa = ldsc + (lane >> 4) * SA + (lane & 15);
+    const float* fb = ldsc + ABUF + (lane >> 4) * SB + wave * 32 + (lane & 15);
+
+    auto stage = [&](const int cur, int st_next) {
+        float af[2][3], bf[2][2];
+        auto read = [&](int step, float (&a)[3], float (&b)[2]) {
+            const float* pa_ = fa + cur * BUF + step * 4 * SA;
+            const float* pb_ = fb + cur * BUF + step * 4 * SB;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) a[i] = pa_[16 * i];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) b[i] = pb_[16 * i];
+        };
+        read(0, af[0], bf[0]);
+#pragma unroll
+        for (int t = 0; t < NSTEP; ++t) {
+            const int c = t & 1;
+            if (t + 1 < NSTEP) read(t + 1, af[c ^ 1], bf[c ^ 1]);
+#pragma unroll
+            for (int m = 0; m < 6; ++m) {
+                const int a = m >> 1, b = m & 1;
+                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[c][a], bf[c][b], acc[a][b], 0, 0, 0);
+                const int f = t * 6 + m;
+                if (f < NF) {
+                    dma(cur ^ 1, f, st_next);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            static_assert(NF <= 6 * (NSTEP - 3), "fetches must end before the table is replaced");
+            if (t == NSTEP - 3) {
+                load_table(st_next + 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (t == NSTEP - 1) {
+                pin_table();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        finish_stage();
+    };
+    int st = 0;
+    for (; st + 1 < nstages; st += 2) {
+        stage(0, st + 1);
+        stage(1, st + 2);
+    }
+    if (nstages & 1) stage(0, st + 1);
+
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int m = j0 + wave * 32 + 16 * b + (lane & 15);
+        if (m >= pe.M) continue;
+        const uint32_t n = fd_div((uint32_t)m, pe.dOHW);
+        const uint32_t p = m - n * pe.OHW;
+        const uint32_t oh = fd_div(p, pe.dOW);
+        const uint32_t ow = p - oh * pe.OW;
+        const int64_t c0 = (int64_t)n * pe.Cout_total + (int64_t)zg * pe.Cog;
+        const int64_t ybase = c0 * pe.y_plane + (int64_t)(oh + pe.y_halo) * pe.y_wp + ow + pe.y_halo;
+        const int64_t mbase = c0 * pe.m_plane + (int64_t)(oh + pe.m_halo) * pe.m_wp + ow + pe.m_halo;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int co = i0 + 16 * a + 4 * (lane >> 4) + q;
+                if (co < pe.Cog) {
+                    float v = acc[a][b][q];
+                    if (pe.bias) v += pe.bias[zg * pe.Cog + co];
+                    if (pe.relu) v = fmaxf(v, 0.f);
+                    if (pe.mask) v = pe.mask[mbase + (int64_t)co * pe.m_plane] > 0.f ? v : 0.f;
+                    pe.y[ybase + (int64_t)co * pe.y_plane] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int BM>   // 128: conv_dma_kernel (32x32 MFMA tiles); 48: conv_dma48_kernel (16x16)
 static int launch_conv_dma(const ConvGeom& g, const float* w, int64_t w_ld, int w_grp_stride, const int* row_tab, int Cog,
                            int Cout_total, const ConvOut& o, hipStream_t s) {
-    constexpr int BM = 128, BN = 128, SR = 32;
-    constexpr size_t lds = (size_t)2 * SR * (BM + BN) * sizeof(float);   // 64 KB: two workgroups per CU
+    constexpr int BN = 128, SR = 32;
+    constexpr size_t lds = BM == 128 ? (size_t)2 * SR * (BM + BN) * sizeof(float)    // 64 KB: two workgroups per CU
+                                     : (size_t)2 * SR * (80 + 144) * sizeof(float);  // 56 KB
     ConvDmaParams pa{w, w_ld, (int64_t)w_grp_stride, (int64_t)g.K * w_ld * 4, row_tab, ceil_div(g.K, KBLK)};
     EpiConvNCHW::Params pe;
     pe.y = o.y; pe.bias = o.bias; pe.mask = o.mask; pe.relu = o.relu;
@@ -1319,13 +1489,14 @@ static int launch_conv_dma(const ConvGeom& g, const float* w, int64_t w_ld, int 
     pe.y_halo = o.y_halo; pe.y_wp = o.OW + 2 * o.y_halo; pe.y_plane = (int64_t)(o.OH + 2 * o.y_halo) * pe.y_wp;
     pe.m_halo = o.m_halo; pe.m_wp = o.OW + 2 * o.m_halo; pe.m_plane = (int64_t)(o.OH + 2 * o.m_halo) * pe.m_wp;
     static bool attr_set = false;
+    auto kern = BM == 128 ? conv_dma_kernel<SR> : conv_dma48_kernel;
     if (!attr_set) {
-        VL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dma_kernel<SR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        VL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     const int tiles_i = ceil_div(Cog, BM), tiles_j = ceil_div(g.M, BN);
     dim3 grid(tiles_i * tiles_j, (unsigned)(Cout_total / Cog), 1);
-    hipLaunchKernelGGL(conv_dma_kernel<SR>, grid, dim3(NT), lds, s, pa, g, pe, tiles_i);
+    hipLaunchKernelGGL(kern, grid, dim3(NT), lds, s, pa, g, pe, tiles_i);
     VL_LAUNCH_CHECK();
     return 0;
 }
@@ -1338,9 +1509,13 @@ static int dispatch_conv(const ConvGeom& g, const float* w, int64_t w_ld, int w_
     if (w128 <= w96 && w128 <= w64) {
         // 128-wide tiles in the padded layout with a 16-blocked reduction (K % 16 == 0): the LDS-DMA kernel
         if (PADDED && g.K % KBLK == 0 && (int64_t)g.K * w_ld * 4 < MAX_BUF_BYTES && getenv("VL_CONV_STAGED") == nullptr)
-            return launch_conv_dma(g, w, w_ld, w_grp_stride, row_tab, Cog, Cout_total, o, s);
+            return launch_conv_dma<128>(g, w, w_ld, w_grp_stride, row_tab, Cog, Cout_total, o, s);
         return launch_conv<128, 2, 2, PADDED>(g, w, w_ld, w_grp_stride, row_tab, Cog, Cout_total, o, s);
     }
+    // 48-wide tiles beat the 64-wide ones whenever they waste fewer rows (conv2 dgrad: 48 channels per group)
+    if (PADDED && g.K % KBLK == 0 && ceil_div(Cog, 48) * 48 < w64 && ceil_div(Cog, 48) * 48 < w96 &&
+        (int64_t)g.K * w_ld * 4 < MAX_BUF_BYTES && getenv("VL_CONV_STAGED") == nullptr)
+        return launch_conv_dma<48>(g, w, w_ld, w_grp_stride, row_tab, Cog, Cout_total, o, s);
     if (w96 <= w64) return launch_conv<96, 1, 4, PADDED>(g, w, w_ld, w_grp_stride, row_tab, Cog, Cout_total, o, s);
     return launch_conv<64, 1, 4, PADDED>(g, w, w_ld, w_grp_stride, row_tab, Cog, Cout_total, o, s);
 }
