@@ -1779,10 +1779,13 @@ extern "C" int vl_gemm(int transa, int transb, int m, int n, int k, const float*
     VL_CHECK(ea * 4 < MAX_BUF_BYTES && eb * 4 < MAX_BUF_BYTES, "vl_gemm: operand exceeds the buffer-offset range");
     const int bm = m <= 64 ? 64 : 128;
     const int tiles = ceil_div(m, bm) * ceil_div(n, 128);
-    // split the reduction when the output alone cannot fill 256 CUs and a workspace was provided
+    // split the reduction when the output tiles alone leave fewer than ~3 workgroups per CU (this kernel hides its load and
+    // barrier latency with co-resident workgroups: fc6 forward = 256 tiles = one per CU ran at 0.65 of peak) and a workspace
+    // was provided
     int splits = 1;
-    if (ws && tiles < 192) {
-        splits = ceil_div(512, tiles);
+    const int want = 3 * device_cus();
+    if (ws && tiles < want && getenv("VL_GEMM_NOSPLIT") == nullptr) {
+        splits = ceil_div(want, tiles);
         const int maxs = k / 256 > 0 ? k / 256 : 1;
         if (splits > maxs) splits = maxs;
         const size_t cap = ws_bytes / ((size_t)m * n * sizeof(float));
