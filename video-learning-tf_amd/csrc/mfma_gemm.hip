@@ -1307,22 +1307,25 @@ static int launch_conv(const ConvGeom& g, const float* w, int64_t w_ld, int w_gr
     return 0;
 }
 
-// ---- the same for a 48-channel output tile, on v_mfma_f32_16x16x4_f32 ------------------------------------------------
+// ---- the same for 48- and 96-channel output tiles, on v_mfma_f32_16x16x4_f32 -----------------------------------------
 // conv2's dgrad produces 48 input channels per group: on 32x32 MFMA tiles that is a 64-row tile with 25 % of the matrix
 // work wasted (its pipe was 93 % busy and still only 0.69 of peak).  The 16x16x4 MFMA has the same rate (64 FLOP/clk/SIMD)
 // and tiles 48 = 3 x 16 exactly.  Four waves side by side, each 48 channels x 32 pixels = 3 x 2 tiles of 16 x 16 (6 independent
-// accumulators of 4 registers).  Operand rows arrive by LDS-DMA exactly as above (a weight row = 48 of 64 lanes); LDS row
+// accumulators of 4 registers); TA = 6 gives the 96-channel tile of the 192-channel layers (conv4 fwd/dgrad, conv5 dgrad).  Operand rows arrive by LDS-DMA exactly as above (a weight row = 48 of 64 lanes); LDS row
 // strides 80 / 144 floats (= 16 mod 32) keep the four 16-lane groups of a fragment read -- lane group g reads row 4 s + g --
 // on disjoint banks.  Lane l holds A[co = l & 15][r = l >> 4], B[r = l >> 4][pixel = l & 15]; D register q is
 // y[co = 4 (l >> 4) + q][pixel = l & 15].
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(NT, 2) void conv_dma48_kernel(const ConvDmaParams pa, const ConvGeom g, const EpiConvNCHW::Params pe,
+template <int TA>   // channel tiles of 16 per workgroup: 3 (48 channels: conv2 dgrad) or 6 (96: the 192-channel layers)
+__global__ __launch_bounds__(NT, 2) void conv_dma16_kernel(const ConvDmaParams pa, const ConvGeom g, const EpiConvNCHW::Params pe,
                                                            int tiles_i) {
-    constexpr int BM = 48, BN = 128, SR = 32;
-    constexpr int SA = 80, SB = 144;                                  // LDS row strides (floats)
+    constexpr int BM = 16 * TA, BN = 128, SR = 32;
+    constexpr int NA = (BM + 63) / 64;                                // 64-lane fetches per weight row
+    constexpr int SA = NA * 64 + 16, SB = 144;                        // LDS row strides (floats), both = 16 mod 32
     constexpr int ABUF = SR * SA, BUF = SR * (SA + SB);
-    constexpr int RW = SR / 4, NF = RW * 3, NSTEP = SR / 4;           // rows per wave, fetches per wave (1 A + 2 B per row), k4-steps
+    constexpr int RW = SR / 4, FPR = NA + 2, NF = RW * FPR, NSTEP = SR / 4;   // rows per wave, fetches per row / per wave, k4-steps
+    constexpr int NM = 2 * TA;                                        // MFMAs per k4-step
     extern __shared__ __attribute__((aligned(16))) float ldsc[];
     const int bid = xcd_swizzle(blockIdx.x, gridDim.x);
     const int ti_blk = bid % tiles_i, tj_blk = bid / tiles_i;
@@ -1333,7 +1336,12 @@ __global__ __launch_bounds__(NT, 2) void conv_dma48_kernel(const ConvDmaParams p
 
     const i32x4 rs_w = rsrc_words(pa.w + (int64_t)zg * pa.w_grp_stride, pa.w_bytes - (int64_t)zg * pa.w_grp_stride * 4);
     const i32x4 rs_x = rsrc_words(g.x + (int64_t)zg * g.grp_stride, (g.total - (int64_t)zg * g.grp_stride) * 4);
-    const uint32_t voff_a = (lane < BM && i0 + lane < pe.Cog) ? (uint32_t)(i0 + lane) * 4u : OOB_OFF;
+    uint32_t voff_a[NA];
+#pragma unroll
+    for (int hf = 0; hf < NA; ++hf) {
+        const int cl = hf * 64 + lane;
+        voff_a[hf] = (cl < BM && i0 + cl < pe.Cog) ? (uint32_t)(i0 + cl) * 4u : OOB_OFF;
+    }
     uint32_t voff_b[2];
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
@@ -1367,13 +1375,14 @@ __global__ __launch_bounds__(NT, 2) void conv_dma48_kernel(const ConvDmaParams p
         for (int f = 0; f < RW; ++f) asm volatile("" : "+s"(tabv[f]));
         asm volatile("" : "+s"(row0));
     };
-    auto dma = [&](const int nb, const int f, int st) {                // f = 3 rr + {0: weight row, 1/2: im2col halves}
-        const int rr = f / 3, kind = f % 3;
+    auto dma = [&](const int nb, const int f, int st) {                // f = FPR rr + {weight row pieces, then the two im2col halves}
+        const int rr = f / FPR, kind = f % FPR;
         const int z = st * g.zero;
-        if (kind == 0) {
-            lds_dma_row(rs_w, lds0 + (uint32_t)(nb * BUF + (wrow + rr) * SA + z) * 4u, blk_ok ? voff_a : OOB_OFF, (row0 + rr) * ld_bytes);
+        if (kind < NA) {
+            lds_dma_row(rs_w, lds0 + (uint32_t)(nb * BUF + (wrow + rr) * SA + kind * 64 + z) * 4u, blk_ok ? voff_a[kind] : OOB_OFF,
+                        (row0 + rr) * ld_bytes);
         } else {
-            const int hf = kind - 1;
+            const int hf = kind - NA;
             lds_dma_row(rs_x, lds0 + (uint32_t)(nb * BUF + ABUF + (wrow + rr) * SB + hf * 64 + z) * 4u, blk_ok ? voff_b[hf] : OOB_OFF,
                         tabv[rr]);
         }
@@ -1383,9 +1392,9 @@ __global__ __launch_bounds__(NT, 2) void conv_dma48_kernel(const ConvDmaParams p
         __syncthreads();
     };
 
-    f32x4 acc[3][2];
+    f32x4 acc[TA][2];
 #pragma unroll
-    for (int a = 0; a < 3; ++a)
+    for (int a = 0; a < TA; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -1404,12 +1413,12 @@ __global__ __launch_bounds__(NT, 2) void conv_dma48_kernel(const ConvDmaParams p
     const float* fb = ldsc + ABUF + (lane >> 4) * SB + wave * 32 + (lane & 15);
 
     auto stage = [&](const int cur, int st_next) {
-        float af[2][3], bf[2][2];
-        auto read = [&](int step, float (&a)[3], float (&b)[2]) {
+        float af[2][TA], bf[2][2];
+        auto read = [&](int step, float (&a)[TA], float (&b)[2]) {
             const float* pa_ = fa + cur * BUF + step * 4 * SA;
             const float* pb_ = fb + cur * BUF + step * 4 * SB;
 #pragma unroll
-            for (int i = 0; i < 3; ++i) a[i] = pa_[16 * i];
+            for (int i = 0; i < TA; ++i) a[i] = pa_[16 * i];
 #pragma unroll
             for (int i = 0; i < 2; ++i) b[i] = pb_[16 * i];
         };
@@ -1419,16 +1428,16 @@ __global__ __launch_bounds__(NT, 2) void conv_dma48_kernel(const ConvDmaParams p
             const int c = t & 1;
             if (t + 1 < NSTEP) read(t + 1, af[c ^ 1], bf[c ^ 1]);
 #pragma unroll
-            for (int m = 0; m < 6; ++m) {
+            for (int m = 0; m < NM; ++m) {
                 const int a = m >> 1, b = m & 1;
                 acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[c][a], bf[c][b], acc[a][b], 0, 0, 0);
-                const int f = t * 6 + m;
+                const int f = t * NM + m;
                 if (f < NF) {
                     dma(cur ^ 1, f, st_next);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            static_assert(NF <= 6 * (NSTEP - 3), "fetches must end before the table is replaced");
+            static_assert(NF <= NM * (NSTEP - 3), "fetches must end before the table is replaced");
             if (t == NSTEP - 3) {
                 load_table(st_next + 1);
                 __builtin_amdgcn_sched_barrier(0);
@@ -1459,7 +1468,7 @@ __global__ __launch_bounds__(NT, 2) void conv_dma48_kernel(const ConvDmaParams p
         const int64_t ybase = c0 * pe.y_plane + (int64_t)(oh + pe.y_halo) * pe.y_wp + ow + pe.y_halo;
         const int64_t mbase = c0 * pe.m_plane + (int64_t)(oh + pe.m_halo) * pe.m_wp + ow + pe.m_halo;
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
+        for (int a = 0; a < TA; ++a) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int co = i0 + 16 * a + 4 * (lane >> 4) + q;
@@ -1475,12 +1484,12 @@ __global__ __launch_bounds__(NT, 2) void conv_dma48_kernel(const ConvDmaParams p
     }
 }
 
-template <int BM>   // 128: conv_dma_kernel (32x32 MFMA tiles); 48: conv_dma48_kernel (16x16)
+template <int BM>   // 128: conv_dma_kernel (32x32 MFMA tiles); 48 / 96: conv_dma16_kernel (16x16 tiles)
 static int launch_conv_dma(const ConvGeom& g, const float* w, int64_t w_ld, int w_grp_stride, const int* row_tab, int Cog,
                            int Cout_total, const ConvOut& o, hipStream_t s) {
     constexpr int BN = 128, SR = 32;
     constexpr size_t lds = BM == 128 ? (size_t)2 * SR * (BM + BN) * sizeof(float)    // 64 KB: two workgroups per CU
-                                     : (size_t)2 * SR * (80 + 144) * sizeof(float);  // 56 KB
+                                     : (size_t)2 * SR * ((BM + 63) / 64 * 64 + 16 + 144) * sizeof(float);   // 56 / 72 KB
     ConvDmaParams pa{w, w_ld, (int64_t)w_grp_stride, (int64_t)g.K * w_ld * 4, row_tab, ceil_div(g.K, KBLK)};
     EpiConvNCHW::Params pe;
     pe.y = o.y; pe.bias = o.bias; pe.mask = o.mask; pe.relu = o.relu;
@@ -1489,7 +1498,7 @@ static int launch_conv_dma(const ConvGeom& g, const float* w, int64_t w_ld, int 
     pe.y_halo = o.y_halo; pe.y_wp = o.OW + 2 * o.y_halo; pe.y_plane = (int64_t)(o.OH + 2 * o.y_halo) * pe.y_wp;
     pe.m_halo = o.m_halo; pe.m_wp = o.OW + 2 * o.m_halo; pe.m_plane = (int64_t)(o.OH + 2 * o.m_halo) * pe.m_wp;
     static bool attr_set = false;
-    auto kern = BM == 128 ? conv_dma_kernel<SR> : conv_dma48_kernel;
+    auto kern = BM == 128 ? conv_dma_kernel<SR> : conv_dma16_kernel<BM == 128 ? 3 : BM / 16>;
     if (!attr_set) {
         VL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
@@ -1516,7 +1525,11 @@ static int dispatch_conv(const ConvGeom& g, const float* w, int64_t w_ld, int w_
     if (PADDED && g.K % KBLK == 0 && ceil_div(Cog, 48) * 48 < w64 && ceil_div(Cog, 48) * 48 < w96 &&
         (int64_t)g.K * w_ld * 4 < MAX_BUF_BYTES && getenv("VL_CONV_STAGED") == nullptr)
         return launch_conv_dma<48>(g, w, w_ld, w_grp_stride, row_tab, Cog, Cout_total, o, s);
-    if (w96 <= w64) return launch_conv<96, 1, 4, PADDED>(g, w, w_ld, w_grp_stride, row_tab, Cog, Cout_total, o, s);
+    if (w96 <= w64) {
+        if (PADDED && g.K % KBLK == 0 && (int64_t)g.K * w_ld * 4 < MAX_BUF_BYTES && getenv("VL_CONV_STAGED") == nullptr)
+            return launch_conv_dma<96>(g, w, w_ld, w_grp_stride, row_tab, Cog, Cout_total, o, s);
+        return launch_conv<96, 1, 4, PADDED>(g, w, w_ld, w_grp_stride, row_tab, Cog, Cout_total, o, s);
+    }
     return launch_conv<64, 1, 4, PADDED>(g, w, w_ld, w_grp_stride, row_tab, Cog, Cout_total, o, s);
 }
 
