@@ -947,8 +947,11 @@ __global__ __launch_bounds__(NT, 64 / SR) void conv_dma_kernel(const ConvDmaPara
         const int rr = f >> 2, kind = f & 3, hf = kind & 1;
         const int z = st * g.zero;
         const uint32_t row_lds = lds0 + (uint32_t)(nb * BUF + (wrow + rr) * 128 + hf * 64 + z) * 4u;
-        if (kind < 2) lds_dma_row(rs_w, row_lds, blk_ok ? voff_a[hf] : OOB_OFF, (row0 + rr) * ld_bytes);
-        else lds_dma_row(rs_x, row_lds + ABUF * 4u, blk_ok ? voff_b[hf] : OOB_OFF, tabv[rr]);
+        // reduction positions past K (the tail of a last, partial 16-block; whole blocks past the end): the im2col side
+        // fetches zeros (range check) and the weight side re-reads row K - 1, so the product is exactly 0 and stays in bounds
+        const bool live = blk_ok && st * SR + wrow + rr < g.K;
+        if (kind < 2) lds_dma_row(rs_w, row_lds, voff_a[hf], min(row0 + rr, g.K - 1) * ld_bytes);
+        else lds_dma_row(rs_x, row_lds + ABUF * 4u, live ? voff_b[hf] : OOB_OFF, tabv[rr]);
     };
     auto finish_stage = [&]() {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1378,12 +1381,13 @@ __global__ __launch_bounds__(NT, 2) void conv_dma16_kernel(const ConvDmaParams p
     auto dma = [&](const int nb, const int f, int st) {                // f = FPR rr + {weight row pieces, then the two im2col halves}
         const int rr = f / FPR, kind = f % FPR;
         const int z = st * g.zero;
+        const bool live = blk_ok && st * SR + wrow + rr < g.K;         // positions past K: see conv_dma_kernel
         if (kind < NA) {
-            lds_dma_row(rs_w, lds0 + (uint32_t)(nb * BUF + (wrow + rr) * SA + kind * 64 + z) * 4u, blk_ok ? voff_a[kind] : OOB_OFF,
-                        (row0 + rr) * ld_bytes);
+            lds_dma_row(rs_w, lds0 + (uint32_t)(nb * BUF + (wrow + rr) * SA + kind * 64 + z) * 4u, voff_a[kind],
+                        min(row0 + rr, g.K - 1) * ld_bytes);
         } else {
             const int hf = kind - NA;
-            lds_dma_row(rs_x, lds0 + (uint32_t)(nb * BUF + ABUF + (wrow + rr) * SB + hf * 64 + z) * 4u, blk_ok ? voff_b[hf] : OOB_OFF,
+            lds_dma_row(rs_x, lds0 + (uint32_t)(nb * BUF + ABUF + (wrow + rr) * SB + hf * 64 + z) * 4u, live ? voff_b[hf] : OOB_OFF,
                         tabv[rr]);
         }
     };
@@ -1516,17 +1520,17 @@ static int dispatch_conv(const ConvGeom& g, const float* w, int64_t w_ld, int w_
     // output-channel tile: 128 when it divides well, else 96 (conv1: 96, conv4: 192) or 64 (conv2 dgrad: 48)
     const int w128 = ceil_div(Cog, 128) * 128, w96 = ceil_div(Cog, 96) * 96, w64 = ceil_div(Cog, 64) * 64;
     if (w128 <= w96 && w128 <= w64) {
-        // 128-wide tiles in the padded layout with a 16-blocked reduction (K % 16 == 0): the LDS-DMA kernel
-        if (PADDED && g.K % KBLK == 0 && (int64_t)g.K * w_ld * 4 < MAX_BUF_BYTES && getenv("VL_CONV_STAGED") == nullptr)
+        // 128-wide tiles in the padded layout: the LDS-DMA kernel
+        if (PADDED && (int64_t)g.K * w_ld * 4 < MAX_BUF_BYTES && getenv("VL_CONV_STAGED") == nullptr)
             return launch_conv_dma<128>(g, w, w_ld, w_grp_stride, row_tab, Cog, Cout_total, o, s);
         return launch_conv<128, 2, 2, PADDED>(g, w, w_ld, w_grp_stride, row_tab, Cog, Cout_total, o, s);
     }
     // 48-wide tiles beat the 64-wide ones whenever they waste fewer rows (conv2 dgrad: 48 channels per group)
-    if (PADDED && g.K % KBLK == 0 && ceil_div(Cog, 48) * 48 < w64 && ceil_div(Cog, 48) * 48 < w96 &&
+    if (PADDED && ceil_div(Cog, 48) * 48 < w64 && ceil_div(Cog, 48) * 48 < w96 &&
         (int64_t)g.K * w_ld * 4 < MAX_BUF_BYTES && getenv("VL_CONV_STAGED") == nullptr)
         return launch_conv_dma<48>(g, w, w_ld, w_grp_stride, row_tab, Cog, Cout_total, o, s);
     if (w96 <= w64) {
-        if (PADDED && g.K % KBLK == 0 && (int64_t)g.K * w_ld * 4 < MAX_BUF_BYTES && getenv("VL_CONV_STAGED") == nullptr)
+        if (PADDED && (int64_t)g.K * w_ld * 4 < MAX_BUF_BYTES && getenv("VL_CONV_STAGED") == nullptr)
             return launch_conv_dma<96>(g, w, w_ld, w_grp_stride, row_tab, Cog, Cout_total, o, s);
         return launch_conv<96, 1, 4, PADDED>(g, w, w_ld, w_grp_stride, row_tab, Cog, Cout_total, o, s);
     }
