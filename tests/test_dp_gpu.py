@@ -1,0 +1,74 @@
+"""Data-parallel train step END TO END on the device: two ranks (both on cuda:0, gloo backend -- RCCL refuses two ranks on one
+GPU, and the box has one) each run LRCNEngine.train_step on their half of the clips with the bucketed gradient all-reduce
+inside; the updated parameters must equal those of ONE engine stepping on all the clips (N-rank == 1-rank).
+Exercises what the CPU gloo test cannot: the 1/(rows*world) loss scaling in softmax_xent, the bucket boundaries in the flat
+gradient buffer, the async reduce overlapping the conv backward launches, wait() before the global-norm clip."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from oracle import lrcn_oracle as O
+
+pytestmark = pytest.mark.gpu
+MEAN = np.array([99.197148, 105.293620, 109.503945], np.float32)
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from vltf_amd import dp
+    from vltf_amd.engine import LRCNEngine, NetConfig
+    r, w, _ = dp.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    shape, ncls, fpc, clips, hid = (67, 67, 3), 5, 2, 4, 6
+    cfg = NetConfig(image_shape=shape, num_classes=ncls, fpc=fpc, lstm_hidden=hid)
+    rng = np.random.default_rng(11)                                  # identical on every rank
+    p = O.init_params(rng, ncls, "fc6", hid, 1, shape, well_scaled=True)
+    frames = rng.integers(0, 256, (clips * fpc,) + shape, dtype=np.uint8)
+    onehot = O.labels_to_one_hot([[l] for l in rng.integers(0, ncls, clips)], ncls)
+    lo, hi = dp.shard_range(clips, rank, world)
+    gar = dp.GradAllReduce()
+    eng = LRCNEngine(cfg, max_clips=hi - lo, device="cuda:0", dp=gar)
+    eng.load_params(p)
+    gar.broadcast_params(eng.w)
+    out = eng.train_step_u8(torch.tensor(frames[lo * fpc:hi * fpc], device="cuda:0"), torch.tensor(onehot[lo:hi], device="cuda:0"),
+                            lr=0.05, clip_norm=0.5, mean_bgr=MEAN)
+    got = eng.get_params()
+    if rank == 0:
+        ref = LRCNEngine(cfg, max_clips=clips, device="cuda:0")       # one engine, all the clips
+        ref.load_params(p)
+        want_out = ref.train_step_u8(torch.tensor(frames, device="cuda:0"), torch.tensor(onehot, device="cuda:0"), lr=0.05,
+                                     clip_norm=0.5, mean_bgr=MEAN)
+        want = ref.get_params()
+        err = {k: float(np.abs(got[k] - want[k]).max() / (np.abs(want[k] - p[k]).max() + 1e-12)) for k in want}
+        q.put(("ok", max(err.values()), abs(out["grad_norm"] - want_out["grad_norm"]) / want_out["grad_norm"]))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_step_equals_one_rank():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=worker, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    for pr in procs:
+        pr.join(300)
+        assert pr.exitcode == 0, "rank exited with %s" % pr.exitcode
+    tag, worst, gn_err = q.get(timeout=10)
+    # the UPDATE (new - old parameter) of every tensor agrees to 1e-3 of its largest element (measured 3e-4: the update of a
+    # bias is ~1e-4 of the parameter, so one fp32 ulp of the parameter is already ~1e-4 of the update); the global gradient
+    # norm agrees to fp32 rounding.  The only difference between the two runs is the summation order across the batch halves.
+    assert tag == "ok" and worst < 1e-3 and gn_err < 1e-5, (worst, gn_err)
