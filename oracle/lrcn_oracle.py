@@ -245,7 +245,7 @@ def truncated_normal(rng, shape, stddev):
 
 
 def init_params(rng, num_classes=101, final_layer="fc6", lstm_hidden=256, lstm_layers=1,
-                image_shape=(227, 227, 3), classifier="lstm", stddev=0.05, well_scaled=False):
+                image_shape=(227, 227, 3), classifier="lstm", stddev=0.05, well_scaled=False, fusion="avg"):
     """Reference initialisers: conv/fc W ~ truncated_normal(0.05), b = 0.1 (alexnet.py:40-46,
     tf_util.py:44-45); BasicLSTMCell kernel glorot-uniform, bias 0 (TF default initialiser).
     ``well_scaled`` replaces sigma by sqrt(2/fan_in) so activations stay O(1)."""
@@ -267,9 +267,12 @@ def init_params(rng, num_classes=101, final_layer="fc6", lstm_hidden=256, lstm_l
             p["rnn/multi_rnn_cell/cell_%d/basic_lstm_cell/bias" % l] = np.zeros(4 * lstm_hidden, np.float32)
             d = lstm_hidden
         if lstm_hidden != num_classes:
+            # fusion `state` (lstm.py:81-93, model.py:137-141): the logits are the final h of the last layer mapped by
+            # convert_dim_fc under its DEFAULT name "fc_convert"; every other fusion maps the pooled outputs with "output_fc"
+            name = "fc_convert" if fusion == "state" else "output_fc"
             sd = math.sqrt(2.0 / lstm_hidden) if well_scaled else stddev
-            p["output_fc_w"] = truncated_normal(rng, (lstm_hidden, num_classes), sd)
-            p["output_fc_b"] = np.full(num_classes, 0.1, np.float32)
+            p[name + "_w"] = truncated_normal(rng, (lstm_hidden, num_classes), sd)
+            p[name + "_b"] = np.full(num_classes, 0.1, np.float32)
     elif classifier == "fc" and dim != num_classes:
         sd = math.sqrt(2.0 / dim) if well_scaled else stddev
         p["fc_convert_w"] = truncated_normal(rng, (dim, num_classes), sd)
@@ -495,10 +498,13 @@ def lrcn_forward(p, frames, fpc, final_layer="fc6", lstm_layers=1, fusion="avg",
             x, _, lc = lstm_layer_forward(x, p["rnn/multi_rnn_cell/cell_%d/basic_lstm_cell/kernel" % l],
                                           p["rnn/multi_rnn_cell/cell_%d/basic_lstm_cell/bias" % l], dtype=dtype)
             lcaches.append(lc)
-        fused = temporal_fusion(x, fusion)                     # lstm.py:83
+        # fusion `state`: lstm_state[-1].h (model.py:137-138) = the last layer's output at t = T-1 (dynamic_rnn with full
+        # sequence lengths, lstm.py:136), no dropout, then convert_dim_fc("fc_convert") (model.py:140-141)
+        fused = temporal_fusion(x, "last" if fusion == "state" else fusion)    # lstm.py:83
         cache.update(lstm=lcaches, seq_shape=x.shape, fused=fused)
-        if "output_fc_w" in p:
-            logits = xw_plus_b(fused, p["output_fc_w"], p["output_fc_b"], dtype)   # lstm.py:88-90
+        head = "fc_convert" if fusion == "state" else "output_fc"
+        if head + "_w" in p:
+            logits = xw_plus_b(fused, p[head + "_w"], p[head + "_b"], dtype)   # lstm.py:88-90
         else:
             logits = fused
     else:  # classifier fc (model.py:115-119) with optional early/late frame fusion (model.py:103-106,149-151)
@@ -517,11 +523,12 @@ def lrcn_backward(p, cache, dlogits, fpc, final_layer="fc6", lstm_layers=1, fusi
     """Gradients of lrcn_forward (classifier lstm) wrt every parameter."""
     g = {}
     d = dlogits.astype(dtype)
-    if "output_fc_w" in p:
-        g["output_fc_w"] = cache["fused"].T @ d
-        g["output_fc_b"] = d.sum(0)
-        d = d @ p["output_fc_w"].astype(dtype).T
-    d = temporal_fusion_grad(cache["seq_shape"], fusion, d)
+    head = "fc_convert" if fusion == "state" else "output_fc"
+    if head + "_w" in p:
+        g[head + "_w"] = cache["fused"].T @ d
+        g[head + "_b"] = d.sum(0)
+        d = d @ p[head + "_w"].astype(dtype).T
+    d = temporal_fusion_grad(cache["seq_shape"], "last" if fusion == "state" else fusion, d)
     for l in reversed(range(lstm_layers)):
         kname = "rnn/multi_rnn_cell/cell_%d/basic_lstm_cell/kernel" % l
         d, dk, db, _, _ = lstm_layer_backward(p[kname], cache["lstm"][l], d, dtype=dtype)

@@ -21,10 +21,11 @@ def make(cfg_kw, shape, b, seed=0, max_clips=None):
 
 def oracle_params(rng, cfg, shape):
     return O.init_params(rng, cfg.num_classes, cfg.frame_encoding_layer, cfg.lstm_hidden, cfg.lstm_layers, shape,
-                         classifier=cfg.classifier, well_scaled=True)
+                         classifier=cfg.classifier, well_scaled=True, fusion=cfg.fusion)
 
 
-@pytest.mark.parametrize("layer,layers,fusion,hid", [("fc6", 1, "avg", 8), ("fc7", 2, "last", 12), ("fc8", 1, "avg", 7)])
+@pytest.mark.parametrize("layer,layers,fusion,hid", [("fc6", 1, "avg", 8), ("fc7", 2, "last", 12), ("fc8", 1, "avg", 7),
+                                                     ("fc6", 2, "state", 9)])
 def test_train_step_small(layer, layers, fusion, hid):
     rng = np.random.default_rng(5)
     shape, ncls, fpc, b = (67, 67, 3), 7, 3, 2

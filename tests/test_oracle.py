@@ -150,17 +150,18 @@ def torch_lrcn(p, frames, fpc, final_layer, lstm_layers, fusion):
     for l in range(lstm_layers):
         x, _, _ = torch_lstm(x, p["rnn/multi_rnn_cell/cell_%d/basic_lstm_cell/kernel" % l],
                              p["rnn/multi_rnn_cell/cell_%d/basic_lstm_cell/bias" % l])
-    f = x.mean(1) if fusion == "avg" else x[:, -1]
-    return f @ p["output_fc_w"] + p["output_fc_b"]
+    f = x.mean(1) if fusion == "avg" else x[:, -1]              # `state`: final h of the last layer = its output at T-1
+    head = "fc_convert" if fusion == "state" else "output_fc"  # model.py:137-141 vs lstm.py:88-90
+    return f @ p[head + "_w"] + p[head + "_b"]
 
 
-@pytest.mark.parametrize("final_layer,layers,fusion", [("fc6", 1, "avg"), ("fc7", 2, "last")])
+@pytest.mark.parametrize("final_layer,layers,fusion", [("fc6", 1, "avg"), ("fc7", 2, "last"), ("fc6", 2, "state")])
 def test_lrcn_train_step_vs_autograd(final_layer, layers, fusion):
     """End-to-end: tiny 67x67 frames, 2 clips x 3 frames; logits, grads, clipped SGD step."""
     rng = np.random.default_rng(5)
     shape = (67, 67, 3)
     ncls, fpc, b = 7, 3, 2
-    p = O.init_params(rng, ncls, final_layer, 8, layers, shape, well_scaled=True)
+    p = O.init_params(rng, ncls, final_layer, 8, layers, shape, well_scaled=True, fusion=fusion)
     frames = (rng.integers(0, 256, (b * fpc,) + shape).astype(np.float32) - 104.0)
     lab = rng.integers(0, ncls, b)
     onehot = O.labels_to_one_hot([[l] for l in lab], ncls)

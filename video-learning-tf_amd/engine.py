@@ -45,7 +45,7 @@ class NetConfig:
     classifier: str = "lstm"                    # defs.classifier.{lstm, fc}
     lstm_hidden: int = 256
     lstm_layers: int = 1
-    fusion: str = "avg"                         # lstm_params[2]: defs.fusion_method.{avg, last}
+    fusion: str = "avg"                         # lstm_params[2]: defs.fusion_method.{avg, last, state}
     frame_fusion: Optional[Tuple[str, str]] = None   # classifier fc: (early|late, avg|last) (model.py:103-106,149-151)
     dropout_keep_prob: float = 0.0              # <= 0 disables (lstm.py:52)
     optimizer: str = "sgd"                      # defs.optim.{sgd, adam}
@@ -71,7 +71,9 @@ def param_specs(cfg: NetConfig):
     dim = cfg.encode_dim()
     if cfg.classifier == "lstm":
         if cfg.lstm_hidden != cfg.num_classes:
-            specs += [("output_fc_w", (cfg.lstm_hidden, cfg.num_classes)), ("output_fc_b", (cfg.num_classes,))]
+            # fusion `state`: logits = convert_dim_fc(final h) under its default name (model.py:137-141), else "output_fc" (lstm.py:90)
+            head = "fc_convert" if cfg.fusion == "state" else "output_fc"
+            specs += [(head + "_w", (cfg.lstm_hidden, cfg.num_classes)), (head + "_b", (cfg.num_classes,))]
         d = dim
         for l in range(cfg.lstm_layers):
             pre = "rnn/multi_rnn_cell/cell_%d/basic_lstm_cell/" % l
@@ -225,8 +227,11 @@ class LRCNEngine:
             self.dfeat = self.df8 if self.df8 is not None else (self.df7 if self.df7 is not None else self.df6)
         # ---- classifier
         if cfg.classifier == "lstm":
-            if cfg.fusion not in ops.FUSION_CODE:
-                raise VltfError("lstm fusion [%s] is not built (avg | last)" % cfg.fusion)
+            if cfg.fusion not in ops.FUSION_CODE and cfg.fusion != "state":
+                raise VltfError("lstm fusion [%s] is not built (avg | last | state)" % cfg.fusion)
+            # `state` = final h of the last layer = its output at t = T-1 (full-length sequences, lstm.py:136), no dropout
+            self.lstm_fusion = "last" if cfg.fusion == "state" else cfg.fusion
+            self.head = "fc_convert" if cfg.fusion == "state" else "output_fc"
             self.lstm = []
             for l in range(cfg.lstm_layers):
                 S = dict(gx=buf(N, 4 * H), act=buf(N, 4 * H), cseq=buf(N, H), hseq=buf(N, H), hprev=buf(N, H))
@@ -373,15 +378,15 @@ class LRCNEngine:
                         ops.lstm_step_fwd(S["gx"], self.gh if t > 0 else None, S["act"], S["cseq"], S["hseq"], S["hprev"], b, T,
                                           t, H, FORGET_BIAS)
                 xin, d = S["hseq"], H
-            ops.temporal_fusion_fwd(xin, self.fused, b, T, H, cfg.fusion)
+            ops.temporal_fusion_fwd(xin, self.fused, b, T, H, self.lstm_fusion)
             v = self.fused
-            self._dropout = train and cfg.dropout_keep_prob > 0
+            self._dropout = train and cfg.dropout_keep_prob > 0 and cfg.fusion != "state"
             if self._dropout:
                 ops.dropout_fwd(self.fused[:b], self.dropped[:b], self.drop_mask[:b], cfg.dropout_keep_prob,
                                 (self.step_count << 20) ^ 0x5DEECE66D)
                 v = self.dropped
             if H != C:
-                ops.gemm(v, P["output_fc_w"], self.logits, b, C, H, bias=P["output_fc_b"])
+                ops.gemm(v, P[self.head + "_w"], self.logits, b, C, H, bias=P[self.head + "_b"])
             elif v is not self.logits:
                 self.logits[:b].copy_(v[:b])
             self._rows = b
@@ -418,15 +423,15 @@ class LRCNEngine:
             d = self.dlogits
             if H != C:
                 v = self.dropped if self._dropout else self.fused
-                ops.gemm(v, self.dlogits, G["output_fc_w"], H, C, b, transa=True)
-                ops.colsum(self.dlogits, G["output_fc_b"], sw, b, C)
-                ops.gemm(self.dlogits, P["output_fc_w"], self.ddropped, b, H, C, transb=True)
+                ops.gemm(v, self.dlogits, G[self.head + "_w"], H, C, b, transa=True)
+                ops.colsum(self.dlogits, G[self.head + "_b"], sw, b, C)
+                ops.gemm(self.dlogits, P[self.head + "_w"], self.ddropped, b, H, C, transb=True)
                 d = self.ddropped
             if self._dropout:
                 ops.dropout_bwd(d[:b], self.drop_mask[:b], self.dfused[:b], cfg.dropout_keep_prob)
                 d = self.dfused
             top = self.lstm[-1]
-            ops.temporal_fusion_bwd(d, top["dout"], b, T, H, cfg.fusion)
+            ops.temporal_fusion_bwd(d, top["dout"], b, T, H, self.lstm_fusion)
             for l in reversed(range(cfg.lstm_layers)):
                 S = self.lstm[l]
                 pre = "rnn/multi_rnn_cell/cell_%d/basic_lstm_cell/" % l
