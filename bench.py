@@ -56,30 +56,43 @@ def committed_traffic(symbol_prefix):
     return None, None
 
 
-def cpu_baseline(clips, fpc, num_classes):
-    """The oracle (kind 'port': numpy restatement of the reference's TF-CPU op graph; TensorFlow itself is
-    not installable here) timed on this box's host cores on a bounded sample of the same workload."""
-    from oracle import lrcn_oracle as O
-    rng = np.random.default_rng(2)
-    p = O.init_params(rng, num_classes, "fc6", 256, 1, (227, 227, 3))
-    frames = np.random.default_rng(0).integers(0, 256, (clips * fpc, 227, 227, 3), dtype=np.uint8)
-    x = frames.astype(np.float32) - MEAN_BGR
-    lab = np.random.default_rng(1).integers(0, num_classes, clips)
-    onehot = O.labels_to_one_hot([[l] for l in lab], num_classes)
-    t0 = time.time()
-    O.lrcn_train_step(p, x, onehot, fpc, lr=1e-3, clip_norm=10.0, dtype=np.float32, chunk=16)
-    dt = time.time() - t0
-    cores = None
-    try:   # threads the BLAS behind numpy actually used
-        from threadpoolctl import threadpool_info
-        cores = max([int(i.get("num_threads", 1)) for i in threadpool_info()] or [1])
-    except Exception:
+def host_cores():
+    """Cores this process may actually use: the scheduler affinity capped by the cgroup CPU quota (the GPU box shows 256
+    logical CPUs but grants 16 cores per GPU; 256 torch threads on that quota ran the baseline 25x slower)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
         pass
-    if not cores:
-        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
-    return {"value": clips / dt, "unit": "clips/s", "cores": cores, "kind": "port",
-            "sample": "%d clips x %d frames 227x227, one train step (fwd+bwd+clip+SGD), numpy fp32 oracle, %.1f s"
-                      % (clips, fpc, dt)}
+    return n
+
+
+def cpu_baseline(clips, fpc, num_classes):
+    """The CPU restatement of the reference's op graph (kind 'port': TensorFlow itself is not installable here) timed on this
+    box's host cores on a bounded sample of the same workload: oracle/torch_cpu.py (torch functional ops + autograd, fp32,
+    oneDNN/MKL on every core) -- the multi-threaded form of the oracle, pinned against the numpy oracle in tests/test_oracle.py.
+    One untimed step, then whole steps until ~12 s have passed."""
+    from oracle import lrcn_oracle as O
+    from oracle import torch_cpu as TC
+    torch.set_num_threads(host_cores())
+    rng = np.random.default_rng(2)
+    p = {k: torch.tensor(v, dtype=torch.float32, requires_grad=True)
+         for k, v in O.init_params(rng, num_classes, "fc6", 256, 1, (227, 227, 3)).items()}
+    frames = np.random.default_rng(0).integers(0, 256, (clips * fpc, 227, 227, 3), dtype=np.uint8)
+    x = torch.from_numpy(frames.astype(np.float32) - MEAN_BGR)
+    lab = torch.from_numpy(np.random.default_rng(1).integers(0, num_classes, clips))
+    TC.train_step(p, x, lab, fpc, lr=1e-3, clip_norm=10.0)
+    steps, t0 = 0, time.time()
+    while steps < 1 or time.time() - t0 < 12.0:
+        TC.train_step(p, x, lab, fpc, lr=1e-3, clip_norm=10.0)
+        steps += 1
+    dt = time.time() - t0
+    return {"value": clips * steps / dt, "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d train steps (fwd+bwd+clip+SGD) of %d clips x %d frames 227x227, torch-CPU fp32 restatement of the "
+                      "reference's TF op graph, %.1f s" % (steps, clips, fpc, dt)}
 
 
 def main():
@@ -92,7 +105,7 @@ def main():
     ap.add_argument("--fpc", type=int, default=16)
     ap.add_argument("--classes", type=int, default=101)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-clips", type=int, default=8)
+    ap.add_argument("--cpu-clips", type=int, default=16)
     ap.add_argument("--dropout", type=float, default=0.0)
     args = ap.parse_args()
 

@@ -1,5 +1,5 @@
 """Cross-check of the numpy oracle (oracle/lrcn_oracle.py) against torch-CPU functional ops and
-autograd -- an independent implementation of the same TF-1.x op semantics.
+autograd (oracle/torch_cpu.py) -- an independent implementation of the same TF-1.x op semantics.
 The reference ships no golden vectors ("parity unpinned"), so this is what pins the oracle."""
 import numpy as np
 import pytest
@@ -7,6 +7,7 @@ import torch
 import torch.nn.functional as F
 
 from oracle import lrcn_oracle as O
+from oracle import torch_cpu as TC
 
 torch.set_num_threads(4)
 
@@ -15,14 +16,7 @@ def t(a):
     return torch.tensor(np.asarray(a), dtype=torch.float64)
 
 
-def torch_conv_same(x_nhwc, w_hwio, stride, group=1):
-    x = x_nhwc.permute(0, 3, 1, 2)
-    w = w_hwio.permute(3, 2, 0, 1)
-    kh, kw = w.shape[2], w.shape[3]
-    _, pt, pb = O.same_pad(x.shape[2], kh, stride)
-    _, pl, pr = O.same_pad(x.shape[3], kw, stride)
-    x = F.pad(x, (pl, pr, pt, pb))
-    return F.conv2d(x, w, stride=stride, groups=group).permute(0, 2, 3, 1)
+torch_conv_same = TC.conv_same
 
 
 @pytest.mark.parametrize("h,w,k,s,g,ci,co", [
@@ -88,19 +82,7 @@ def test_maxpool_fwd_bwd_first_argmax():
     assert dz[0, 0, 0, 0] == 1 and dz.sum() == 1
 
 
-def torch_lstm(x, kernel, bias):
-    b, tt, d = x.shape
-    hd = kernel.shape[1] // 4
-    h = torch.zeros(b, hd, dtype=torch.float64)
-    c = torch.zeros(b, hd, dtype=torch.float64)
-    outs = []
-    for s in range(tt):
-        z = torch.cat([x[:, s], h], 1) @ kernel + bias
-        i, j, f, o = z.chunk(4, 1)
-        c = c * torch.sigmoid(f + 1.0) + torch.sigmoid(i) * torch.tanh(j)
-        h = torch.tanh(c) * torch.sigmoid(o)
-        outs.append(h)
-    return torch.stack(outs, 1), c, h
+torch_lstm = TC.lstm
 
 
 def test_lstm_fwd_bwd():
@@ -136,23 +118,7 @@ def test_softmax_xent():
 
 
 def torch_lrcn(p, frames, fpc, final_layer, lstm_layers, fusion):
-    a = frames
-    for name, kh, kw, co, s, g in O.ALEXNET_CONVS:
-        a = torch.relu(torch_conv_same(a, p["dcnn/%sW" % name], s, g) + p["dcnn/%sb" % name])
-        if name in ("conv1", "conv2"):
-            a = F.local_response_norm(a.permute(0, 3, 1, 2), 5, alpha=1e-4, beta=0.75, k=1.0).permute(0, 2, 3, 1)
-        if name in ("conv1", "conv2", "conv5"):
-            a = F.max_pool2d(a.permute(0, 3, 1, 2), 3, 2).permute(0, 2, 3, 1)
-    a = torch.relu(a.reshape(a.shape[0], -1) @ p["dcnn/fc6W"] + p["dcnn/fc6b"])
-    if final_layer != "fc6":
-        a = torch.relu(a @ p["dcnn/fc7W"] + p["dcnn/fc7b"])
-    x = a.reshape(-1, fpc, a.shape[1])
-    for l in range(lstm_layers):
-        x, _, _ = torch_lstm(x, p["rnn/multi_rnn_cell/cell_%d/basic_lstm_cell/kernel" % l],
-                             p["rnn/multi_rnn_cell/cell_%d/basic_lstm_cell/bias" % l])
-    f = x.mean(1) if fusion == "avg" else x[:, -1]              # `state`: final h of the last layer = its output at T-1
-    head = "fc_convert" if fusion == "state" else "output_fc"  # model.py:137-141 vs lstm.py:88-90
-    return f @ p[head + "_w"] + p[head + "_b"]
+    return TC.lrcn_logits(p, frames, fpc, final_layer, lstm_layers, fusion)
 
 
 @pytest.mark.parametrize("final_layer,layers,fusion", [("fc6", 1, "avg"), ("fc7", 2, "last"), ("fc6", 2, "state")])
