@@ -953,6 +953,19 @@ __global__ __launch_bounds__(NT, 64 / SR) void conv_dma_kernel(const ConvDmaPara
         if (kind < 2) lds_dma_row(rs_w, row_lds, voff_a[hf], min(row0 + rr, g.K - 1) * ld_bytes);
         else lds_dma_row(rs_x, row_lds + ABUF * 4u, live ? voff_b[hf] : OOB_OFF, tabv[rr]);
     };
+    // Steady-state form of the same fetch: every reduction position of the target stage lies below K, so there is no liveness
+    // select (a VALU instruction per fetch, and each VALU instruction costs MFMA issue cycles) and the weight row's offset is a
+    // running scalar -- 4 scalar instructions per fetch, inside the shadow of one MFMA.  The general form serves the prologue
+    // and the last stage(s).
+    int a_soff = 0;
+    auto dma_fast = [&](const int nb, const int f, int st) {
+        const int rr = f >> 2, kind = f & 3, hf = kind & 1;
+        const uint32_t row_lds = lds0 + (uint32_t)(nb * BUF + (wrow + rr) * 128 + hf * 64 + st * g.zero) * 4u;
+        if (f == 0) a_soff = row0 * ld_bytes;
+        if (kind < 2) lds_dma_row(rs_w, row_lds, voff_a[hf], a_soff);
+        else lds_dma_row(rs_x, row_lds + ABUF * 4u, voff_b[hf], tabv[rr]);
+        if (kind == 1) a_soff += ld_bytes;
+    };
     auto finish_stage = [&]() {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -979,7 +992,7 @@ __global__ __launch_bounds__(NT, 64 / SR) void conv_dma_kernel(const ConvDmaPara
     const float* fa = ldsc + (lane >> 5) * 128 + wm * 64 + 2 * (lane & 31);
     const float* fb = ldsc + ABUF + (lane >> 5) * 128 + wn * 64 + (lane & 31);
 
-    auto stage = [&](const int cur, int st_next) {                    // MFMAs on buffer cur while stage st_next streams into the other
+    auto stage = [&](const int cur, const bool fast, int st_next) {   // MFMAs on buffer cur while stage st_next streams into the other
         float2 af[2], bf[2], an[2], bn[2];
         auto read_b = [&](int step) {                                 // pixel tiles: [0, 32) and [32, 64) of the wave's block
             const float* q = fb + cur * BUF + step * 256;
@@ -1005,7 +1018,10 @@ __global__ __launch_bounds__(NT, 64 / SR) void conv_dma_kernel(const ConvDmaPara
                 const int f = (t * 8 + m) * FPM;                     // FPM fetches in the shadow of each of the first NF / FPM MFMAs
                 if (f < NF) {
 #pragma unroll
-                    for (int e = 0; e < FPM; ++e) dma(cur ^ 1, f + e, st_next);
+                    for (int e = 0; e < FPM; ++e) {
+                        if (fast) dma_fast(cur ^ 1, f + e, st_next);
+                        else dma(cur ^ 1, f + e, st_next);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -1027,12 +1043,17 @@ __global__ __launch_bounds__(NT, 64 / SR) void conv_dma_kernel(const ConvDmaPara
         }
         finish_stage();
     };
+    // stages 0 .. nfull-1 lie entirely below K: a stage whose prefetch target is one of them runs the fast fetch form
+    const int nfull = g.K / SR;
     int st = 0;
-    for (; st + 1 < nstages; st += 2) {
-        stage(0, st + 1);
-        stage(1, st + 2);
+    for (; st + 2 < nfull; st += 2) {
+        stage(0, true, st + 1);
+        stage(1, true, st + 2);
     }
-    if (nstages & 1) stage(0, st + 1);
+    for (; st < nstages; ++st) {
+        if (st & 1) stage(1, false, st + 1);
+        else stage(0, false, st + 1);
+    }
 
     // ---- epilogue: NCHW (+ halo), bias, ReLU, ReluGrad mask
 #pragma unroll
@@ -1391,6 +1412,19 @@ __global__ __launch_bounds__(NT, 2) void conv_dma16_kernel(const ConvDmaParams p
                         tabv[rr]);
         }
     };
+    int a_soff = 0;
+    auto dma_fast = [&](const int nb, const int f, int st) {           // steady state: no liveness select, running weight-row offset
+        const int rr = f / FPR, kind = f % FPR;
+        const int z = st * g.zero;
+        if (f == 0) a_soff = row0 * ld_bytes;
+        if (kind < NA) {
+            lds_dma_row(rs_w, lds0 + (uint32_t)(nb * BUF + (wrow + rr) * SA + kind * 64 + z) * 4u, voff_a[kind], a_soff);
+        } else {
+            const int hf = kind - NA;
+            lds_dma_row(rs_x, lds0 + (uint32_t)(nb * BUF + ABUF + (wrow + rr) * SB + hf * 64 + z) * 4u, voff_b[hf], tabv[rr]);
+        }
+        if (kind == NA - 1) a_soff += ld_bytes;
+    };
     auto finish_stage = [&]() {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -1416,7 +1450,7 @@ __global__ __launch_bounds__(NT, 2) void conv_dma16_kernel(const ConvDmaParams p
     const float* fa = ldsc + (lane >> 4) * SA + (lane & 15);
     const float* fb = ldsc + ABUF + (lane >> 4) * SB + wave * 32 + (lane & 15);
 
-    auto stage = [&](const int cur, int st_next) {
+    auto stage = [&](const int cur, const bool fast, int st_next) {
         float af[2][TA], bf[2][2];
         auto read = [&](int step, float (&a)[TA], float (&b)[2]) {
             const float* pa_ = fa + cur * BUF + step * 4 * SA;
@@ -1437,7 +1471,8 @@ __global__ __launch_bounds__(NT, 2) void conv_dma16_kernel(const ConvDmaParams p
                 acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[c][a], bf[c][b], acc[a][b], 0, 0, 0);
                 const int f = t * NM + m;
                 if (f < NF) {
-                    dma(cur ^ 1, f, st_next);
+                    if (fast) dma_fast(cur ^ 1, f, st_next);
+                    else dma(cur ^ 1, f, st_next);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -1453,12 +1488,16 @@ __global__ __launch_bounds__(NT, 2) void conv_dma16_kernel(const ConvDmaParams p
         }
         finish_stage();
     };
+    const int nfull = g.K / SR;                                        // stages entirely below K (see conv_dma_kernel)
     int st = 0;
-    for (; st + 1 < nstages; st += 2) {
-        stage(0, st + 1);
-        stage(1, st + 2);
+    for (; st + 2 < nfull; st += 2) {
+        stage(0, true, st + 1);
+        stage(1, true, st + 2);
     }
-    if (nstages & 1) stage(0, st + 1);
+    for (; st < nstages; ++st) {
+        if (st & 1) stage(1, false, st + 1);
+        else stage(0, false, st + 1);
+    }
 
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
