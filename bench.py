@@ -117,6 +117,7 @@ def main():
     rank, world, local = dpmod.init_from_env()
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
+    local = local % torch.cuda.device_count()      # ranks beyond the visible GPUs share them (gloo rehearsal on a 1-GPU box only)
     dev = "cuda:%d" % local
     torch.cuda.set_device(local)
 
