@@ -210,7 +210,7 @@ def test_lrn(ops, n, h, w, c):
 
 
 @pytest.mark.parametrize("hwc", [False, True])
-@pytest.mark.parametrize("n,h,w,c", [(2, 9, 11, 3), (2, 13, 13, 16), (1, 57, 57, 5), (2, 28, 28, 7)])
+@pytest.mark.parametrize("n,h,w,c", [(2, 9, 11, 3), (2, 13, 13, 16), (1, 57, 57, 5), (2, 28, 28, 7), (3, 13, 13, 256), (2, 13, 13, 70)])
 def test_maxpool(ops, hwc, n, h, w, c):
     rng = np.random.default_rng(h + c)
     x = np.maximum(rng.standard_normal((n, h, w, c)), 0).astype(np.float32)           # ties at 0 like post-ReLU data
@@ -232,6 +232,11 @@ def test_maxpool(ops, hwc, n, h, w, c):
     close(nhwc(host(dx)), want, rtol=1e-6, atol_rel=1e-7)
     ops.maxpool_bwd(dyd, ad, dx, relu_mask=xd, hwc=hwc)
     close(nhwc(host(dx)), want * (x > 0), rtol=1e-6, atol_rel=1e-7)
+    if hwc:         # pool5 as the engine runs it: (h, w, c)-flat pooled tensors, dx = conv5's dy with a halo
+        dxh = torch.zeros((n, c, h + 2, w + 2), device=DEV)
+        ops.maxpool_bwd(dyd, ad, dxh, relu_mask=xd, hwc=True, dx_halo=1)
+        close(nhwc(host(dxh[:, :, 1:-1, 1:-1])), want * (x > 0), rtol=1e-6, atol_rel=1e-7)
+        assert float(dxh[:, :, 0].abs().max()) == 0 and float(dxh[:, :, :, -1].abs().max()) == 0
     if not hwc:     # haloed pool output (feeds a conv) and haloed dx (is a conv's dy)
         yp = torch.zeros((n, c, oh + 4, ow + 4), device=DEV)
         ap = torch.zeros(yp.shape, dtype=torch.uint8, device=DEV)

@@ -755,6 +755,54 @@ extern "C" int vl_maxpool_fwd(const float* x, float* y, uint8_t* argmax, int n, 
     return 0;
 }
 
+// pool5's backward (3x3 / 2, pooled tensor stored (h, w, c)-flat for fc6, input gradient NCHW): in the generic kernel above a
+// wave walks input columns, so its <= 4 pooled neighbours are c * 4 bytes apart -- every byte / float of the pooled tensors is
+// its own cache line.  Here a workgroup stages the pooled gradient and arg-max of CB channels of one image through LDS
+// (coalesced along c, which is contiguous in the source), then writes the NCHW planes coalesced along the pixels.
+template <int CB>
+__global__ __launch_bounds__(256) void maxpool_bwd_hwc_k3s2_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ arg,
+                                                                   float* __restrict__ dx, const float* __restrict__ mask, int C, int H,
+                                                                   int W, int OH, int OW, int halo) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char pl_smem[];
+    const int OHW = OH * OW, HW = H * W;
+    float* sdy = reinterpret_cast<float*>(pl_smem);                    // [CB][OHW + 1]
+    uint8_t* sarg = pl_smem + (size_t)CB * (OHW + 1) * sizeof(float);   // [CB][OHW + 1]
+    const int img = blockIdx.y, c0 = blockIdx.x * CB;
+    const float* dyp = dy + (int64_t)img * OHW * C;
+    const uint8_t* ap = arg + (int64_t)img * OHW * C;
+    for (int e = threadIdx.x; e < CB * OHW; e += 256) {
+        const int p = e / CB, cl = e - p * CB;                        // lanes walk c: contiguous in the (h, w, c) source
+        const bool ok = c0 + cl < C;
+        sdy[cl * (OHW + 1) + p] = ok ? dyp[(int64_t)p * C + c0 + cl] : 0.f;
+        sarg[cl * (OHW + 1) + p] = ok ? ap[(int64_t)p * C + c0 + cl] : (uint8_t)255;
+    }
+    __syncthreads();
+    const int wp = W + 2 * halo;
+    const int64_t pp = (int64_t)(H + 2 * halo) * wp;
+    for (int e = threadIdx.x; e < CB * HW; e += 256) {
+        const int cl = e / HW, p = e - cl * HW;
+        if (c0 + cl >= C) break;
+        const int ih = p / W, iw = p - ih * W;
+        const int64_t plane = (int64_t)img * C + c0 + cl;
+        float acc = 0.f;
+        if (!mask || mask[plane * HW + p] > 0.f) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const int oh = (ih >> 1) - a, lr = (ih & 1) + 2 * a;
+                if (oh < 0 || oh >= OH || lr > 2) continue;
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const int ow = (iw >> 1) - b, lc = (iw & 1) + 2 * b;
+                    if (ow < 0 || ow >= OW || lc > 2) continue;
+                    const int o = cl * (OHW + 1) + oh * OW + ow;
+                    if ((int)sarg[o] == lr * 3 + lc) acc += sdy[o];
+                }
+            }
+        }
+        dx[plane * pp + (int64_t)(ih + halo) * wp + iw + halo] = acc;
+    }
+}
+
 extern "C" int vl_maxpool_bwd(const float* dy, const uint8_t* argmax, float* dx, const float* relu_mask, int n, int c, int h,
                               int w, int k, int s, int64_t ys_n, int64_t ys_c, int64_t ys_h, int64_t ys_w, int dx_halo,
                               vl_stream_t stream) {
@@ -762,6 +810,16 @@ extern "C" int vl_maxpool_bwd(const float* dy, const uint8_t* argmax, float* dx,
     const int oh = (h - k) / s + 1, ow = (w - k) / s + 1;
     const int64_t total = (int64_t)n * c * h * w;
     VL_CHECK(total < (1ll << 31), "vl_maxpool_bwd: tensor too large");
+    if (k == 3 && s == 2 && ys_c == 1 && ys_w == c && ys_h == (int64_t)ow * c && ys_n == (int64_t)oh * ow * c && n <= 65535 &&
+        (size_t)64 * (oh * ow + 1) * 5 <= 48 * 1024) {
+        // the (h, w, c)-flat pooled layout (pool5 -> fc6): LDS-transposed form
+        constexpr int CB = 64;
+        const size_t lds = (size_t)CB * (oh * ow + 1) * 5;
+        hipLaunchKernelGGL((maxpool_bwd_hwc_k3s2_kernel<CB>), dim3(ceil_div(c, CB), n), dim3(256), lds, (hipStream_t)stream, dy, argmax, dx,
+                           relu_mask, c, h, w, oh, ow, dx_halo);
+        VL_LAUNCH_CHECK();
+        return 0;
+    }
     const dim3 grid(grid_for(total, 256, 16384));
     const FastDiv d1 = make_fastdiv(h * w), d2 = make_fastdiv(w), d3 = make_fastdiv(c);
     if (k == 3 && s == 2)
