@@ -17,19 +17,25 @@ __global__ void input_prep_u8_kernel(const uint8_t* __restrict__ src, float* __r
                                      int ow, const int32_t* __restrict__ cy, const int32_t* __restrict__ cx,
                                      const uint8_t* __restrict__ mir, const float* __restrict__ mean, int halo, int phase) {
     // phase > 1: column-phase-split destination [c][phase][oh + 2 halo][ceil((ow + 2 halo) / phase)] (vl_conv_set_x_phase_split)
-    const int64_t plane = (int64_t)oh * ow, total = plane * n;
+    // Threads walk the DESTINATION: (image, row, phase, column within the phase plane), so a wave writes contiguous floats in
+    // each of the three channel planes; with one thread per source pixel the phase-split layout turned a wave's stores into
+    // 12 short segments.  The source bytes of a wave are then `phase` pixels apart (12 B), all within a few cache lines.
     const int wp = (ow + 2 * halo + phase - 1) / phase;
     const int64_t pp = (int64_t)(oh + 2 * halo) * wp;
+    const int64_t per_img = (int64_t)oh * phase * wp, total = per_img * n;
     const float m0 = mean ? mean[0] : 0.f, m1 = mean ? mean[1] : 0.f, m2 = mean ? mean[2] : 0.f;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int img = (int)(e / plane);
-        const int p = (int)(e - (int64_t)img * plane);
-        const int y = p / ow, x = p - y * ow;
+        const int img = (int)(e / per_img);
+        int r = (int)(e - (int64_t)img * per_img);
+        const int y = r / (phase * wp);
+        r -= y * phase * wp;
+        const int ph = r / wp, q = r - ph * wp;
+        const int x = q * phase + ph - halo;                          // physical column q * phase + ph of the haloed row
+        if (x < 0 || x >= ow) continue;                               // halo / padding columns stay zero
         const int sy = y + (cy ? cy[img] : 0);
         const int sx = ((mir && mir[img]) ? ow - 1 - x : x) + (cx ? cx[img] : 0);
         const uint8_t* s = src + (((int64_t)img * rh + sy) * rw + sx) * 3;
-        const int xc = x + halo;
-        float* d = dst + ((int64_t)img * 3 * phase + xc % phase) * pp + (int64_t)(y + halo) * wp + xc / phase;
+        float* d = dst + ((int64_t)img * 3 * phase + ph) * pp + (int64_t)(y + halo) * wp + q;
         d[0] = (float)s[0] - m0;
         d[phase * pp] = (float)s[1] - m1;
         d[2 * phase * pp] = (float)s[2] - m2;
@@ -41,7 +47,7 @@ extern "C" int vl_input_prep_u8(const uint8_t* src, float* dst, int n, int raw_h
                                 int dst_halo, int dst_phase, vl_stream_t stream) {
     VL_CHECK(src && dst && dst_halo >= 0 && dst_phase >= 1, "vl_input_prep_u8: bad argument");
     VL_CHECK(n > 0 && out_h > 0 && out_w > 0 && out_h <= raw_h && out_w <= raw_w, "vl_input_prep_u8: bad shape");
-    const int64_t total = (int64_t)n * out_h * out_w;
+    const int64_t total = (int64_t)n * out_h * dst_phase * ((out_w + 2 * dst_halo + dst_phase - 1) / dst_phase);
     hipLaunchKernelGGL(input_prep_u8_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, (hipStream_t)stream, src, dst, n,
                        raw_h, raw_w, out_h, out_w, crop_y, crop_x, mirror, mean_bgr, dst_halo, dst_phase);
     VL_LAUNCH_CHECK();
