@@ -27,6 +27,7 @@ import torch
 # forward MACs per frame; dgrad and wgrad of a layer have the same count
 CONV_MACS = {"conv1": 113221152, "conv2": 240844800, "conv3": 149520384, "conv4": 112140288, "conv5": 74760192}
 CLIP_TRAIN_FLOP = 2 * 33357755136          # T = 16, fc6 encode
+CLIP_FWD_FLOP = 2 * 11723097856            # forward only
 PEAK_FP32_MFMA_TFLOPS = 157.3              # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 # launches that share the single-kernel symbol conv_dma_kernel<32> (output-channel tile 128, LDS-DMA operand rows:
 # conv2/3/5 forward and conv3 dgrad, whose output channel count is 256)
@@ -168,6 +169,15 @@ def main():
     times = eng.probe_times_ms()
     eng.set_probe(None)
     out = eng.train_step_u8(frames, onehot, lr=1e-3, clip_norm=10.0, mean_bgr=MEAN_BGR, fetch=True)   # sanity, untimed
+    # forward only (sess.run(model.logits), run_task.py:95; SURVEY 8d asks for it beside the train step): per rank, untimed for `value`
+    for _ in range(2):
+        eng.forward_u8(frames, mean_bgr=MEAN_BGR)
+    torch.cuda.synchronize()
+    tf0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.forward_u8(frames, mean_bgr=MEAN_BGR)
+    torch.cuda.synchronize()
+    fwd_ms = (time.perf_counter() - tf0) / args.steps * 1e3
 
     total_clips = clips * world if scaling == "weak" else args.global_batch
     if gar is not None:
@@ -212,6 +222,9 @@ def main():
                                     "per_launch_ms": {k: round(v, 3) for k, v in sorted(avg.items())}},
                      "step_frac_of_mfma_roofline": round(value / world * CLIP_TRAIN_FLOP / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)
                      if args.fpc == 16 else None},
+        "forward_only": {"value": round(clips / (fwd_ms * 1e-3), 2), "unit": "clips/s per GPU", "ms_per_batch": round(fwd_ms, 3),
+                         "frac_of_mfma_roofline": round(clips / (fwd_ms * 1e-3) * CLIP_FWD_FLOP / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)
+                         if args.fpc == 16 else None},
         "check": {"loss": round(out["loss"], 4), "grad_norm": round(out["grad_norm"], 3)},
     }
     if world == 1 and not args.no_cpu_baseline:
