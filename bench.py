@@ -108,6 +108,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-clips", type=int, default=16)
     ap.add_argument("--dropout", type=float, default=0.0)
+    ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the extra strong-scaling measurement")
     args = ap.parse_args()
 
     from vltf_amd import dp as dpmod
@@ -179,6 +180,32 @@ def main():
     torch.cuda.synchronize()
     fwd_ms = (time.perf_counter() - tf0) / args.steps * 1e3
 
+    # N > 1, weak run: also time the STRONG-scaling form of the same job (BASELINE config 3: the reference's global batch of 64
+    # clips split over the ranks) -- reported beside `value`, never as `value`
+    strong = None
+    if world > 1 and scaling == "weak" and not args.no_strong:
+        gb = args.clips_per_gpu
+        lo, hi = dpmod.shard_range(gb, rank, world)
+        sc = hi - lo
+        if sc > 0:
+            eng_s = LRCNEngine(cfg, max_clips=sc, device=dev, dp=gar)
+            eng_s.load_params(init_params(cfg, seed=2))
+            f_s, o_s = frames[:sc * args.fpc], onehot[:sc]
+            for _ in range(args.warmup):
+                eng_s.train_step_u8(f_s, o_s, lr=1e-3, clip_norm=10.0, mean_bgr=MEAN_BGR, fetch=False)
+            torch.cuda.synchronize()
+            barrier()
+            ts0 = time.perf_counter()
+            for _ in range(args.steps):
+                eng_s.train_step_u8(f_s, o_s, lr=1e-3, clip_norm=10.0, mean_bgr=MEAN_BGR, fetch=False)
+            torch.cuda.synchronize()
+            barrier()
+            ts = torch.tensor([time.perf_counter() - ts0], dtype=torch.float64, device=dev)
+            torch.distributed.all_reduce(ts, op=torch.distributed.ReduceOp.MAX)
+            strong = {"global_batch": gb, "clips_per_gpu": sc, "value": round(gb * args.steps / float(ts.item()), 2), "unit": "clips/s",
+                      "ms_per_step": round(float(ts.item()) / args.steps * 1e3, 3)}
+            del eng_s
+
     total_clips = clips * world if scaling == "weak" else args.global_batch
     if gar is not None:
         tc = gar.sum_scalars(torch.tensor([float(clips)], device=dev))
@@ -225,6 +252,7 @@ def main():
         "forward_only": {"value": round(clips / (fwd_ms * 1e-3), 2), "unit": "clips/s per GPU", "ms_per_batch": round(fwd_ms, 3),
                          "frac_of_mfma_roofline": round(clips / (fwd_ms * 1e-3) * CLIP_FWD_FLOP / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)
                          if args.fpc == 16 else None},
+        "strong_scaling": strong,
         "check": {"loss": round(out["loss"], 4), "grad_norm": round(out["grad_norm"], 3)},
     }
     if world == 1 and not args.no_cpu_baseline:
