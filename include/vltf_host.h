@@ -29,6 +29,11 @@ uint32_t vlh_masked_crc32c(const void* data, size_t n);
  *   -3 CRC mismatch, -4 malformed Example / size mismatch.  records_read may be NULL. */
 int64_t vlh_read_frames(const char* path, int64_t offset, int count, int verify_crc, uint8_t* images, int64_t image_bytes,
                         int32_t* dims, int64_t* labels, int max_labels, int32_t* label_counts, int32_t* records_read);
+/* The same on `threads` threads (<= 64): the length headers are walked serially, the payload reads, checksums, Example parsing
+ * and image copies are split over the threads.  Same results, return value and error codes; threads <= 1 = vlh_read_frames. */
+int64_t vlh_read_frames_mt(const char* path, int64_t offset, int count, int verify_crc, uint8_t* images, int64_t image_bytes,
+                           int32_t* dims, int64_t* labels, int max_labels, int32_t* label_counts, int32_t* records_read,
+                           int threads);
 /* Skips `count` records by their headers only (resume fast-forward, dataset_.py:772-811); returns the new offset
  * or a negative code as above. */
 int64_t vlh_skip_records(const char* path, int64_t offset, int64_t count, int verify_crc);

@@ -38,7 +38,11 @@ def write_cfg(folder, name, data_path, phase, resume=None, epochs=2):
     return path
 
 
-def test_train_resume_validate(tmp_path):
+@pytest.mark.parametrize("prefetch", ["2", "0"])
+def test_train_resume_validate(tmp_path, monkeypatch, prefetch):
+    """prefetch 2: batches read and uploaded ahead of the loop by the feeder's background thread (the default);
+    prefetch 0: the reference's synchronous feed.  Same checkpoints, logs, resume behaviour and validation results."""
+    monkeypatch.setenv("VLTF_PREFETCH", prefetch)
     from vltf_amd import run_task
     folder = str(tmp_path)
     train_path, _, _ = make_dataset(folder, "train.txt", shape=RAW, seed=1)

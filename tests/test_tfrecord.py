@@ -122,6 +122,39 @@ def test_framing_roundtrip_and_native_reader(tmp_path):
         _hostio.read_frames(empty, 0, 1, (12, 10, 3))
 
 
+def test_threaded_native_reader_matches_serial(tmp_path):
+    """vlh_read_frames_mt: same images / labels / offsets / EOF accounting / first-error semantics as one thread."""
+    rng = np.random.default_rng(4)
+    n = 53
+    frames = rng.integers(0, 256, (n, 9, 8, 3), dtype=np.uint8)
+    labels = [[int(rng.integers(0, 300))] * (1 + i % 3) for i in range(n)]          # label >= 128: records differ in length
+    path = str(tmp_path / "m.tfrecord")
+    write_frames(path, frames, labels)
+    size = os.path.getsize(path)
+    for threads in (2, 3, 8, 64):
+        a = _hostio.read_frames(path, 0, 40, (9, 8, 3), threads=1)
+        b = _hostio.read_frames(path, 0, 40, (9, 8, 3), threads=threads)
+        assert np.array_equal(a[0], b[0]) and a[1] == b[1] == labels[:40] and a[2] == b[2]
+        c = _hostio.read_frames(path, b[2], 13, (9, 8, 3), threads=threads)
+        assert np.array_equal(c[0], frames[40:]) and c[2] == size
+        with pytest.raises(EOFError) as e:                          # ragged tail: 13 records left, 30 asked
+            _hostio.read_frames(path, b[2], 30, (9, 8, 3), threads=threads)
+        assert e.value.records_read == 13
+    raw = bytearray(open(path, "rb").read())
+    raw[a[2] + 12 + 40] ^= 0x01                                     # corrupt the payload of record 40
+    bad = str(tmp_path / "mbad.tfrecord")
+    open(bad, "wb").write(raw)
+    with pytest.raises(_hostio.HostIOError, match="record 40"):
+        _hostio.read_frames(bad, 0, n, (9, 8, 3), threads=8)
+    ok, _, _ = _hostio.read_frames(bad, 0, 40, (9, 8, 3), threads=8)   # the records before it are fine
+    assert np.array_equal(ok, frames[:40])
+    truncated = str(tmp_path / "mtrunc.tfrecord")
+    open(truncated, "wb").write(bytes(raw[:a[2] - 7]))               # cut inside record 39
+    with pytest.raises(EOFError) as e:
+        _hostio.read_frames(truncated, 0, 40, (9, 8, 3), threads=4)
+    assert e.value.records_read == 39
+
+
 def test_corruption_is_detected(tmp_path):
     frames = np.zeros((2, 4, 4, 3), np.uint8)
     path = str(tmp_path / "c.tfrecord")

@@ -16,5 +16,5 @@ for f in api mfma_gemm pointwise; do
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o "$out" "$here/obj/api.o" "$here/obj/mfma_gemm.o" "$here/obj/pointwise.o"
-gcc -O3 -msse4.2 -std=c11 -fPIC -shared -Wall -o "$here/../libvltf_host.so" "$here/host_io.c"
+gcc -O3 -msse4.2 -std=c11 -fPIC -shared -Wall -pthread -o "$here/../libvltf_host.so" "$here/host_io.c"
 echo "built $out and $here/../libvltf_host.so"

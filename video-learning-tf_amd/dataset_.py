@@ -136,13 +136,14 @@ class Dataset:
     def loop(self):
         return self.batch_index < len(self.batches)
 
-    def _read(self, count):
+    def _read(self, count, out=None):
         """deserialize_from_tfrecord (dataset_.py:171-217): on EOF mid-batch the reference rewinds and re-reads from
         the start of the file (reread_serialized, 219-230); parse errors are retried read_tries times."""
         tries = 0
         while True:
             try:
-                imgs, labels, self.offset = _hostio.read_frames(self.record_path, self.offset, count, self.raw_image_shape)
+                imgs, labels, self.offset = _hostio.read_frames(self.record_path, self.offset, count, self.raw_image_shape,
+                                                                out=None if out is None else out[:count])
                 return imgs, labels
             except EOFError as ex:
                 warning("Unexpected EOF after %d/%d records of the batch; rewinding the iterator" % (ex.records_read, count))
@@ -156,7 +157,11 @@ class Dataset:
                 if tries > self.read_tries:
                     error("Failed to troubleshoot serialization error.")
 
-    def get_next_batch(self):
+    def frames_in_batch(self, batch_index):
+        v0 = batch_index * self.batch_size
+        return sum(self.num_frames_per_clip * c for c in self.clips_per_video[v0:v0 + self.batch_size])
+
+    def get_next_batch(self, out=None):
         """get_next_batch_video_tfr (dataset_.py:386-420): batch = batch_size videos; reads sum(cpv)*fpc consecutive
         frame records; one label per clip (its first frame's).  Returns (frames uint8 [n,H,W,C] raw, crop_y, crop_x,
         mirror, onehot int32 [clips, classes])."""
@@ -166,7 +171,7 @@ class Dataset:
         n = sum(fpc * c for c in cpv)
         if not n:
             error("Computed 0 frames in next batch.")
-        frames, labels_per_frame = self._read(n)
+        frames, labels_per_frame = self._read(n, out)      # out: caller's (pinned) uint8 buffer [>= n, H, W, C]
         labels, first = [], 0
         for c in cpv:
             labels.extend([labels_per_frame[first]] * c)

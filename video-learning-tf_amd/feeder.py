@@ -2,12 +2,95 @@
 The feed dict of the reference (placeholder -> numpy) becomes a plain dict of device-ready arrays."""
 import os
 import pickle
+import queue
+import threading
 
 import numpy as np
 
 from . import dataset_
 from .defs_ import defs
 from .utils_ import debug, error, get_datetime_str, get_run_checkpoints, info, warning
+
+
+class BatchPrefetcher:
+    """Reads the remaining batches of the current epoch ahead of the training loop.
+
+    The reference feeds synchronously: parse a batch on the host, sess.run, repeat (run_task.py:25-81).  At the device's rate
+    that leaves the GPU idle more than half of the time: one 64-clip batch is 236 MB of records, ~45 ms to read and checksum on
+    one thread and 4 ms to upload, against a 37 ms train step.  Here a background thread produces batch k+1 .. k+depth while
+    batch k trains: the native reader (several threads) writes the frames straight into a pinned slot, the slot is uploaded on a
+    side stream, and the training loop receives device tensors plus the event that marks the upload done.
+    Everything order-dependent stays on the producer thread in batch order (record offsets, the per-frame crop / mirror draws
+    of dataset_.py:444-461), so a run is identical to the synchronous one.  `consumed` counts batches handed out: checkpoints
+    record it, not the read-ahead position."""
+
+    def __init__(self, dataset, device, depth=2):
+        import torch
+        self.torch, self.d, self.device, self.depth = torch, dataset, torch.device(device), max(1, int(depth))
+        self.consumed = dataset.batch_index
+        self.q, self.thread, self.stop_flag = None, None, None
+        h, w, c = dataset.raw_image_shape
+        nmax = max(dataset.frames_in_batch(b) for b in range(len(dataset.batches))) if dataset.batches else 0
+        self.slots = []
+        # batch j trains while j+1 .. j+depth wait in the queue and the producer fills j+depth+1: depth + 2 live batches
+        for _ in range(self.depth + 2):
+            self.slots.append({"pin": torch.empty((nmax, h, w, c), dtype=torch.uint8, pin_memory=True),
+                               "dev": torch.empty((nmax, h, w, c), dtype=torch.uint8, device=self.device)})
+        self.copy_stream = torch.cuda.Stream(device=self.device)
+
+    def _run(self, q, stop, first_slot):
+        torch, d = self.torch, self.d
+        torch.cuda.set_device(self.device)
+        k = first_slot
+        try:
+            while d.loop() and not stop.is_set():
+                slot = self.slots[k % len(self.slots)]
+                frames, cy, cx, mirror, onehot = d.get_next_batch(out=slot["pin"].numpy())
+                n = len(frames)
+                with torch.cuda.stream(self.copy_stream):
+                    slot["dev"][:n].copy_(slot["pin"][:n], non_blocking=True)
+                    dev = {key: torch.from_numpy(v).to(self.device, non_blocking=True)
+                           for key, v in (("crop_y", cy), ("crop_x", cx), ("mirror", mirror), ("labels", onehot))}
+                    ev = torch.cuda.Event()
+                    ev.record(self.copy_stream)
+                item = {"frames_u8": frames, "crop_y": cy, "crop_x": cx, "mirror": mirror, "labels": onehot, "mean_bgr": d.mean_bgr,
+                        "dataset": d, "batch_index": d.batch_index, "device": dict(dev, frames_u8=slot["dev"][:n]), "ready": ev}
+                k += 1
+                while not stop.is_set():
+                    try:
+                        q.put(item, timeout=0.1)
+                        break
+                    except queue.Full:
+                        pass
+            q.put(None)
+        except BaseException as ex:          # surfaces in the training loop, like a synchronous read error would
+            q.put(ex)
+
+    def next(self):
+        if self.thread is None:
+            self.q, self.stop_flag = queue.Queue(maxsize=self.depth), threading.Event()
+            self.thread = threading.Thread(target=self._run, args=(self.q, self.stop_flag, self.consumed), daemon=True)
+            self.thread.start()
+        item = self.q.get()
+        if isinstance(item, BaseException):
+            self.stop()
+            raise item
+        if item is None:
+            error("No batch left in this epoch.")
+        self.consumed += 1
+        return item
+
+    def stop(self):
+        """End of epoch / rewind: the producer has read exactly the epoch's batches (or is told to quit)."""
+        if self.thread is not None:
+            self.stop_flag.set()
+            while self.thread.is_alive():       # drain so a blocked put() returns
+                try:
+                    self.q.get_nowait()
+                except queue.Empty:
+                    pass
+                self.thread.join(0.05)
+            self.thread = None
 
 
 class Feeder:
@@ -20,6 +103,7 @@ class Feeder:
         self.save_freq_per_epoch = save_freq_per_epoch
         self.save_interval, self.num_saves = -1, 0
         self.saved = []
+        self.prefetch = None
 
     def add_dataset(self, dataset_phase, id, path, mean_image, prepend_folder, image_shape, imgproc, raw_image_shape, data_format,
                     frame_format, batch_item, num_classes, tag, read_tries, captioning_config=None):
@@ -43,6 +127,8 @@ class Feeder:
                 dset.calculate_batches(bs, self.input_mode)
 
     def loop(self):
+        if self.prefetch is not None:
+            return self.prefetch.consumed < self.get_num_batches()
         return self.datasets[self.phase][0].loop()
 
     def get_dataset_by_tag(self, tag):
@@ -55,14 +141,27 @@ class Feeder:
         return len(self.datasets[self.phase][0].batches) if self.datasets else -1
 
     def get_batch_index(self):
+        if self.prefetch is not None:
+            return self.prefetch.consumed       # batches handed to the training loop, not batches read ahead
         return self.datasets[self.phase][0].batch_index
 
     def get_batch_sizes(self):
         return [d.batch_size for d in self.datasets[self.phase]]
 
     def rewind_datasets(self):
+        if self.prefetch is not None:
+            self.prefetch.stop()
         for d in self.datasets[self.phase]:
             d.rewind()
+        if self.prefetch is not None:
+            self.prefetch.consumed = 0
+
+    def enable_prefetch(self, device, depth=2, tag=defs.dataset_tag.main):
+        """Read ahead of the training loop (BatchPrefetcher).  get_feed_dict / loop / get_batch_index keep their meaning."""
+        dsets = self.get_dataset_by_tag(tag)
+        if len(dsets) != 1:
+            error("%d datasets satisfy the network input requirement [%s], but exactly one must." % (len(dsets), tag))
+        self.prefetch = BatchPrefetcher(dsets[0], device, depth)
 
     def get_feed_dict(self, tag=defs.dataset_tag.main):
         """feeder.py:84-106: -> (fdict, num_data, num_labels, padding).  fdict holds the raw uint8 frames and the
@@ -71,9 +170,12 @@ class Feeder:
         if len(dsets) != 1:
             error("%d datasets satisfy the network input requirement [%s], but exactly one must." % (len(dsets), tag))
         d = dsets[0]
+        if self.prefetch is not None:
+            fdict = self.prefetch.next()
+            return fdict, [len(fdict["frames_u8"])], len(fdict["labels"]), 0
         frames, cy, cx, mirror, onehot = d.get_next_batch()
         fdict = {"frames_u8": frames, "crop_y": cy, "crop_x": cx, "mirror": mirror, "labels": onehot, "mean_bgr": d.mean_bgr,
-                 "dataset": d}
+                 "dataset": d, "batch_index": d.batch_index}
         return fdict, [len(frames)], len(onehot), 0
 
     # ---- save cadence (feeder.py:111-129) ---------------------------------------------------------------

@@ -22,7 +22,7 @@ def print_iter_info(settings, feeder, num_images, num_labels, padding):
     dataset = feeder.datasets[settings.phase][0]
     epoch_str = "" if settings.val else "epoch: %2d/%2d," % (settings.train.epoch_index + 1, settings.train.epochs)
     info("Mode: [%s], %s batch %4d / %4d : %s images, %3d labels" %
-         (settings.phase, epoch_str, dataset.batch_index, len(dataset.batches), str(num_images), num_labels))
+         (settings.phase, epoch_str, feeder.get_batch_index(), len(dataset.batches), str(num_images), num_labels))
 
 
 def net_config(settings, dataset):
@@ -54,13 +54,17 @@ def load_weights_file(path):
 def do_train(settings, train, feeder, engine):
     """run_task.py:25-81."""
     run_batch_count, min_train_loss = 0, (1000, -1)
+    fed_clips, fed_time = 0, 0.0          # feed + step time of every batch but the first (checkpoint writes excluded)
     info("Starting train")
     for _ in range(settings.train.epoch_index, settings.train.epochs):
         while feeder.loop():
+            tic = time.perf_counter()
             fdict, num_data, num_labels, padding = feeder.get_feed_dict()
             print_iter_info(settings, feeder, num_data, num_labels, padding)
             run_batch_count += 1
             batch_loss, learning_rate, settings.global_step = train.run_step(fdict)
+            if run_batch_count > 1:
+                fed_clips, fed_time = fed_clips + num_labels, fed_time + time.perf_counter() - tic
             if min_train_loss[0] > batch_loss:
                 min_train_loss = (batch_loss, settings.global_step)
             nats = batch_loss / math.log(settings.num_classes)
@@ -75,6 +79,8 @@ def do_train(settings, train, feeder, engine):
         settings.train.epoch_index += 1
         feeder.rewind_datasets()
     info("Minimum training loss: %2.2f on global index %d" % (min_train_loss[0], min_train_loss[1]))
+    if fed_time > 0:
+        info("Training throughput: %.1f clips/s over %d batches (input feed + train step)" % (fed_clips / fed_time, run_batch_count - 1))
     if run_batch_count > 0 and not feeder.should_save(run_batch_count):
         info("Saving model checkpoint out of turn, since training's finished.")
         feeder.save(engine, "ep_%d_btch_%d_gs_%d" % (1 + settings.train.epoch_index, feeder.get_num_batches(), settings.global_step),
@@ -89,9 +95,15 @@ def do_test(settings, val, feeder, engine):
     while feeder.loop():
         fdict, num_data, num_labels, padding = feeder.get_feed_dict()
         print_iter_info(settings, feeder, num_data, num_labels, padding)
-        logits = engine.forward_u8(torch.from_numpy(fdict["frames_u8"]).to(dev), fdict["mean_bgr"], torch.from_numpy(fdict["crop_y"]).to(dev),
-                                   torch.from_numpy(fdict["crop_x"]).to(dev), torch.from_numpy(fdict["mirror"]).to(dev)).cpu().numpy()
-        val.process_validation_logits(fdict["dataset"], settings, logits, fdict["labels"].astype(np.float32))
+        if "device" in fdict:            # read and uploaded ahead by the feeder's BatchPrefetcher
+            torch.cuda.current_stream(dev).wait_event(fdict["ready"])
+            t = fdict["device"]
+            logits = engine.forward_u8(t["frames_u8"], fdict["mean_bgr"], t["crop_y"], t["crop_x"], t["mirror"]).cpu().numpy()
+        else:
+            logits = engine.forward_u8(torch.from_numpy(fdict["frames_u8"]).to(dev), fdict["mean_bgr"],
+                                       torch.from_numpy(fdict["crop_y"]).to(dev), torch.from_numpy(fdict["crop_x"]).to(dev),
+                                       torch.from_numpy(fdict["mirror"]).to(dev)).cpu().numpy()
+        val.process_validation_logits(fdict["dataset"], settings, logits, fdict["labels"].astype(np.float32), fdict["batch_index"])
         val.save_validation_logits_chunk()
     val.save_validation_logits_chunk(save_all=True)
     accuracy = val.get_accuracy()
@@ -119,6 +131,8 @@ def main(init_file, seed=0, device=None):
         params.update({k: v for k, v in loaded.items() if k in params and not k.startswith("dcnn/fc8")})   # fc8 is re-initialised (alexnet.py:273)
     engine.load_params(params)
     feeder.init_saveload(engine, settings.resume_file)
+    if os.environ.get("VLTF_PREFETCH", "2") != "0":      # batches read + uploaded ahead of the loop (0 = the reference's synchronous feed)
+        feeder.enable_prefetch(engine.dev, depth=int(os.environ.get("VLTF_PREFETCH", "2")))
     if gar is not None:
         gar.broadcast_params(engine.w)
     result = None

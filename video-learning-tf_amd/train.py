@@ -60,11 +60,17 @@ class Train:
             error("global step %d exceeds the precomputed learning-rate table (%d)" % (self.global_step, len(self.learning_rates)))
         lr = float(self.learning_rates[self.global_step])
         dev = self.engine.dev
-        out = self.engine.train_step_u8(torch.from_numpy(fdict["frames_u8"]).to(dev, non_blocking=True),
-                                        torch.from_numpy(fdict["labels"]).to(dev),
-                                        lr, self.clip_norm, fdict["mean_bgr"],
-                                        torch.from_numpy(fdict["crop_y"]).to(dev), torch.from_numpy(fdict["crop_x"]).to(dev),
-                                        torch.from_numpy(fdict["mirror"]).to(dev))
+        if "device" in fdict:            # uploaded ahead of time by the feeder's BatchPrefetcher: wait for the copy on the stream
+            torch.cuda.current_stream(dev).wait_event(fdict["ready"])
+            t = fdict["device"]
+            out = self.engine.train_step_u8(t["frames_u8"], t["labels"], lr, self.clip_norm, fdict["mean_bgr"], t["crop_y"], t["crop_x"],
+                                            t["mirror"])
+        else:
+            out = self.engine.train_step_u8(torch.from_numpy(fdict["frames_u8"]).to(dev, non_blocking=True),
+                                            torch.from_numpy(fdict["labels"]).to(dev),
+                                            lr, self.clip_norm, fdict["mean_bgr"],
+                                            torch.from_numpy(fdict["crop_y"]).to(dev), torch.from_numpy(fdict["crop_x"]).to(dev),
+                                            torch.from_numpy(fdict["mirror"]).to(dev))
         self.global_step += 1
         self.last = out
         return out["loss"], lr, self.global_step

@@ -29,9 +29,10 @@ class Validation:
         self.item_logits = np.vstack((self.item_logits, video_logits))
         self.item_labels = np.vstack((self.item_labels, video_labels[0, :]))
 
-    def process_validation_logits(self, dataset, settings, logits, labels):
-        """val.py:59-113, video batch mode (the only working one in the reference)."""
-        maxvid = dataset.batch_index * dataset.batch_size
+    def process_validation_logits(self, dataset, settings, logits, labels, batch_index=None):
+        """val.py:59-113, video batch mode (the only working one in the reference).  batch_index: the dataset's batch index right
+        after THIS batch was read (the reference reads dataset.batch_index here; with a read-ahead feeder that has moved on)."""
+        maxvid = (dataset.batch_index if batch_index is None else batch_index) * dataset.batch_size
         for vidx in range(maxvid - dataset.batch_size, maxvid):
             if vidx >= dataset.num_items:
                 break
