@@ -158,35 +158,60 @@ class Dataset:
                     error("Failed to troubleshoot serialization error.")
 
     def frames_in_batch(self, batch_index):
+        """Upper bound of the frames one get_next_batch() call returns (a rank's shard is never larger than the batch)."""
         v0 = batch_index * self.batch_size
         return sum(self.num_frames_per_clip * c for c in self.clips_per_video[v0:v0 + self.batch_size])
+
+    def set_shard(self, rank, world):
+        """Data parallel: this process trains on videos shard_range(len(batch), rank, world) of every global batch."""
+        self.shard = (int(rank), int(world))
 
     def get_next_batch(self, out=None):
         """get_next_batch_video_tfr (dataset_.py:386-420): batch = batch_size videos; reads sum(cpv)*fpc consecutive
         frame records; one label per clip (its first frame's).  Returns (frames uint8 [n,H,W,C] raw, crop_y, crop_x,
-        mirror, onehot int32 [clips, classes])."""
+        mirror, onehot int32 [clips, classes]).  With a shard set, only this rank's videos of the batch are read (the records
+        of the other ranks are skipped by their length headers) and `self.global_clips` holds the clip count of the WHOLE batch
+        (the loss is its mean, train.py:123)."""
         v0 = self.batch_index * self.batch_size
-        cpv = self.clips_per_video[v0:v0 + self.batch_size]
+        cpv_all = self.clips_per_video[v0:v0 + self.batch_size]
         fpc = self.num_frames_per_clip
-        n = sum(fpc * c for c in cpv)
-        if not n:
+        n_all = sum(fpc * c for c in cpv_all)
+        if not n_all:
             error("Computed 0 frames in next batch.")
-        frames, labels_per_frame = self._read(n, out)      # out: caller's (pinned) uint8 buffer [>= n, H, W, C]
+        rank, world = getattr(self, "shard", (0, 1))
+        base, rem = divmod(len(cpv_all), world)
+        lo = rank * base + min(rank, rem)
+        hi = lo + base + (1 if rank < rem else 0)
+        cpv = cpv_all[lo:hi]
+        before, n = sum(fpc * c for c in cpv_all[:lo]), sum(fpc * c for c in cpv)
+        after = n_all - before - n
+        self.global_clips = sum(cpv_all)
+        if before:
+            self.offset = _hostio.skip_records(self.record_path, self.offset, before)
+        if n:
+            frames, labels_per_frame = self._read(n, out)      # out: caller's (pinned) uint8 buffer [>= n, H, W, C]
+        else:                                                  # fewer videos than ranks in a short last batch
+            frames, labels_per_frame = np.empty((0,) + tuple(self.raw_image_shape), np.uint8), []
+        if after:
+            self.offset = _hostio.skip_records(self.record_path, self.offset, after)
         labels, first = [], 0
         for c in cpv:
             labels.extend([labels_per_frame[first]] * c)
             first += c * fpc
-        cy = np.zeros(n, np.int32)
-        cx = np.zeros(n, np.int32)
-        mirror = np.zeros(n, np.uint8)
-        for i in range(n):      # per-frame draws, like process_image per frame (dataset_.py:481-501)
+        # per-frame draws, like process_image per frame (dataset_.py:481-501), for EVERY frame of the global batch in order, so
+        # that N ranks with one seed apply exactly the augmentation one process would
+        cy = np.zeros(n_all, np.int32)
+        cx = np.zeros(n_all, np.int32)
+        mirror = np.zeros(n_all, np.uint8)
+        for i in range(n_all):
             if self.crop_mode == defs.imgproc.rand_crop:
                 cy[i], cx[i] = self.rng.choice(self.crop_h), self.rng.choice(self.crop_w)
             elif self.crop_mode == defs.imgproc.center_crop:
                 cy[i], cx[i] = self.crop_h, self.crop_w
             if defs.imgproc.rand_mirror in self.imgproc:
                 mirror[i] = 0 if self.rng.randrange(2) else 1          # `if not randrange(2)` mirrors
-        ground_truth = labels_to_one_hot(labels, self.num_classes)
+        cy, cx, mirror = cy[before:before + n].copy(), cx[before:before + n].copy(), mirror[before:before + n].copy()
+        ground_truth = labels_to_one_hot(labels, self.num_classes) if labels else np.zeros((0, self.num_classes), np.int32)
         self.batch_index += 1
         return frames, cy, cx, mirror, ground_truth
 

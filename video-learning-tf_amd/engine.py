@@ -533,7 +533,7 @@ class LRCNEngine:
                         relu_mask=y.reshape(-1)[:n].view(n, 1, 1, 1), k=1, s=1)
 
     # ---- train step ----------------------------------------------------------------------------
-    def _train(self, n, b, onehot, lr, clip_norm, fetch):
+    def _train(self, n, b, onehot, lr, clip_norm, fetch, global_rows=None):
         if not self.training:
             raise VltfError("engine was built with training=False")
         if onehot.dtype != torch.int32 or tuple(onehot.shape) != (self._rows_for(b, n), self.cfg.num_classes):
@@ -541,9 +541,24 @@ class LRCNEngine:
         rows = self._forward(n, b, train=True)
         world = self.dp.world if self.dp is not None else 1
         ops.fill(self.stats, 0.0)
-        # mean over the GLOBAL batch: each rank scales by 1/(rows*world); the all-reduce sums (train.py:123)
-        ops.softmax_xent(self.logits[:rows], onehot, self.dlogits, self.stats, 1.0 / (rows * world))
+        # mean over the GLOBAL batch (train.py:123): each rank scales its rows by 1/global_rows and the all-reduce sums.
+        # global_rows defaults to rows*world (equal shards); a workflow with ragged shards passes the true count.
+        ops.softmax_xent(self.logits[:rows], onehot, self.dlogits, self.stats, 1.0 / (global_rows or rows * world))
         self._backward(n, b)
+        return self._finish_step(rows, lr, clip_norm, fetch)
+
+    def train_step_empty(self, lr, clip_norm=0.0, fetch=True):
+        """This rank's shard of the global batch is empty (fewer videos than ranks in a short last batch): contribute zero
+        gradients to the exchange and apply the same update as every other rank."""
+        if self.dp is None:
+            raise VltfError("train_step_empty is a data-parallel call")
+        ops.fill(self.g, 0.0)
+        ops.fill(self.stats, 0.0)
+        for lo, cnt in self.buckets:
+            self.dp.reduce_async(self.g, lo, cnt)
+        return self._finish_step(0, lr, clip_norm, fetch)
+
+    def _finish_step(self, rows, lr, clip_norm, fetch):
         if self.dp is not None:
             self.dp.wait()
         ops.sumsq(self.g, self.ss, self.small_ws)
@@ -556,8 +571,8 @@ class LRCNEngine:
             return None
         torch.cuda.synchronize(self.dev)
         st = self.stats.cpu().numpy()
-        return {"loss": float(st[0]) / rows, "accuracy": float(st[1]) / rows, "grad_norm": math.sqrt(float(self.ss.item())),
-                "rows": rows}
+        return {"loss": float(st[0]) / max(rows, 1), "accuracy": float(st[1]) / max(rows, 1), "grad_norm": math.sqrt(float(self.ss.item())),
+                "rows": rows, "loss_sum": float(st[0]), "correct": float(st[1])}
 
     def _rows_for(self, b, n):
         if self.cfg.classifier == "lstm":
@@ -565,10 +580,10 @@ class LRCNEngine:
         return b if (self.early or self.late) else n
 
     def train_step_u8(self, frames_u8, onehot, lr, clip_norm=0.0, mean_bgr=None, crop_y=None, crop_x=None, mirror=None,
-                      fetch=True):
+                      fetch=True, global_rows=None):
         """sess.run([summaries, loss, lr, global_step, optimizer], fdict) (run_task.py:44)."""
         n, b = self.feed_u8(frames_u8, mean_bgr, crop_y, crop_x, mirror)
-        return self._train(n, b, onehot, lr, clip_norm, fetch)
+        return self._train(n, b, onehot, lr, clip_norm, fetch, global_rows)
 
     def train_step_f32(self, frames_nhwc, onehot, lr, clip_norm=0.0, fetch=True):
         n, b = self.feed_f32_nhwc(frames_nhwc)

@@ -54,7 +54,7 @@ class BatchPrefetcher:
                     ev = torch.cuda.Event()
                     ev.record(self.copy_stream)
                 item = {"frames_u8": frames, "crop_y": cy, "crop_x": cx, "mirror": mirror, "labels": onehot, "mean_bgr": d.mean_bgr,
-                        "dataset": d, "batch_index": d.batch_index, "device": dict(dev, frames_u8=slot["dev"][:n]), "ready": ev}
+                        "dataset": d, "batch_index": d.batch_index, "global_clips": d.global_clips, "device": dict(dev, frames_u8=slot["dev"][:n]), "ready": ev}
                 k += 1
                 while not stop.is_set():
                     try:
@@ -175,7 +175,7 @@ class Feeder:
             return fdict, [len(fdict["frames_u8"])], len(fdict["labels"]), 0
         frames, cy, cx, mirror, onehot = d.get_next_batch()
         fdict = {"frames_u8": frames, "crop_y": cy, "crop_x": cx, "mirror": mirror, "labels": onehot, "mean_bgr": d.mean_bgr,
-                 "dataset": d, "batch_index": d.batch_index}
+                 "dataset": d, "batch_index": d.batch_index, "global_clips": d.global_clips}
         return fdict, [len(frames)], len(onehot), 0
 
     # ---- save cadence (feeder.py:111-129) ---------------------------------------------------------------

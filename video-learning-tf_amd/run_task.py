@@ -122,8 +122,14 @@ def main(init_file, seed=0, device=None):
     dataset = feeder.get_dataset_by_tag(defs.dataset_tag.main)[0]
     cfg, pipeline = net_config(settings, dataset)
     batch = settings.train.batch_size if settings.train else settings.val.batch_size
-    max_clips = batch * max(dataset.clips_per_video)
     gar = dpmod.GradAllReduce() if world > 1 else None
+    if world > 1 and settings.train:
+        # data parallel: `batch_size` stays the GLOBAL batch of the config; every rank trains on its videos of it
+        dataset.set_shard(rank, world)
+        batch = -(-batch // world)
+        if rank != 0:
+            feeder.save = lambda *a, **k: None              # rank 0 writes the checkpoints (parameters are identical everywhere)
+    max_clips = batch * max(dataset.clips_per_video)
     engine = LRCNEngine(cfg, max_clips=max_clips, device=device or "cuda:%d" % local, training=bool(settings.train), dp=gar)
     params = init_params(cfg, seed=seed)
     if pipeline.weights_file:
@@ -140,7 +146,10 @@ def main(init_file, seed=0, device=None):
         train = Train(settings, feeder, engine)
         do_train(settings, train, feeder, engine)
     elif settings.val:
-        result = do_test(settings, Validation(settings), feeder, engine)
+        if rank == 0:                                       # validation is not sharded: rank 0 evaluates and writes the result files
+            result = do_test(settings, Validation(settings), feeder, engine)
+        if world > 1:
+            torch.distributed.barrier()
     info("Run [%s] complete." % settings.run_id)
     return result
 

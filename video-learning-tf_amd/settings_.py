@@ -174,6 +174,8 @@ class Settings:
     def configure_logging(self):
         self.timestamp = get_datetime_str()
         logfile = os.path.join(self.run_folder, "log_" + self.run_id + "_" + self.timestamp + ".log")
+        if int(os.environ.get("RANK", "0")) > 0:      # data parallel: rank 0 owns the run's log file, the others log to the console
+            logfile = None
         self.logger = CustomLogger()
         self.logger.configure_logging(logfile, self.logging_level)
 

@@ -60,17 +60,27 @@ class Train:
             error("global step %d exceeds the precomputed learning-rate table (%d)" % (self.global_step, len(self.learning_rates)))
         lr = float(self.learning_rates[self.global_step])
         dev = self.engine.dev
-        if "device" in fdict:            # uploaded ahead of time by the feeder's BatchPrefetcher: wait for the copy on the stream
+        eng, dpg = self.engine, self.engine.dp
+        # data parallel: the loss is the mean over the GLOBAL batch, of which this rank holds a shard (possibly ragged or empty)
+        per_clip = eng.cfg.classifier == "lstm" or eng.early or eng.late          # one logits row per clip
+        grows = fdict.get("global_clips") if (dpg is not None and per_clip) else None
+        if len(fdict["labels"]) == 0:
+            out = eng.train_step_empty(lr, self.clip_norm)
+        elif "device" in fdict:          # uploaded ahead of time by the feeder's BatchPrefetcher: wait for the copy on the stream
             torch.cuda.current_stream(dev).wait_event(fdict["ready"])
             t = fdict["device"]
-            out = self.engine.train_step_u8(t["frames_u8"], t["labels"], lr, self.clip_norm, fdict["mean_bgr"], t["crop_y"], t["crop_x"],
-                                            t["mirror"])
+            out = eng.train_step_u8(t["frames_u8"], t["labels"], lr, self.clip_norm, fdict["mean_bgr"], t["crop_y"], t["crop_x"],
+                                    t["mirror"], global_rows=grows)
         else:
-            out = self.engine.train_step_u8(torch.from_numpy(fdict["frames_u8"]).to(dev, non_blocking=True),
-                                            torch.from_numpy(fdict["labels"]).to(dev),
-                                            lr, self.clip_norm, fdict["mean_bgr"],
-                                            torch.from_numpy(fdict["crop_y"]).to(dev), torch.from_numpy(fdict["crop_x"]).to(dev),
-                                            torch.from_numpy(fdict["mirror"]).to(dev))
+            out = eng.train_step_u8(torch.from_numpy(fdict["frames_u8"]).to(dev, non_blocking=True),
+                                    torch.from_numpy(fdict["labels"]).to(dev),
+                                    lr, self.clip_norm, fdict["mean_bgr"],
+                                    torch.from_numpy(fdict["crop_y"]).to(dev), torch.from_numpy(fdict["crop_x"]).to(dev),
+                                    torch.from_numpy(fdict["mirror"]).to(dev), global_rows=grows)
+        if dpg is not None:              # log the global-batch loss, not the shard's
+            tot = dpg.sum_scalars(torch.tensor([out["loss_sum"], out["correct"], float(out["rows"])], device=dev, dtype=torch.float64))
+            tot = tot.cpu().numpy()
+            out = dict(out, loss=float(tot[0] / max(tot[2], 1)), accuracy=float(tot[1] / max(tot[2], 1)))
         self.global_step += 1
         self.last = out
         return out["loss"], lr, self.global_step
