@@ -87,15 +87,18 @@ def do_train(settings, train, feeder, engine):
                     settings.global_step)
 
 
-def do_test(settings, val, feeder, engine):
-    """run_task.py:84-114."""
+def do_test(settings, val, feeder, engine, rank=0, world=1):
+    """run_task.py:84-114.  Data parallel: every rank evaluates its videos of each batch (Dataset.set_shard) and the clip logits are
+    gathered to rank 0 in rank order = the unsharded order; rank 0 alone aggregates per video and writes the result files."""
     tic = time.time()
     settings.global_step = 0
     dev = engine.dev
     while feeder.loop():
         fdict, num_data, num_labels, padding = feeder.get_feed_dict()
         print_iter_info(settings, feeder, num_data, num_labels, padding)
-        if "device" in fdict:            # read and uploaded ahead by the feeder's BatchPrefetcher
+        if num_labels == 0:
+            logits = np.zeros((0, settings.num_classes), np.float32)
+        elif "device" in fdict:          # read and uploaded ahead by the feeder's BatchPrefetcher
             torch.cuda.current_stream(dev).wait_event(fdict["ready"])
             t = fdict["device"]
             logits = engine.forward_u8(t["frames_u8"], fdict["mean_bgr"], t["crop_y"], t["crop_x"], t["mirror"]).cpu().numpy()
@@ -103,8 +106,16 @@ def do_test(settings, val, feeder, engine):
             logits = engine.forward_u8(torch.from_numpy(fdict["frames_u8"]).to(dev), fdict["mean_bgr"],
                                        torch.from_numpy(fdict["crop_y"]).to(dev), torch.from_numpy(fdict["crop_x"]).to(dev),
                                        torch.from_numpy(fdict["mirror"]).to(dev)).cpu().numpy()
-        val.process_validation_logits(fdict["dataset"], settings, logits, fdict["labels"].astype(np.float32), fdict["batch_index"])
-        val.save_validation_logits_chunk()
+        labels = fdict["labels"].astype(np.float32)
+        if world > 1:
+            parts = [None] * world
+            torch.distributed.all_gather_object(parts, (logits, labels))
+            logits, labels = np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
+        if rank == 0:
+            val.process_validation_logits(fdict["dataset"], settings, logits, labels, fdict["batch_index"])
+            val.save_validation_logits_chunk()
+    if rank != 0:
+        return None
     val.save_validation_logits_chunk(save_all=True)
     accuracy = val.get_accuracy()
     info("Validation run complete in [%s], accuracy: %2.5f" % (elapsed_str(tic), accuracy))
@@ -123,8 +134,8 @@ def main(init_file, seed=0, device=None):
     cfg, pipeline = net_config(settings, dataset)
     batch = settings.train.batch_size if settings.train else settings.val.batch_size
     gar = dpmod.GradAllReduce() if world > 1 else None
-    if world > 1 and settings.train:
-        # data parallel: `batch_size` stays the GLOBAL batch of the config; every rank trains on its videos of it
+    if world > 1:
+        # data parallel: `batch_size` stays the GLOBAL batch of the config; every rank works on its videos of it
         dataset.set_shard(rank, world)
         batch = -(-batch // world)
         if rank != 0:
@@ -146,8 +157,7 @@ def main(init_file, seed=0, device=None):
         train = Train(settings, feeder, engine)
         do_train(settings, train, feeder, engine)
     elif settings.val:
-        if rank == 0:                                       # validation is not sharded: rank 0 evaluates and writes the result files
-            result = do_test(settings, Validation(settings), feeder, engine)
+        result = do_test(settings, Validation(settings) if rank == 0 else None, feeder, engine, rank, world)
         if world > 1:
             torch.distributed.barrier()
     info("Run [%s] complete." % settings.run_id)
