@@ -994,26 +994,32 @@ extern "C" int vl_lstm_step_bwd(const float* dout, const float* dh_next, const f
 template <bool BWD>
 __global__ void lstm_seq_kernel(const float* __restrict__ gx, const float* __restrict__ kmat, float* __restrict__ act,
                                 float* __restrict__ cseq, float* __restrict__ hseq, float* __restrict__ hprev,
-                                const float* __restrict__ dout, float* __restrict__ dz, int T, int H, float forget_bias) {
+                                const float* __restrict__ dout, float* __restrict__ dz, int T, int H, float forget_bias, int KQ) {
+    // blockDim = KQ * HP threads (HP = H rounded up to the wave): thread (u, kq) accumulates the kq-th slice of the recurrent
+    // reduction for hidden unit u; the KQ partial sums meet in LDS and the kq = 0 threads do the gate math.  The recurrence is a
+    // chain of T dependent steps whose length is set by load latency, not bandwidth (1 MB of weights per step from L2): splitting
+    // the reduction four ways cuts the dependent load batches per step from 16 to 4.
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int b = blockIdx.x, u = threadIdx.x;
+    const int HP = blockDim.x / KQ;
+    const int b = blockIdx.x, u = threadIdx.x % HP, kq = threadIdx.x / HP;
     const bool live = u < H;
     const int uc = live ? u : 0;                       // clamped: idle lanes load valid addresses, results unused
     const int H4 = 4 * H;
     constexpr int KB = 16;
     if (!BWD) {
+        float* hs = sm;                                // [H] h_{t-1}
+        float* part = sm + H;                          // [KQ][4][H] partial gate pre-activations
         float c = 0.f;
-        for (int i = threadIdx.x; i < H; i += blockDim.x) sm[i] = 0.f;
+        for (int i = threadIdx.x; i < H; i += blockDim.x) hs[i] = 0.f;
         __syncthreads();
-        const int nb = H / KB, rot = (b * 5) % (nb > 0 ? nb : 1);
+        const int klen = (H + KQ - 1) / KQ, k0 = kq * klen, k1 = min(H, k0 + klen);
+        const int nb = (k1 - k0) / KB, rot = (b * 5) % (nb > 0 ? nb : 1);
         for (int t = 0; t < T; ++t) {
             const int64_t r = (int64_t)b * T + t;
-            float z[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) z[q] = gx[r * H4 + q * H + uc];
+            float z[4] = {0.f, 0.f, 0.f, 0.f};
             if (t > 0) {
                 for (int ib = 0; ib < nb; ++ib) {
-                    const int kb = ((ib + rot) % nb) * KB;
+                    const int kb = k0 + ((ib + rot) % nb) * KB;
                     float w[KB][4];
 #pragma unroll
                     for (int kk = 0; kk < KB; ++kk)
@@ -1021,24 +1027,34 @@ __global__ void lstm_seq_kernel(const float* __restrict__ gx, const float* __res
                         for (int q = 0; q < 4; ++q) w[kk][q] = kmat[(int64_t)(kb + kk) * H4 + q * H + uc];
 #pragma unroll
                     for (int kk = 0; kk < KB; ++kk) {
-                        const float hk = sm[kb + kk];
+                        const float hk = hs[kb + kk];
 #pragma unroll
                         for (int q = 0; q < 4; ++q) z[q] += hk * w[kk][q];
                     }
                 }
-                for (int k = nb * KB; k < H; ++k) {
-                    const float hk = sm[k];
+                for (int k = k0 + nb * KB; k < k1; ++k) {
+                    const float hk = hs[k];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) z[q] += hk * kmat[(int64_t)k * H4 + q * H + uc];
                 }
+                if (live)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) part[(kq * 4 + q) * H + u] = z[q];
             }
-            const float hp = sm[uc];
-            __syncthreads();                           // everyone has consumed h_{t-1}
-            if (live) {
-                const float gi = sigmoidf_(z[0]), gj = tanhf(z[1]), gf = sigmoidf_(z[2] + forget_bias), go = sigmoidf_(z[3]);
+            const float hp = hs[uc];
+            __syncthreads();                           // partial sums complete; everyone has consumed h_{t-1}
+            if (live && kq == 0) {
+                float zz[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    zz[q] = gx[r * H4 + q * H + u];
+                    if (t > 0)
+                        for (int j = 0; j < KQ; ++j) zz[q] += part[(j * 4 + q) * H + u];    // fixed order: reproducible
+                }
+                const float gi = sigmoidf_(zz[0]), gj = tanhf(zz[1]), gf = sigmoidf_(zz[2] + forget_bias), go = sigmoidf_(zz[3]);
                 c = c * gf + gi * gj;
                 const float h = tanhf(c) * go;
-                sm[u] = h;
+                hs[u] = h;
                 float* a = act + r * H4 + u;
                 a[0] = gi; a[H] = gj; a[2 * H] = gf; a[3 * H] = go;
                 cseq[r * H + u] = c;
@@ -1049,11 +1065,14 @@ __global__ void lstm_seq_kernel(const float* __restrict__ gx, const float* __res
         }
     } else {
         // kmat = khT [4H][H]: dh_prev[u] = sum_g dz[g] * khT[g][u]
+        float* zs = sm;                                // [4H] dz_t
+        float* part = sm + H4;                         // [KQ][H] partial dh
         float dc = 0.f, dh = 0.f;
-        const int nb = H4 / KB, rot = (b * 5) % (nb > 0 ? nb : 1);
+        const int glen = (H4 + KQ - 1) / KQ, g0 = kq * glen, g1 = min(H4, g0 + glen);
+        const int nb = (g1 - g0) / KB, rot = (b * 5) % (nb > 0 ? nb : 1);
         for (int t = T - 1; t >= 0; --t) {
             const int64_t r = (int64_t)b * T + t;
-            if (live) {
+            if (live && kq == 0) {
                 const float din = (dout ? dout[r * H + u] : 0.f) + dh;
                 const float* a = act + r * H4 + u;
                 const float gi = a[0], gj = a[H], gf = a[2 * H], go = a[3 * H];
@@ -1067,35 +1086,45 @@ __global__ void lstm_seq_kernel(const float* __restrict__ gx, const float* __res
                 dc = dcv * gf;
                 float* zp = dz + r * H4 + u;
                 zp[0] = zi; zp[H] = zj; zp[2 * H] = zf; zp[3 * H] = zo;
-                sm[u] = zi; sm[H + u] = zj; sm[2 * H + u] = zf; sm[3 * H + u] = zo;
+                zs[u] = zi; zs[H + u] = zj; zs[2 * H + u] = zf; zs[3 * H + u] = zo;
             }
             __syncthreads();                           // dz_t complete in LDS
             if (t > 0) {
                 float acc = 0.f;
                 for (int ib = 0; ib < nb; ++ib) {
-                    const int g = ((ib + rot) % nb) * KB;
+                    const int g = g0 + ((ib + rot) % nb) * KB;
                     float w[KB];
 #pragma unroll
                     for (int gg = 0; gg < KB; ++gg) w[gg] = kmat[(int64_t)(g + gg) * H + uc];
 #pragma unroll
-                    for (int gg = 0; gg < KB; ++gg) acc += sm[g + gg] * w[gg];
+                    for (int gg = 0; gg < KB; ++gg) acc += zs[g + gg] * w[gg];
                 }
-                for (int g = nb * KB; g < H4; ++g) acc += sm[g] * kmat[(int64_t)g * H + uc];
+                for (int g = g0 + nb * KB; g < g1; ++g) acc += zs[g] * kmat[(int64_t)g * H + uc];
+                if (live) part[kq * H + u] = acc;
+            }
+            __syncthreads();                           // partial dh complete; dz_t consumed before it is overwritten
+            if (t > 0 && live && kq == 0) {
+                float acc = 0.f;
+                for (int j = 0; j < KQ; ++j) acc += part[j * H + u];
                 dh = acc;
             }
-            __syncthreads();                           // dz_t consumed before it is overwritten
+            // (the next iteration's first barrier separates these reads of `part` from its next writes)
         }
     }
 }
 
-static int lstm_seq_threads(int H) { return ((H + 63) / 64) * 64; }
+// threads per workgroup: H rounded up to the wave, times the reduction split (4 when that fits a 1024-thread workgroup)
+static int lstm_seq_hp(int H) { return ((H + 63) / 64) * 64; }
+static int lstm_seq_kq(int H) { return lstm_seq_hp(H) * 4 <= 1024 ? 4 : (lstm_seq_hp(H) * 2 <= 1024 ? 2 : 1); }
+
 
 extern "C" int vl_lstm_seq_fwd(const float* gx, const float* kh, float* act, float* cseq, float* hseq, float* hprev, int batch,
                                int T, int H, float forget_bias, vl_stream_t stream) {
     VL_CHECK(gx && kh && act && cseq && hseq && hprev, "vl_lstm_seq_fwd: null argument");
     VL_CHECK(batch > 0 && T > 0 && H > 0 && H <= 1024, "vl_lstm_seq_fwd: bad shape (hidden size must be <= 1024)");
-    hipLaunchKernelGGL((lstm_seq_kernel<false>), dim3(batch), dim3(lstm_seq_threads(H)), (size_t)H * sizeof(float),
-                       (hipStream_t)stream, gx, kh, act, cseq, hseq, hprev, (const float*)nullptr, (float*)nullptr, T, H, forget_bias);
+    const int kq = lstm_seq_kq(H);
+    hipLaunchKernelGGL((lstm_seq_kernel<false>), dim3(batch), dim3(lstm_seq_hp(H) * kq), (size_t)(1 + 4 * kq) * H * sizeof(float),
+                       (hipStream_t)stream, gx, kh, act, cseq, hseq, hprev, (const float*)nullptr, (float*)nullptr, T, H, forget_bias, kq);
     VL_LAUNCH_CHECK();
     return 0;
 }
@@ -1104,9 +1133,10 @@ extern "C" int vl_lstm_seq_bwd(const float* dout, const float* kh_t, const float
                                int T, int H, vl_stream_t stream) {
     VL_CHECK(kh_t && act && cseq && dz, "vl_lstm_seq_bwd: null argument");
     VL_CHECK(batch > 0 && T > 0 && H > 0 && H <= 1024, "vl_lstm_seq_bwd: bad shape (hidden size must be <= 1024)");
-    hipLaunchKernelGGL((lstm_seq_kernel<true>), dim3(batch), dim3(lstm_seq_threads(H)), (size_t)4 * H * sizeof(float),
+    const int kq = lstm_seq_kq(H);
+    hipLaunchKernelGGL((lstm_seq_kernel<true>), dim3(batch), dim3(lstm_seq_hp(H) * kq), (size_t)(4 + kq) * H * sizeof(float),
                        (hipStream_t)stream, (const float*)nullptr, kh_t, const_cast<float*>(act), const_cast<float*>(cseq),
-                       (float*)nullptr, (float*)nullptr, dout, dz, T, H, 0.f);
+                       (float*)nullptr, (float*)nullptr, dout, dz, T, H, 0.f, kq);
     VL_LAUNCH_CHECK();
     return 0;
 }
