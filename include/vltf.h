@@ -199,6 +199,8 @@ int vl_adam_apply(float* w, const float* g, float* m, float* v, int64_t count, f
 
 /* ---- utilities ------------------------------------------------------------------------------- */
 int vl_fill(float* p, int64_t count, float value, vl_stream_t stream);
+/* ReluGrad in place: d[i] = y[i] > 0 ? d[i] : 0 (y = the ReLU's forward output, alexnet.py:228,248). */
+int vl_relu_grad(float* d, const float* y, int64_t count, vl_stream_t stream);
 /* truncated-normal / uniform parameter initialisers are host side; nothing here. */
 
 #ifdef __cplusplus

@@ -519,21 +519,32 @@ def lrcn_forward(p, frames, fpc, final_layer="fc6", lstm_layers=1, fusion="avg",
     return logits, cache
 
 
-def lrcn_backward(p, cache, dlogits, fpc, final_layer="fc6", lstm_layers=1, fusion="avg", dtype=F64):
-    """Gradients of lrcn_forward (classifier lstm) wrt every parameter."""
+def lrcn_backward(p, cache, dlogits, fpc, final_layer="fc6", lstm_layers=1, fusion="avg", dtype=F64, classifier="lstm",
+                  frame_fusion=None):
+    """Gradients of lrcn_forward wrt every parameter (classifier lstm, or fc with early / late frame fusion)."""
     g = {}
     d = dlogits.astype(dtype)
-    head = "fc_convert" if fusion == "state" else "output_fc"
-    if head + "_w" in p:
-        g[head + "_w"] = cache["fused"].T @ d
-        g[head + "_b"] = d.sum(0)
-        d = d @ p[head + "_w"].astype(dtype).T
-    d = temporal_fusion_grad(cache["seq_shape"], "last" if fusion == "state" else fusion, d)
-    for l in reversed(range(lstm_layers)):
-        kname = "rnn/multi_rnn_cell/cell_%d/basic_lstm_cell/kernel" % l
-        d, dk, db, _, _ = lstm_layer_backward(p[kname], cache["lstm"][l], d, dtype=dtype)
-        g[kname] = dk
-        g[kname[:-6] + "bias"] = db
+    if classifier == "lstm":
+        head = "fc_convert" if fusion == "state" else "output_fc"
+        if head + "_w" in p:
+            g[head + "_w"] = cache["fused"].T @ d
+            g[head + "_b"] = d.sum(0)
+            d = d @ p[head + "_w"].astype(dtype).T
+        d = temporal_fusion_grad(cache["seq_shape"], "last" if fusion == "state" else fusion, d)
+        for l in reversed(range(lstm_layers)):
+            kname = "rnn/multi_rnn_cell/cell_%d/basic_lstm_cell/kernel" % l
+            d, dk, db, _, _ = lstm_layer_backward(p[kname], cache["lstm"][l], d, dtype=dtype)
+            g[kname] = dk
+            g[kname[:-6] + "bias"] = db
+    else:   # classifier fc (model.py:115-119), late fusion after it (149-151), early fusion before it (103-106)
+        if frame_fusion and frame_fusion[0] == "late" and fpc > 1:
+            d = temporal_fusion_grad((d.shape[0], fpc, d.shape[1]), frame_fusion[1], d).reshape(-1, d.shape[1])
+        if "fc_convert_w" in p:
+            g["fc_convert_w"] = cache["fc_in"].T @ d
+            g["fc_convert_b"] = d.sum(0)
+            d = d @ p["fc_convert_w"].astype(dtype).T
+        if frame_fusion and frame_fusion[0] == "early" and fpc > 1:
+            d = temporal_fusion_grad((d.shape[0], fpc, d.shape[1]), frame_fusion[1], d)
     dfeat = d.reshape(-1, d.shape[-1])
     chunk = cache["chunk"]
     for ci, cc in enumerate(cache["cnn"]):
@@ -544,12 +555,12 @@ def lrcn_backward(p, cache, dlogits, fpc, final_layer="fc6", lstm_layers=1, fusi
 
 
 def lrcn_train_step(p, frames, onehot, fpc, lr, clip_norm=0.0, final_layer="fc6", lstm_layers=1,
-                    fusion="avg", dtype=F64, chunk=32):
+                    fusion="avg", dtype=F64, chunk=32, classifier="lstm", frame_fusion=None):
     """One single-tier SGD step (train.py:199-222): loss, grads, global-norm clip, w -= lr*g.
     Returns (new_params, loss, global_norm, accuracy, logits, grads_unclipped)."""
-    logits, cache = lrcn_forward(p, frames, fpc, final_layer, lstm_layers, fusion, "lstm", None, dtype, True, chunk)
+    logits, cache = lrcn_forward(p, frames, fpc, final_layer, lstm_layers, fusion, classifier, frame_fusion, dtype, True, chunk)
     loss, dlogits = softmax_xent_mean(logits, onehot, dtype)
-    grads = lrcn_backward(p, cache, dlogits, fpc, final_layer, lstm_layers, fusion, dtype)
+    grads = lrcn_backward(p, cache, dlogits, fpc, final_layer, lstm_layers, fusion, dtype, classifier, frame_fusion)
     clipped, gn = clip_by_global_norm(grads, clip_norm)
     new_p = {k: (p[k].astype(dtype) - lr * clipped[k]).astype(np.float32) for k in p}
     return new_p, loss, gn, accuracy(logits, onehot), logits, grads

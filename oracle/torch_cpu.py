@@ -40,8 +40,8 @@ def lstm(x, kernel, bias):
     return torch.stack(outs, 1), c, h
 
 
-def lrcn_logits(p, frames, fpc, final_layer="fc6", lstm_layers=1, fusion="avg"):
-    """p: {tf variable name: tensor}; frames [B*T,H,W,3] NHWC.  Classifier lstm."""
+def lrcn_logits(p, frames, fpc, final_layer="fc6", lstm_layers=1, fusion="avg", classifier="lstm", frame_fusion=None):
+    """p: {tf variable name: tensor}; frames [B*T,H,W,3] NHWC.  Classifier lstm, or fc with early / late frame fusion."""
     a = frames
     for name, kh, kw, co, s, g in O.ALEXNET_CONVS:
         a = torch.relu(conv_same(a, p["dcnn/%sW" % name], s, g) + p["dcnn/%sb" % name])
@@ -52,6 +52,17 @@ def lrcn_logits(p, frames, fpc, final_layer="fc6", lstm_layers=1, fusion="avg"):
     a = torch.relu(a.reshape(a.shape[0], -1) @ p["dcnn/fc6W"] + p["dcnn/fc6b"])
     if final_layer != "fc6":
         a = torch.relu(a @ p["dcnn/fc7W"] + p["dcnn/fc7b"])
+    if final_layer not in ("fc6", "fc7"):
+        a = a @ p["dcnn/fc8W"] + p["dcnn/fc8b"]                 # alexnet.py:275: xw_plus_b, no ReLU
+    if classifier == "fc":                                      # model.py:103-119,149-151
+        fuse = lambda v: v.reshape(-1, fpc, v.shape[1]).mean(1) if frame_fusion[1] == "avg" else v.reshape(-1, fpc, v.shape[1])[:, -1]
+        if frame_fusion and frame_fusion[0] == "early" and fpc > 1:
+            a = fuse(a)
+        if "fc_convert_w" in p:
+            a = a @ p["fc_convert_w"] + p["fc_convert_b"]
+        if frame_fusion and frame_fusion[0] == "late" and fpc > 1:
+            a = fuse(a)
+        return a
     x = a.reshape(-1, fpc, a.shape[1])
     for l in range(lstm_layers):
         x, _, _ = lstm(x, p["rnn/multi_rnn_cell/cell_%d/basic_lstm_cell/kernel" % l],

@@ -94,6 +94,33 @@ def test_single_frame_fc_classifier(ff):
     np.testing.assert_allclose(got, want, rtol=1e-3, atol=1e-3)
 
 
+@pytest.mark.parametrize("layer,ff", [("fc7", ("early", "avg")), ("fc7", ("late", "last")), ("fc8", ("late", "avg")), ("fc6", None)])
+def test_fc_classifier_train_step(layer, ff):
+    """Config 1 of BASELINE.json as a TRAIN step: frame-level AlexNet, classifier fc, early / late / no frame fusion
+    (model.py:103-119,149-151) -- loss, gradients and the clipped-SGD update against the oracle."""
+    rng = np.random.default_rng(12)
+    shape, ncls, fpc, b = (67, 67, 3), 6, 3, 2
+    cfg, eng = make(dict(num_classes=ncls, fpc=fpc, frame_encoding_layer=layer, classifier="fc", frame_fusion=ff), shape, b)
+    p = oracle_params(rng, cfg, shape)
+    eng.load_params(p)
+    frames = rng.integers(0, 256, (b * fpc,) + shape, dtype=np.uint8)
+    rows = b if ff else b * fpc
+    onehot = O.labels_to_one_hot([[l] for l in rng.integers(0, ncls, rows)], ncls)
+    x = frames.astype(np.float32) - MEAN
+    newp, loss, gn, acc, logits, grads = O.lrcn_train_step(p, x, onehot, fpc, lr=0.01, clip_norm=0.5, final_layer=layer,
+                                                          classifier="fc", frame_fusion=ff)
+    out = eng.train_step_u8(torch.tensor(frames, device=DEV), torch.tensor(onehot, device=DEV), lr=0.01, clip_norm=0.5, mean_bgr=MEAN)
+    np.testing.assert_allclose(eng.logits_host(), logits, rtol=1e-3, atol=1e-3)
+    assert abs(out["loss"] - loss) < 1e-4 * max(1, abs(loss)) and abs(out["grad_norm"] - gn) < 1e-3 * gn
+    g = eng.get_grads()
+    for k in p:
+        scale = np.abs(grads[k]).max() + 1e-12
+        np.testing.assert_allclose(g[k], grads[k], rtol=2e-3, atol=2e-4 * scale, err_msg="grad " + k)
+    got = eng.get_params()
+    for k in p:
+        np.testing.assert_allclose(got[k], newp[k], rtol=1e-4, atol=1e-5, err_msg="param " + k)
+
+
 def test_full_geometry_logits_and_step():
     """227x227x3, 2 clips x 4 frames, fc6 -> LSTM(256) -> 101 classes: the real layer shapes."""
     rng = np.random.default_rng(1)

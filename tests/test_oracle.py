@@ -148,6 +148,28 @@ def test_lrcn_train_step_vs_autograd(final_layer, layers, fusion):
         np.testing.assert_allclose(newp[k], want, rtol=1e-6, atol=1e-7, err_msg=k)
 
 
+@pytest.mark.parametrize("final_layer,ff", [("fc7", ("early", "avg")), ("fc7", ("late", "last")), ("fc8", ("late", "avg")), ("fc6", None)])
+def test_fc_classifier_train_step_vs_autograd(final_layer, ff):
+    """Config 1 of BASELINE.json (frame-level AlexNet, classifier fc, early / late frame fusion): oracle gradients vs torch autograd."""
+    rng = np.random.default_rng(8)
+    shape, ncls, fpc, b = (67, 67, 3), 6, 3, 2
+    p = O.init_params(rng, ncls, final_layer, 8, 1, shape, classifier="fc", well_scaled=True)
+    frames = (rng.integers(0, 256, (b * fpc,) + shape).astype(np.float32) - 104.0)
+    rows = b if ff else b * fpc
+    lab = rng.integers(0, ncls, rows)
+    onehot = O.labels_to_one_hot([[l] for l in lab], ncls)
+    newp, loss, gn, acc, logits, grads = O.lrcn_train_step(p, frames, onehot, fpc, lr=0.01, clip_norm=0.5, final_layer=final_layer,
+                                                          classifier="fc", frame_fusion=ff)
+    pt = {k: t(v).requires_grad_() for k, v in p.items()}
+    lg = TC.lrcn_logits(pt, t(frames), fpc, final_layer, classifier="fc", frame_fusion=ff)
+    lt = F.cross_entropy(lg, torch.tensor(lab))
+    lt.backward()
+    np.testing.assert_allclose(logits, lg.detach().numpy(), rtol=1e-9, atol=1e-9)
+    assert abs(loss - lt.item()) < 1e-10
+    for k in p:
+        np.testing.assert_allclose(grads[k], pt[k].grad.numpy(), rtol=1e-7, atol=1e-10, err_msg=k)
+
+
 def test_lr_table():
     # train.py:50-109: exp and staircase give identical piecewise-constant tables
     a = O.precompute_learning_rates(0.05, ["exp", "interval", 3, 0.5], 5, 2)

@@ -1408,6 +1408,19 @@ __global__ void fill_kernel(float* __restrict__ p, int64_t count, float value) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) p[i] = value;
 }
 
+// ReluGrad in place (tf.nn.relu's gradient: 0 where the forward output is <= 0): d[i] = y[i] > 0 ? d[i] : 0
+__global__ void relu_grad_kernel(float* __restrict__ d, const float* __restrict__ y, int64_t count) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
+        d[i] = y[i] > 0.f ? d[i] : 0.f;
+}
+
+extern "C" int vl_relu_grad(float* d, const float* y, int64_t count, vl_stream_t stream) {
+    VL_CHECK(d && y && count > 0, "vl_relu_grad: bad argument");
+    hipLaunchKernelGGL(relu_grad_kernel, dim3(grid_for(count, 256, 4096)), dim3(256), 0, (hipStream_t)stream, d, y, count);
+    VL_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int vl_fill(float* p, int64_t count, float value, vl_stream_t stream) {
     VL_CHECK(p && count > 0, "vl_fill: bad argument");
     hipLaunchKernelGGL(fill_kernel, dim3(grid_for(count, 256, 4096)), dim3(256), 0, (hipStream_t)stream, p, count, value);

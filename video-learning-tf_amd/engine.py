@@ -472,7 +472,7 @@ class LRCNEngine:
                 # ReluGrad of the encode layer applies per frame after un-fusing
                 ops.temporal_fusion_bwd(self.dfc_in, self.dfeat, b, T, D, cfg.frame_fusion[1])
                 if self.f8 is None:
-                    self._relu_mask_inplace(self.dfeat, self.feat, n * D)
+                    ops.relu_grad(self.dfeat, self.feat, n * D)
         # ---- fc8 / fc7 / fc6 (dfeat already carries the ReluGrad of the encode layer)
         d = self.dfeat
         if self.f8 is not None:
@@ -521,16 +521,6 @@ class LRCNEngine:
 
     def _pool_bwd(self, L, n, dx, relu_mask, dx_halo):
         ops.maxpool_bwd(L["dp"][:n], L["arg"][:n], dx, relu_mask=relu_mask, hwc=L["hwc"], dy_halo=L["p_halo"], dx_halo=dx_halo)
-
-    def _relu_mask_inplace(self, d, y, count):
-        # rare path (classifier fc + early fusion): mask through the lrn-free identity of maxpool_bwd is not
-        # available here, so use the GEMM-free elementwise route: dropout_bwd with keep=1 needs a u8 mask;
-        # instead reuse vl_maxpool_bwd's mask semantics via a 1x1 "pool".
-        n = count
-        arg = torch.zeros(n, dtype=torch.uint8, device=self.dev)
-        tmp = d.reshape(-1)[:n].clone()
-        ops.maxpool_bwd(tmp.view(n, 1, 1, 1), arg.view(n, 1, 1, 1), d.reshape(-1)[:n].view(n, 1, 1, 1),
-                        relu_mask=y.reshape(-1)[:n].view(n, 1, 1, 1), k=1, s=1)
 
     # ---- train step ----------------------------------------------------------------------------
     def _train(self, n, b, onehot, lr, clip_norm, fetch, global_rows=None):

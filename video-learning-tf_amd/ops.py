@@ -335,3 +335,9 @@ def adam_apply(w, g, m, v, lr, step, clip_norm=0.0, sumsq_t=None, gscale=1.0):
 def fill(t, value):
     _f32(t)
     _ffi.call("vl_fill", _p(t), t.numel(), value, stream())
+
+
+def relu_grad(d, y, count=None):
+    """d = y > 0 ? d : 0 in place over the first `count` elements."""
+    _f32(d, y); _dense(d, y)
+    _ffi.call("vl_relu_grad", _p(d), _p(y), d.numel() if count is None else int(count), stream())
