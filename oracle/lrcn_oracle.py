@@ -468,6 +468,26 @@ def clip_by_global_norm(grads, clip_norm):
     return {k: v * scale for k, v in grads.items()}, gn
 
 
+def adam_update(p, grads, state, lr, clip_norm=0.0, beta1=0.9, beta2=0.999, eps=1e-8):
+    """tf.train.AdamOptimizer(lr) (train.py:205-206, defaults beta1 0.9, beta2 0.999, epsilon 1e-8) applied to the globally clipped
+    gradients (train.py:213-217).  TF-1.x Adam: lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t); m, v exponential averages;
+    w -= lr_t * m / (sqrt(v) + eps).  state = {"t": int, "m": {...}, "v": {...}} is updated in place; returns the new parameters."""
+    clipped, _ = clip_by_global_norm(grads, clip_norm)
+    state["t"] = state.get("t", 0) + 1
+    t = state["t"]
+    lr_t = lr * math.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t)
+    out = {}
+    for k in p:
+        g = clipped[k].astype(F64)
+        m = state.setdefault("m", {}).get(k, np.zeros_like(g))
+        v = state.setdefault("v", {}).get(k, np.zeros_like(g))
+        m = beta1 * m + (1.0 - beta1) * g
+        v = beta2 * v + (1.0 - beta2) * g * g
+        state["m"][k], state["v"][k] = m, v
+        out[k] = (p[k].astype(F64) - lr_t * m / (np.sqrt(v) + eps)).astype(np.float32)
+    return out
+
+
 def labels_to_one_hot(labels, num_classes):
     """utils_.py:160-169."""
     onehots = np.zeros((len(labels), num_classes), np.int32)

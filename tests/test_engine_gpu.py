@@ -150,6 +150,37 @@ def test_full_geometry_logits_and_step():
         assert err < bound, "grad %s: relative L2 error %.3e" % (k, err)
 
 
+def test_adam_steps_match_oracle():
+    """defs.optim.adam (train.py:205-206): three clipped Adam steps against the oracle's TF-1.x Adam on the oracle's gradients."""
+    rng = np.random.default_rng(21)
+    shape, ncls, fpc, b = (67, 67, 3), 5, 2, 2
+    cfg, eng = make(dict(num_classes=ncls, fpc=fpc, lstm_hidden=8, optimizer="adam"), shape, b)
+    p = oracle_params(rng, cfg, shape)
+    eng.load_params(p)
+    frames = rng.integers(0, 256, (b * fpc,) + shape, dtype=np.uint8)
+    onehot = O.labels_to_one_hot([[l] for l in rng.integers(0, ncls, b)], ncls)
+    x = frames.astype(np.float32) - MEAN
+    state, lr, clip = {}, 1e-3, 0.5
+    fd, od = torch.tensor(frames, device=DEV), torch.tensor(onehot, device=DEV)
+    tiny = {k: np.zeros(v.shape, bool) for k, v in p.items()}
+    for step in range(3):
+        _, loss, gn, _, _, grads = O.lrcn_train_step(p, x, onehot, fpc, lr=0.0, clip_norm=clip)      # gradients at the current p
+        clipped, _ = O.clip_by_global_norm(grads, clip)
+        p = O.adam_update(p, grads, state, lr, clip)
+        out = eng.train_step_u8(fd, od, lr=lr, clip_norm=clip, mean_bgr=MEAN)
+        assert abs(out["loss"] - loss) < 2e-4 * max(1, abs(loss)) and abs(out["grad_norm"] - gn) < 2e-3 * gn, step
+        got = eng.get_params()
+        for k in p:
+            # One Adam step moves a weight by ~lr * g / (|g| + eps') whatever the gradient's size (eps' = 1e-8/sqrt(1-beta2) = 3e-7 at
+            # step 1), so the parameters are compared at 2 % of lr per step -- except where |g| is within ~30x of eps': there
+            # d(update)/dg = lr/eps' and fp32 rounding of the gradient (1e-8 absolute) is already several % of lr (measured
+            # 78 of 131k LSTM weights at 3.4 % of lr); those only have to stay within the step size itself.
+            tiny[k] |= np.abs(clipped[k]) < 1e-5
+            d = np.abs(got[k] - p[k])
+            assert d[~tiny[k]].max(initial=0) <= 0.02 * lr * (step + 1) + 1e-6, (step, k, d[~tiny[k]].max())
+            assert d.max() <= lr * (step + 1) + 1e-6, (step, k, d.max())
+
+
 def test_adam_and_dropout_run():
     rng = np.random.default_rng(3)
     shape, ncls, fpc, b = (67, 67, 3), 5, 2, 2
