@@ -101,11 +101,21 @@ def interior(t, halo):
     return t if halo == 0 else t[:, :, halo:-halo, halo:-halo]
 
 
-@pytest.mark.parametrize("padded", [False, True])
+@pytest.fixture
+def conv_math(ops, request):
+    ops.set_conv_math(request.param)
+    assert ops.conv_math() == request.param
+    yield request.param
+    ops.set_conv_math("f32")
+
+
+@pytest.mark.parametrize("conv_math,padded", [("f32", False), ("f32", True), ("bf16x3", True)], indirect=["conv_math"])
 @pytest.mark.parametrize("n,h,w,cin,cout,k,s,g", CONV_CASES)
-def test_conv_fwd_bwd(ops, padded, n, h, w, cin, cout, k, s, g):
+def test_conv_fwd_bwd(ops, conv_math, padded, n, h, w, cin, cout, k, s, g):
     """padded=False: dense NCHW, bounds-tested gather.  padded=True: every tensor carries a zero halo
-    (x/dy: the SAME padding -> test-free gather; y/dx: an arbitrary halo of 1) as the engine lays them out."""
+    (x/dy: the SAME padding -> test-free gather; y/dx: an arbitrary halo of 1) as the engine lays them out.
+    conv_math="bf16x3": the opt-in split-bf16 products of vl_set_conv_math (padded layout, >= 96 output channels per group:
+    conv1 phase-split, conv2-5 forward, conv3-5 dgrad here) against the SAME oracle at the SAME tolerances."""
     rng = np.random.default_rng(h * 100 + cin)
     x = rng.standard_normal((n, h, w, cin)).astype(np.float32)
     wt = (rng.standard_normal((k, k, cin // g, cout)) / math.sqrt(k * k * cin / g)).astype(np.float32)
@@ -163,7 +173,10 @@ def test_conv_fwd_bwd(ops, padded, n, h, w, cin, cout, k, s, g):
         assert tuple(xps.shape) == conv.x_shape(n)
         y2 = torch.zeros_like(y)
         conv.fwd(xps, wd, bd, y2, relu=True)
-        assert torch.equal(y2, y)
+        if conv_math == "f32":
+            assert torch.equal(y2, y)
+        else:                                     # the phase-split layout runs the split-product kernel, the plain one fp32
+            close(nhwc(host(interior(y2, yh))), np.maximum(z, 0), msg="conv fwd+relu (phase-split x, bf16x3)")
         dw2, db3 = torch.empty_like(wd), torch.empty(cout, device=DEV)
         conv.wgrad(xps, dyd, dw2, ws, db=db3 if conv.fuses_bias() else None)
         close(host(dw2), dwo, msg="conv wgrad (phase-split x)")

@@ -23,6 +23,7 @@ def main():
     cin, h, w, cout, k, s, g = GEOM[layer]
     conv = ops.Conv(cin, h, w, cout, k, k, s, g)
     dev = "cuda:0"
+    torch.manual_seed(0)
     padded = os.environ.get("VL_PROBE_DENSE") is None          # default: the engine's zero-halo layout
     xh = conv.same_pad() if padded else 0
     dyh = conv.same_pad() if (padded and s == 1) else 0
@@ -55,6 +56,13 @@ def main():
 
     run()
     torch.cuda.synchronize()
+    if os.environ.get("VL_PROBE_SAVE"):            # result of this arithmetic, to compare runs under different VL_CONV_MATH
+        torch.save({"fwd": y, "dgrad": dx, "wgrad": dw}[what].cpu(), os.environ["VL_PROBE_SAVE"])
+    if os.environ.get("VL_PROBE_CMP"):
+        ref = torch.load(os.environ["VL_PROBE_CMP"], weights_only=True)
+        got = {"fwd": y, "dgrad": dx, "wgrad": dw}[what].cpu()
+        print("  vs %s: rel L2 %.3e  max abs %.3e (ref max %.3e)" % (os.environ["VL_PROBE_CMP"], float((got - ref).norm() / ref.norm()),
+                                                                  float((got - ref).abs().max()), float(ref.abs().max())))
     t0 = time.perf_counter()
     for _ in range(iters):
         run()

@@ -884,6 +884,39 @@ struct ConvDmaParams {
     int nblk;                // ceil(K / 16) blocks
 };
 
+// Helpers of the split-product ("bf16x3") convolution, conv_ring_kernel below: an fp32 operand x is split into a bf16 head
+// and a bf16 tail, x = hi + lo + O(2^-17 |x|), and a product is hi*hi + hi*lo + lo*hi on the bf16 matrix pipe (16x the fp32
+// MFMA rate) with fp32 accumulators.  Operands stay fp32 in HBM, so every other kernel is unchanged.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int I> struct IntC { static constexpr int value = I; };
+template <int B, int E, typename F>
+__device__ __forceinline__ void static_for(F&& f) {     // f(IntC<B>) ... f(IntC<E-1>): indices that must be compile-time constants
+    if constexpr (B < E) {
+        f(IntC<B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+struct SplitBf16 {        // 8 reduction positions of one operand row/column: 4 dwords of bf16 pairs, head and tail
+    int hi[4], lo[4];
+};
+template <bool TAIL>
+__device__ __forceinline__ void split_pair(float x0, float x1, int& hi, int& lo) {
+    const f32x2 v = {x0, x1};
+    const uint32_t h = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));      // round to nearest even
+    hi = (int)h;
+    if (TAIL) {
+        const f32x2 r = {x0 - __uint_as_float(h << 16), x1 - __uint_as_float(h & 0xffff0000u)};
+        lo = (int)__builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2));
+    }
+}
+__device__ __forceinline__ f32x16 mfma_bf16(const int (&a)[4], const int (&b)[4], const f32x16& c) {
+    const i32x4 av = {a[0], a[1], a[2], a[3]}, bv = {b[0], b[1], b[2], b[3]};
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), c, 0, 0, 0);
+}
+
 template <int SR>   // reduction rows per stage: 64 (one workgroup per CU) or 32 (two: one's epilogue under the other's MFMAs)
 __global__ __launch_bounds__(NT, 64 / SR) void conv_dma_kernel(const ConvDmaParams pa, const ConvGeom g, const EpiConvNCHW::Params pe,
                                                                int tiles_i) {
@@ -1085,6 +1118,290 @@ __global__ __launch_bounds__(NT, 64 / SR) void conv_dma_kernel(const ConvDmaPara
     }
 }
 
+// ---- conv forward / dgrad with split-bf16 products: deep LDS ring, 16-byte fetches (padded layout, 128 x 256 tiles) ---
+// What bounds the split-product form is not the matrix pipe: a v_mfma_f32_32x32x16_bf16 occupies it for 32 cycles but only
+// ~24 cycles of other vector issue (6 VALU / LDS instructions, shared by the SIMD's two waves) hide beside it, and an
+// in-register head/tail split costs 5 VALU per operand pair.  With both operands split in the kernel (conv_dma_kernel<32, 3>)
+// that is 11 VALU per MFMA and bf16x3 stops at 1.65x the fp32 kernel, whatever the fetch pipeline does (measured: removing the
+// fetches changes nothing, removing the split -25 %).  So:
+//  * the WEIGHT operand is split once per launch by conv_wsplit_kernel into the exact image a stage's LDS slot holds
+//    ([stage][head | tail][lane half][channel][4 bf16 pairs]): the conv kernel fetches it with linear 16-byte LDS-DMA and
+//    reads an MFMA operand with one ds_read_b128, no VALU;
+//  * the im2col operand is fetched 16 B per lane (`buffer_load_dwordx4 ... lds`, lane l lands at M0 + 16 l): ONE reduction
+//    row x 256 pixels per instruction, lane l = the 4 consecutive output pixels 4 l .. 4 l + 3.  Four consecutive output
+//    pixels are four consecutive input floats only inside an image row, so the tile enumerates pixels over rows padded to
+//    OWp = roundup(OW, 4) (13 -> 16, 57 -> 60): the dead pixels read whatever follows the row (halo or the next row: finite,
+//    inside the buffer's range check), cost MFMA cycles and are dropped by the epilogue.  Requires unit column stride in
+//    memory (stride-1 layers, or the phase-split x0 of conv1).  It is split in registers (5 VALU per pair);
+//  * the LDS is spent on latency: ONE workgroup of 8 waves per CU, stages of 16 reduction rows (24 KB), a ring of NBUF = 5.
+// Stage st: MFMAs on the operands of stage st (registers) while the VALU splits the im2col operands of stage st + 1 (read
+// from LDS one stage ago), the LDS reads of stage st + 2 are in flight, and stage st + 6 streams into the slot stage st + 1
+// occupied.  The barrier at the end of stage st waits (vmcnt) only for stage st + 3.  Every wave issues exactly FW = 3
+// fetches per stage, in stage order, so "all but the last 9" means stage st + 3 has landed.
+// Reduction position p = 16 st + 8 h + 2 q + e of a stage belongs to lane half h, bf16 pair q, element e of the MFMA operand.
+__device__ __forceinline__ void lds_dma_row4(i32x4 rs, uint32_t lds_byte_addr, uint32_t voff, int soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_byte_addr), "v"(voff), "s"(rs), "s"(soff)
+                 : "m0");
+}
+
+// out[group][stage][plane: head, tail][h][co < CogP][q] = bf16 pair of weight rows row_tab[stage] + 8 h + 2 q, + 1 (zero past K / Cog)
+__global__ void conv_wsplit_kernel(const float* __restrict__ w, int64_t w_ld, int64_t w_grp_stride, const int* __restrict__ row_tab,
+                                   int K, int Cog, int CogP, int nstages, uint32_t* __restrict__ out) {
+    const int st = blockIdx.x, zg = blockIdx.y;
+    const int row0 = row_tab[st];
+    uint32_t* o = out + ((int64_t)zg * nstages + st) * 16 * CogP;
+    for (int idx = threadIdx.x; idx < 8 * CogP; idx += blockDim.x) {
+        const int q = idx & 3, co = (idx >> 2) % CogP, h = idx / (4 * CogP);
+        const int r = 8 * h + 2 * q, p = st * 16 + r;
+        float x0 = 0.f, x1 = 0.f;
+        if (co < Cog) {
+            const float* src = w + (int64_t)(row0 + r) * w_ld + zg * w_grp_stride + co;
+            if (p < K) x0 = src[0];
+            if (p + 1 < K) x1 = src[w_ld];
+        }
+        int hi, lo;
+        split_pair<true>(x0, x1, hi, lo);
+        o[(int64_t)(h * CogP + co) * 4 + q] = (uint32_t)hi;
+        o[(int64_t)((2 + h) * CogP + co) * 4 + q] = (uint32_t)lo;
+    }
+}
+
+struct ConvRingParams {
+    const uint32_t* wsplit;  // conv_wsplit_kernel's image
+    int CogP;                // its channel pitch (Cog rounded up to the 128-channel tile)
+    int nstages;             // ceil(K / 16)
+};
+
+template <int MATH>
+__global__ __launch_bounds__(512, 1) void conv_ring_kernel(const ConvRingParams pa, const ConvGeom g, const EpiConvNCHW::Params pe,
+                                                           int tiles_i, int OWp, int Mp, FastDiv dOHWp, FastDiv dOWp) {
+    constexpr int BM = 128, BN = 256, SR = 16, NBUF = 5;
+    constexpr int ABUF = SR * BM, BUF = SR * (BM + BN);               // dwords
+    constexpr int FW = 3;                                             // fetches per wave per stage: one weight piece, im2col rows 2w, 2w + 1
+    constexpr int NP = MATH == 3 ? 3 : 1;
+    constexpr int NM = 4 * NP;                                        // MFMAs per wave per stage
+    static_assert(SR == KBLK, "one stage = one block of the reduction order");
+    extern __shared__ __attribute__((aligned(16))) float ldsr[];
+    const int bid = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int ti_blk = bid % tiles_i, tj_blk = bid / tiles_i;
+    const int zg = blockIdx.y;
+    const int i0 = ti_blk * BM, j0 = tj_blk * BN;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int OHWp = g.OHW / g.OW * OWp;
+    const int nstages = pa.nstages;
+
+    // weights: wave w fetches piece w of a stage's image = (plane w >> 2, lane half (w >> 1) & 1, channels 64 (w & 1) ..+63),
+    // 16 B per lane; the piece lands at dword 256 w of the slot, i.e. the slot holds [plane][h][128 channels][4 pairs]
+    const int64_t stage_dw = (int64_t)16 * pa.CogP;                   // dwords per stage of the image
+    const uint32_t* wbase = pa.wsplit + (int64_t)zg * nstages * stage_dw;
+    const i32x4 rs_w = rsrc_words(reinterpret_cast<const float*>(wbase), nstages * stage_dw * 4);
+    const uint32_t voff_a = (uint32_t)(((wave >> 1) * pa.CogP + i0 + (wave & 1) * 64 + lane) * 16);
+    const int stage_bytes = (int)(stage_dw * 4);
+    const i32x4 rs_x = rsrc_words(g.x + (int64_t)zg * g.grp_stride, (g.total - (int64_t)zg * g.grp_stride) * 4);
+    // pixels 4 lane .. 4 lane + 3 of the tile, in the padded-row enumeration
+    uint32_t voff_b;
+    {
+        const int m = j0 + 4 * lane;
+        const bool vm = m < Mp;
+        const uint32_t mm = vm ? m : 0;
+        const uint32_t n = fd_div(mm, dOHWp);
+        const uint32_t p = mm - n * OHWp;
+        const uint32_t oh = fd_div(p, dOWp);
+        const uint32_t ow = p - oh * OWp;
+        const int ih0 = (int)oh * g.stride - g.pt + g.halo, iw0 = (int)ow * g.col_mul + g.col_add;
+        voff_b = vm ? (uint32_t)((int64_t)n * g.img_stride + (int64_t)ih0 * g.Wp + iw0) * 4u : OOB_OFF;
+    }
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)ldsr;
+
+    // this wave fetches im2col rows 2 wave, 2 wave + 1 of every stage; their offsets sit in SGPRs
+    int tab0 = 0, tab1 = 0;
+    const int wrow = wave * 2;
+    auto load_table = [&](int st) __attribute__((always_inline)) {
+        const int sc = min(st, nstages - 1) + st * g.zero;            // stages past the end are never fetched: any valid entry
+        const const_int_ptr tt = as_const(g.ktab) + sc * SR + wrow;
+        tab0 = tt[0];
+        tab1 = tt[1];
+    };
+    auto pin_table = [&]() __attribute__((always_inline)) {
+        asm volatile("" : "+s"(tab0));
+        asm volatile("" : "+s"(tab1));
+    };
+    // fetch f of stage st into the ring slot at byte offset wr: 0 = the weight piece, 1 / 2 = im2col rows 2w / 2w + 1.
+    // Reduction positions past K (tail of the last stage): the weight image holds zeros there and the im2col side fetches
+    // zeros through the per-lane range check (an offset of OOB_OFF).
+    auto dma = [&](const uint32_t wr, const int f, int st) __attribute__((always_inline)) {
+        if (f == 0) {
+            lds_dma_row4(rs_w, lds0 + wr + (uint32_t)wave * 1024u, voff_a, st * stage_bytes);
+        } else {
+            const bool live = st * SR + wrow + (f - 1) < g.K;
+            lds_dma_row4(rs_x, lds0 + wr + (uint32_t)(ABUF + (wrow + f - 1) * BN) * 4u, live ? voff_b : OOB_OFF, f == 1 ? tab0 : tab1);
+        }
+    };
+    auto dma_fast = [&](const uint32_t wr, const int f, int st) __attribute__((always_inline)) {   // every position of the stage lies below K
+        if (f == 0) lds_dma_row4(rs_w, lds0 + wr + (uint32_t)wave * 1024u, voff_a, st * stage_bytes);
+        else lds_dma_row4(rs_x, lds0 + wr + (uint32_t)(ABUF + (wrow + f - 1) * BN) * 4u, voff_b, f == 1 ? tab0 : tab1);
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
+
+    // lane half h = lane >> 5 owns reduction rows 8 h .. 8 h + 7 of a stage.  Weights: block a of this wave = channels
+    // 64 wm + 32 a + (lane & 31); its operand is the 16 B at [plane][h][channel].  im2col: rows 8 h + j, pixel 64 wn + 32 b + (lane & 31).
+    const float* fa = ldsr + ((lane >> 5) * BM + wm * 64 + (lane & 31)) * 4;
+    const float* fb = ldsr + ABUF + (lane >> 5) * 8 * BN + wn * 64 + (lane & 31);
+    struct Raw {                                                      // a stage's operands of this lane as read from LDS
+        i32x4 ahi[2], alo[2];
+        float2 b[8];
+    };
+    auto load_raw = [&](int rd, Raw& r) __attribute__((always_inline)) {                  // rd: ring slot offset in dwords
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            r.ahi[a] = *reinterpret_cast<const i32x4*>(fa + rd + a * 32 * 4);
+            if constexpr (NP == 3) r.alo[a] = *reinterpret_cast<const i32x4*>(fa + rd + 2 * BM * 4 + a * 32 * 4);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float* q = fb + rd + j * BN;
+            r.b[j] = float2{q[0], q[32]};
+        }
+    };
+    auto split = [&](const Raw& r, SplitBf16 (&A)[2], SplitBf16 (&B)[2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                A[a].hi[j] = r.ahi[a][j];
+                if constexpr (NP == 3) A[a].lo[j] = r.alo[a][j];
+            }
+            split_pair<NP == 3>(r.b[2 * j].x, r.b[2 * j + 1].x, B[0].hi[j], B[0].lo[j]);
+            split_pair<NP == 3>(r.b[2 * j].y, r.b[2 * j + 1].y, B[1].hi[j], B[1].lo[j]);
+        }
+    };
+
+    // ---- prologue: stages 0 .. 4 in flight; stages 0 and 1 landed -> stage 0 split in registers, stage 1 raw in registers;
+    // then stage 5 into slot 0, and stage 2 landed
+    for (int s0 = 0; s0 < NBUF; ++s0) {
+        load_table(s0);
+        pin_table();
+        if (s0 < nstages) {
+#pragma unroll
+            for (int f = 0; f < FW; ++f) dma((uint32_t)(s0 * BUF * 4), f, s0);
+        }
+    }
+    load_table(NBUF);
+    pin_table();
+    if (nstages >= NBUF) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");               // groups 0, 1 of 5 done
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    SplitBf16 A[2] = {}, B[2] = {}, An[2] = {}, Bn[2] = {};
+    Raw R0 = {}, R1 = {};
+    load_raw(0, R0);
+    load_raw(BUF, R1);
+    split(R0, A, B);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (NBUF < nstages) {
+#pragma unroll
+        for (int f = 0; f < FW; ++f) dma(0u, f, NBUF);
+    }
+    load_table(NBUF + 1);
+    pin_table();
+    if (nstages > NBUF) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");                // groups 2 .. 5 issued since: stage 2 done
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    int rd = 2 * BUF;                                                 // ring slot (dwords) of stage st + 2
+    uint32_t wr = BUF * 4;                                            // ring slot (bytes) of stage st + 6 = the one of stage st + 1
+    constexpr int D = NBUF + 1;
+    // Ac / Bc: operands of stage st; An / Bn receive stage st + 1, split from Rc; Rn receives the LDS reads of stage st + 2.
+    // The register sets swap roles every stage.
+    auto stage = [&](const bool fast, int st, SplitBf16 (&Ac)[2], SplitBf16 (&Bc)[2], SplitBf16 (&An)[2], SplitBf16 (&Bn)[2],
+                     const Raw& Rc, Raw& Rn) __attribute__((always_inline)) {
+        load_raw(rd, Rn);                                             // garbage past the end: never multiplied
+        static_for<0, NM>([&](auto MI) __attribute__((always_inline)) {
+            constexpr int m = decltype(MI)::value;
+            constexpr int prod = m >> 2, a = (m >> 1) & 1, b = m & 1;
+            acc[a][b] = mfma_bf16(prod == 2 ? Ac[a].lo : Ac[a].hi, prod == 1 ? Bc[b].lo : Bc[b].hi, acc[a][b]);
+            if constexpr (m < FW) {                                   // one fetch in the shadow of each of the first three MFMAs
+                if (fast) dma_fast(wr, m, st + D);
+                else if (st + D < nstages) dma(wr, m, st + D);
+            }
+            __builtin_amdgcn_sched_barrier(0x106);                    // VALU / SALU / LDS reads may move across, MFMAs and fetches stay put
+        });
+        split(Rc, An, Bn);
+        load_table(st + D + 1);
+        pin_table();
+        rd = rd + BUF == NBUF * BUF ? 0 : rd + BUF;
+        wr = wr + BUF * 4 == NBUF * BUF * 4 ? 0u : wr + BUF * 4;
+    };
+    auto finish = [&](int st) __attribute__((always_inline)) {
+        // groups issued so far end with stage min(st + D, nstages - 1); stage st + 3 must have landed
+        const int after = min(st + D, nstages - 1) - (st + 3);
+        if (after >= 3) asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");
+        else if (after == 2) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+        else if (after == 1) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+    // stage st + D lies entirely below K (and exists) for st + D < nfull: the fast fetch form
+    const int nfull = g.K / SR;
+    int st = 0;
+    for (; st + 1 + D < nfull; st += 2) {
+        stage(true, st, A, B, An, Bn, R1, R0);
+        asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        stage(true, st + 1, An, Bn, A, B, R0, R1);
+        asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    for (; st < nstages; st += 2) {
+        stage(false, st, A, B, An, Bn, R1, R0);
+        finish(st);
+        if (st + 1 < nstages) {
+            stage(false, st + 1, An, Bn, A, B, R0, R1);
+            finish(st + 1);
+        }
+    }
+
+    // ---- epilogue: NCHW (+ halo), bias, ReLU, ReluGrad mask.  Accumulator (a, b, q) of lane l: channel 64 wm + 32 a + i,
+    // i = (q & 3) + 8 (q >> 2) + 4 (l >> 5); pixel 64 wn + 32 b + (l & 31) of the padded-row enumeration
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int m = j0 + wn * 64 + 32 * b + (lane & 31);
+        if (m >= Mp) continue;
+        const uint32_t n = fd_div((uint32_t)m, dOHWp);
+        const uint32_t p = m - n * OHWp;
+        const uint32_t oh = fd_div(p, dOWp);
+        const uint32_t ow = p - oh * OWp;
+        if ((int)ow >= pe.OW) continue;                                // dead pixel of the row padding
+        const int64_t c0 = (int64_t)n * pe.Cout_total + (int64_t)zg * pe.Cog;
+        const int64_t ybase = c0 * pe.y_plane + (int64_t)(oh + pe.y_halo) * pe.y_wp + ow + pe.y_halo;
+        const int64_t mbase = c0 * pe.m_plane + (int64_t)(oh + pe.m_halo) * pe.m_wp + ow + pe.m_halo;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int i = (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+                const int co = i0 + wm * 64 + 32 * a + i;
+                if (co < pe.Cog) {
+                    float v = acc[a][b][q];
+                    if (pe.bias) v += pe.bias[zg * pe.Cog + co];
+                    if (pe.relu) v = fmaxf(v, 0.f);
+                    if (pe.mask) v = pe.mask[mbase + (int64_t)co * pe.m_plane] > 0.f ? v : 0.f;
+                    pe.y[ybase + (int64_t)co * pe.y_plane] = v;
+                }
+            }
+        }
+    }
+}
+
 // out[e] = sum_s slab[s][e] (+bias[e % n_cols]) (relu) (mask) : deterministic split reduction.
 __global__ void reduce_slabs_kernel(const float* __restrict__ ws, float* __restrict__ out, int64_t count, int splits,
                                     int64_t slab_stride, const float* __restrict__ bias, int ncols, int64_t ldc,
@@ -1125,6 +1442,8 @@ struct vl_conv_desc {
     int* rowtab_fwd;
     int* rowtab_bwd;
     int fwd_padded, bwd_padded;
+    uint32_t* wsplit_fwd;   // conv_wsplit_kernel's image of the forward / dgrad weights (split-product arithmetic only)
+    uint32_t* wsplit_bwd;
 };
 
 static void tf_same_pad(int in, int k, int s, int* out, int* before, int* after) {
@@ -1252,7 +1571,10 @@ extern "C" int vl_conv_create(vl_conv_desc** out, int cin, int h, int w, int cou
     d->cog = cout / groups;
     d->K = kh * kw * d->cig;
     d->Kd = kh * kw * d->cog;
-    if (rebuild_tables(d)) {
+    // weight images of the split-product kernels: [groups][ceil(K / 16)][16][channels rounded up to 128] dwords each
+    const size_t sf = (size_t)groups * ceil_div(d->K, KBLK) * 16 * (ceil_div(d->cog, 128) * 128) * 4;
+    const size_t sb = (size_t)groups * ceil_div(d->Kd, KBLK) * 16 * (ceil_div(d->cig, 128) * 128) * 4;
+    if (rebuild_tables(d) || hipMalloc((void**)&d->wsplit_fwd, sf) != hipSuccess || hipMalloc((void**)&d->wsplit_bwd, sb) != hipSuccess) {
         vl_conv_destroy(d);
         vl_set_error("vl_conv_create: device table allocation failed");
         return 2;
@@ -1290,6 +1612,8 @@ extern "C" void vl_conv_destroy(vl_conv_desc* d) {
     free_dev(d->ptab2_bwd);
     free_dev(d->rowtab_fwd);
     free_dev(d->rowtab_bwd);
+    free_dev(d->wsplit_fwd);
+    free_dev(d->wsplit_bwd);
     free(d);
 }
 
@@ -1527,6 +1851,21 @@ __global__ __launch_bounds__(NT, 2) void conv_dma16_kernel(const ConvDmaParams p
     }
 }
 
+// contraction arithmetic of conv forward / dgrad: 0 = fp32 MFMA (default, the parity path), 3 = bf16x3 split products
+// (vl_set_conv_math; VL_CONV_MATH=bf16x3 presets it)
+static int g_conv_math = [] {
+    const char* e = getenv("VL_CONV_MATH");
+    return e != nullptr && strcmp(e, "bf16x3") == 0 ? 3 : 0;
+}();
+
+extern "C" int vl_set_conv_math(int math) {
+    VL_CHECK(math == 0 || math == 3, "vl_set_conv_math: 0 (fp32) or 3 (bf16x3)");
+    g_conv_math = math;
+    return 0;
+}
+
+extern "C" int vl_conv_math(void) { return g_conv_math; }
+
 template <int BM>   // 128: conv_dma_kernel (32x32 MFMA tiles); 48 / 96: conv_dma16_kernel (16x16 tiles)
 static int launch_conv_dma(const ConvGeom& g, const float* w, int64_t w_ld, int w_grp_stride, const int* row_tab, int Cog,
                            int Cout_total, const ConvOut& o, hipStream_t s) {
@@ -1554,11 +1893,43 @@ static int launch_conv_dma(const ConvGeom& g, const float* w, int64_t w_ld, int 
     return 0;
 }
 
+static int launch_conv_ring(const ConvGeom& g, const float* w, int64_t w_ld, int w_grp_stride, const int* row_tab, int Cog,
+                            int Cout_total, const ConvOut& o, uint32_t* wsplit, hipStream_t s) {
+    constexpr int BM = 128, BN = 256;
+    constexpr size_t lds = (size_t)5 * 16 * (BM + BN) * sizeof(float);       // 120 KB: one workgroup per CU
+    const int groups = Cout_total / Cog, nstages = ceil_div(g.K, KBLK), CogP = ceil_div(Cog, BM) * BM;
+    hipLaunchKernelGGL(conv_wsplit_kernel, dim3(nstages, groups), dim3(256), 0, s, w, w_ld, (int64_t)w_grp_stride, row_tab, g.K, Cog,
+                       CogP, nstages, wsplit);
+    VL_LAUNCH_CHECK();
+    ConvRingParams pa{wsplit, CogP, nstages};
+    EpiConvNCHW::Params pe;
+    pe.y = o.y; pe.bias = o.bias; pe.mask = o.mask; pe.relu = o.relu;
+    pe.Cog = Cog; pe.Cout_total = Cout_total; pe.OHW = g.OHW; pe.OW = g.OW; pe.M = g.M;
+    pe.dOHW = g.dOHW; pe.dOW = g.dOW;
+    pe.y_halo = o.y_halo; pe.y_wp = o.OW + 2 * o.y_halo; pe.y_plane = (int64_t)(o.OH + 2 * o.y_halo) * pe.y_wp;
+    pe.m_halo = o.m_halo; pe.m_wp = o.OW + 2 * o.m_halo; pe.m_plane = (int64_t)(o.OH + 2 * o.m_halo) * pe.m_wp;
+    static bool attr_set = false;
+    auto kern = conv_ring_kernel<3>;
+    if (!attr_set) {
+        VL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const int OH = g.OHW / g.OW, OWp = (g.OW + 3) / 4 * 4, Mp = g.M / g.OW * OWp;
+    const int tiles_i = ceil_div(Cog, BM), tiles_j = ceil_div(Mp, BN);
+    dim3 grid(tiles_i * tiles_j, (unsigned)groups, 1);
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, pa, g, pe, tiles_i, OWp, Mp, make_fastdiv(OH * OWp), make_fastdiv(OWp));
+    VL_LAUNCH_CHECK();
+    return 0;
+}
+
 template <bool PADDED>
 static int dispatch_conv(const ConvGeom& g, const float* w, int64_t w_ld, int w_grp_stride, const int* row_tab, int Cog,
-                         int Cout_total, const ConvOut& o, hipStream_t s) {
+                         int Cout_total, const ConvOut& o, uint32_t* wsplit, hipStream_t s) {
     // output-channel tile: 128 when it divides well, else 96 (conv1: 96, conv4: 192) or 64 (conv2 dgrad: 48)
     const int w128 = ceil_div(Cog, 128) * 128, w96 = ceil_div(Cog, 96) * 96, w64 = ceil_div(Cog, 64) * 64;
+    // split products: the ring kernel (128-channel tiles; its 16-byte im2col fetches need unit column stride in memory)
+    if (g_conv_math == 3 && PADDED && Cog >= 96 && g.col_mul == 1)
+        return launch_conv_ring(g, w, w_ld, w_grp_stride, row_tab, Cog, Cout_total, o, wsplit, s);
     if (w128 <= w96 && w128 <= w64) {
         // 128-wide tiles in the padded layout: the LDS-DMA kernel
         if (PADDED && (int64_t)g.K * w_ld * 4 < MAX_BUF_BYTES && getenv("VL_CONV_STAGED") == nullptr) {
@@ -1605,8 +1976,8 @@ extern "C" int vl_conv_fwd(const vl_conv_desc* d, const float* x, const float* w
     VL_CHECK(g.total * 4 < MAX_BUF_BYTES, "vl_conv_fwd: input of %lld elements exceeds the buffer-offset range", (long long)g.total);
     ConvOut o{y, bias, nullptr, relu, d->y_halo, 0, d->oh, d->ow};
     // HWIO weights are the [K][Cout_total] GEMM operand as they stand; group g = column block g*cog.
-    if (d->fwd_padded) return dispatch_conv<true>(g, w, d->cout, d->cog, d->rowtab_fwd, d->cog, d->cout, o, (hipStream_t)stream);
-    return dispatch_conv<false>(g, w, d->cout, d->cog, d->rowtab_fwd, d->cog, d->cout, o, (hipStream_t)stream);
+    if (d->fwd_padded) return dispatch_conv<true>(g, w, d->cout, d->cog, d->rowtab_fwd, d->cog, d->cout, o, d->wsplit_fwd, (hipStream_t)stream);
+    return dispatch_conv<false>(g, w, d->cout, d->cog, d->rowtab_fwd, d->cog, d->cout, o, d->wsplit_fwd, (hipStream_t)stream);
 }
 
 __global__ void conv_wt_transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, int KH, int KW, int cig,
@@ -1645,8 +2016,8 @@ extern "C" int vl_conv_dgrad(const vl_conv_desc* d, const float* dy, const float
               d->ptab_bwd, d->ptab2_bwd);
     VL_CHECK(g.total * 4 < MAX_BUF_BYTES, "vl_conv_dgrad: dy of %lld elements exceeds the buffer-offset range", (long long)g.total);
     ConvOut o{dx, nullptr, relu_mask, 0, d->dx_halo, d->x_halo, d->h, d->w};
-    if (d->bwd_padded) return dispatch_conv<true>(g, wt, d->cin, d->cig, d->rowtab_bwd, d->cig, d->cin, o, (hipStream_t)stream);
-    return dispatch_conv<false>(g, wt, d->cin, d->cig, d->rowtab_bwd, d->cig, d->cin, o, (hipStream_t)stream);
+    if (d->bwd_padded) return dispatch_conv<true>(g, wt, d->cin, d->cig, d->rowtab_bwd, d->cig, d->cin, o, d->wsplit_bwd, (hipStream_t)stream);
+    return dispatch_conv<false>(g, wt, d->cin, d->cig, d->rowtab_bwd, d->cig, d->cin, o, d->wsplit_bwd, (hipStream_t)stream);
 }
 
 // ---- conv wgrad -------------------------------------------------------------------------------

@@ -49,6 +49,7 @@ class NetConfig:
     frame_fusion: Optional[Tuple[str, str]] = None   # classifier fc: (early|late, avg|last) (model.py:103-106,149-151)
     dropout_keep_prob: float = 0.0              # <= 0 disables (lstm.py:52)
     optimizer: str = "sgd"                      # defs.optim.{sgd, adam}
+    conv_math: str = "f32"                      # "f32" | "bf16x3" (ops.set_conv_math: opt-in split-bf16 conv products)
 
     def encode_dim(self):
         return FC_DIM if self.frame_encoding_layer in ("fc6", "fc7") else self.num_classes
@@ -344,6 +345,7 @@ class LRCNEngine:
     # ---- forward -------------------------------------------------------------------------------
     def _forward(self, n, b, train):
         P, cfg = self.P, self.cfg
+        ops.set_conv_math(cfg.conv_math)             # process-wide switch: set per call so that engines of both kinds can coexist
         x = self.x0[:n]
         for L in self.layers:
             name = L["name"]

@@ -337,6 +337,20 @@ def fill(t, value):
     _ffi.call("vl_fill", _p(t), t.numel(), value, stream())
 
 
+CONV_MATH = {"f32": 0, "bf16x3": 3}
+
+
+def set_conv_math(name):
+    """Arithmetic of conv forward / dgrad (vl_set_conv_math): "f32" (default) or "bf16x3" (split bf16 products, opt-in)."""
+    if name not in CONV_MATH:
+        raise _ffi.VltfError("conv math must be one of %s, not %r" % (sorted(CONV_MATH), name))
+    _ffi.call("vl_set_conv_math", CONV_MATH[name])
+
+
+def conv_math():
+    return {v: k for k, v in CONV_MATH.items()}[int(_ffi.lib().vl_conv_math())]
+
+
 def relu_grad(d, y, count=None):
     """d = y > 0 ? d : 0 in place over the first `count` elements."""
     _f32(d, y); _dense(d, y)
