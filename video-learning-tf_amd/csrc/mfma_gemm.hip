@@ -670,7 +670,40 @@ __device__ __forceinline__ void lds_dma_row(i32x4 rs, uint32_t lds_byte_addr, ui
                  : "m0");
 }
 
-template <int BN, int WM, int WN>
+// Helpers of the split-product ("bf16x3") convolution, conv_ring_kernel below: an fp32 operand x is split into a bf16 head
+// and a bf16 tail, x = hi + lo + O(2^-17 |x|), and a product is hi*hi + hi*lo + lo*hi on the bf16 matrix pipe (16x the fp32
+// MFMA rate) with fp32 accumulators.  Operands stay fp32 in HBM, so every other kernel is unchanged.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int I> struct IntC { static constexpr int value = I; };
+template <int B, int E, typename F>
+__device__ __forceinline__ void static_for(F&& f) {     // f(IntC<B>) ... f(IntC<E-1>): indices that must be compile-time constants
+    if constexpr (B < E) {
+        f(IntC<B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+struct SplitBf16 {        // 8 reduction positions of one operand row/column: 4 dwords of bf16 pairs, head and tail
+    int hi[4], lo[4];
+};
+template <bool TAIL>
+__device__ __forceinline__ void split_pair(float x0, float x1, int& hi, int& lo) {
+    const f32x2 v = {x0, x1};
+    const uint32_t h = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));      // round to nearest even
+    hi = (int)h;
+    if (TAIL) {
+        const f32x2 r = {x0 - __uint_as_float(h << 16), x1 - __uint_as_float(h & 0xffff0000u)};
+        lo = (int)__builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2));
+    }
+}
+__device__ __forceinline__ f32x16 mfma_bf16(const int (&a)[4], const int (&b)[4], const f32x16& c) {
+    const i32x4 av = {a[0], a[1], a[2], a[3]}, bv = {b[0], b[1], b[2], b[3]};
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), c, 0, 0, 0);
+}
+
+template <int BN, int WM, int WN, int MATH = 0>   // MATH 3: split bf16 products (vl_set_conv_math), see tile_split
 __global__ __launch_bounds__(NT, 1) void wgrad_dma_kernel(const ConvGeom g, const DyParams d, const EpiRowMajor::Params pe,
                                                           int tiles_i, int tiles_j, int groups, int units, int rtiles,
                                                           int rt_per_split, float* db_slabs, int db_stride) {
@@ -710,7 +743,7 @@ __global__ __launch_bounds__(NT, 1) void wgrad_dma_kernel(const ConvGeom g, cons
     const int64_t dy_img = (int64_t)d.Cout_total * d.plane;
 
     uint32_t voff_x, voff_dy;
-    auto decode = [&](int rt) {                           // per-lane byte offsets of the tile's 64 pixels
+    auto decode = [&](int rt) __attribute__((always_inline)) {                           // per-lane byte offsets of the tile's 64 pixels
         const int m = rt * 64 + lane;
         const bool vm = m < g.M;
         const uint32_t mm = vm ? m : 0;
@@ -733,17 +766,17 @@ __global__ __launch_bounds__(NT, 1) void wgrad_dma_kernel(const ConvGeom g, cons
     // in the quiet tail of every tile and made opaque: left to itself hipcc re-materialises the s_loads right in front of the
     // first fetch of each tile and waits for them there.
     int tabv[RA];
-    auto load_table = [&](int rt) {                        // issue the wide s_loads ...
+    auto load_table = [&](int rt) __attribute__((always_inline)) {                        // issue the wide s_loads ...
         const const_int_ptr tt = (const_int_ptr)(uintptr_t)(tab + rt * g.zero);
 #pragma unroll
         for (int f = 0; f < RA; ++f) tabv[f] = tt[f];
     };
-    auto pin_table = [&]() {                               // ... and, a few MFMAs later, wait for them and fix them in SGPRs
+    auto pin_table = [&]() __attribute__((always_inline)) {                               // ... and, a few MFMAs later, wait for them and fix them in SGPRs
 #pragma unroll
         for (int f = 0; f < RA; ++f) asm volatile("" : "+s"(tabv[f]));
     };
     // fetch number f (0 .. RA + RB - 1) of the next tile: A rows first, then B rows
-    auto dma = [&](const int nb, const int f, int rt_next) {
+    auto dma = [&](const int nb, const int f, int rt_next) __attribute__((always_inline)) {
         const int z = rt_next * g.zero;
         if (f < RA) {
             const uint32_t la = lds0 + (uint32_t)(wave * (RA * STR) + z) * 4u;
@@ -756,7 +789,7 @@ __global__ __launch_bounds__(NT, 1) void wgrad_dma_kernel(const ConvGeom g, cons
     };
     // bias row: local row K - i0 of the LAST i-tile (uniform)
     const int ones_row = (db_slabs != nullptr && g.K >= i0 && g.K < i0 + BM) ? g.K - i0 : -1;
-    auto finish_tile = [&](const int nb) {                // DMAs of buffer nb landed -> visible to every wave
+    auto finish_tile = [&](const int nb) __attribute__((always_inline)) {                // DMAs of buffer nb landed -> visible to every wave
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (ones_row >= 0 && (ones_row / RA) == wave) ldsw[nb * BUF + ones_row * STR + lane] = 1.0f;
         __syncthreads();
@@ -787,7 +820,7 @@ __global__ __launch_bounds__(NT, 1) void wgrad_dma_kernel(const ConvGeom g, cons
 
     // one tile: MFMAs on buffer `cur` while tile rt_next streams into the other buffer.  The fetch for a tile past
     // this split's range is harmless (valid or range-checked addresses, never read) and keeps the body branch-free.
-    auto tile = [&](const int cur, int rt_next) {
+    auto tile = [&](const int cur, int rt_next) __attribute__((always_inline)) {
         float2 af[2][TM], bf[2][TN];
 #pragma unroll
         for (int a = 0; a < TM; ++a) af[0][a] = *reinterpret_cast<const float2*>(fa + cur * BUF + a * 32 * STR);
@@ -832,12 +865,69 @@ __global__ __launch_bounds__(NT, 1) void wgrad_dma_kernel(const ConvGeom g, cons
         }
         finish_tile(cur ^ 1);
     };
+    // The same tile in split-product arithmetic: the reduction index is the pixel, so one 32x32x16 MFMA consumes 16 of the
+    // tile's 64 pixels; lane half h owns pixels 16 s + 8 h .. + 7 of step s, which sit next to each other in the LDS row, so
+    // a float2 read IS a bf16 pair after the head / tail split (5 VALU per pair, both operands: they are activations).
+    // (TM + TN) x 4 pairs and 3 TM TN MFMAs per step; the row fetches ride in the shadow of the first MFMAs as above, FPM
+    // of them per MFMA because a tile has 4x fewer MFMAs than in fp32.
+    const float* fa3 = ldsw + (wi0 + (lane & 31)) * STR + 8 * (lane >> 5);
+    const float* fb3 = ldsw + SA + (wj0 + (lane & 31)) * STR + 8 * (lane >> 5);
+    auto tile_split = [&](const int cur, int rt_next) __attribute__((always_inline)) {
+        constexpr int NMS = 3 * TM * TN, NTOT = 4 * NMS, NF = RA + RB;
+        constexpr int FPM = (NF + NTOT - 15) / (NTOT - 14);
+        static_assert((NF + FPM - 1) / FPM <= NTOT - 12, "fetches must end before the table is replaced");
+        SplitBf16 As[2][TM], Bs[2][TN];
+        auto load_split = [&](const int st, SplitBf16 (&A)[TM], SplitBf16 (&B)[TN]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float2 v = *reinterpret_cast<const float2*>(fa3 + cur * BUF + a * 32 * STR + 16 * st + 2 * q);
+                    split_pair<true>(v.x, v.y, A[a].hi[q], A[a].lo[q]);
+                }
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float2 v = *reinterpret_cast<const float2*>(fb3 + cur * BUF + b * 32 * STR + 16 * st + 2 * q);
+                    split_pair<true>(v.x, v.y, B[b].hi[q], B[b].lo[q]);
+                }
+        };
+        load_split(0, As[0], Bs[0]);
+        static_for<0, 4>([&](auto SI) __attribute__((always_inline)) {
+            constexpr int st = decltype(SI)::value, c = st & 1;
+            if constexpr (st + 1 < 4) load_split(st + 1, As[c ^ 1], Bs[c ^ 1]);
+            static_for<0, NMS>([&](auto MI) __attribute__((always_inline)) {
+                constexpr int m = decltype(MI)::value;
+                constexpr int prod = m / (TM * TN), a = (m % (TM * TN)) / TN, b = m % TN;
+                acc[a][b] = mfma_bf16(prod == 2 ? As[c][a].lo : As[c][a].hi, prod == 1 ? Bs[c][b].lo : Bs[c][b].hi, acc[a][b]);
+                constexpr int idx = st * NMS + m;
+                static_for<0, FPM>([&](auto EI) __attribute__((always_inline)) {
+                    constexpr int f = idx * FPM + decltype(EI)::value;
+                    if constexpr (f < NF) dma(cur ^ 1, f, rt_next);
+                });
+                __builtin_amdgcn_sched_barrier(0x106);        // VALU / SALU / LDS reads may move across, MFMAs and fetches stay put
+                if constexpr (idx == NTOT - 12) load_table(rt_next + 1);
+                if constexpr (idx == NTOT - 6) {
+                    int rtn = rt_next + 1;
+                    asm volatile("" : "+s"(rtn));
+                    decode(rtn);
+                    pin_table();
+                }
+            });
+        });
+        finish_tile(cur ^ 1);
+    };
+    auto run_tile = [&](const int cur, int rt_next) __attribute__((always_inline)) {
+        if constexpr (MATH == 3) tile_split(cur, rt_next);
+        else tile(cur, rt_next);
+    };
     int rt = rt0;
     for (int i = 0; i + 1 < ntiles; i += 2, rt += 2) {
-        tile(0, rt + 1);
-        tile(1, rt + 2);
+        run_tile(0, rt + 1);
+        run_tile(1, rt + 2);
     }
-    if (ntiles > 0 && (ntiles & 1)) tile(0, rt + 1);
+    if (ntiles > 0 && (ntiles & 1)) run_tile(0, rt + 1);
 
     EpiRowMajor::template apply<TM, TN>(pe, zg, zs, i0 + wi0, j0 + wj0, acc);
     if (ones_row >= 0) {                                  // accumulator row K -> this split's db partial
@@ -883,39 +973,6 @@ struct ConvDmaParams {
     const int* row_tab;      // first weight row of every 16-row block of the reduction order
     int nblk;                // ceil(K / 16) blocks
 };
-
-// Helpers of the split-product ("bf16x3") convolution, conv_ring_kernel below: an fp32 operand x is split into a bf16 head
-// and a bf16 tail, x = hi + lo + O(2^-17 |x|), and a product is hi*hi + hi*lo + lo*hi on the bf16 matrix pipe (16x the fp32
-// MFMA rate) with fp32 accumulators.  Operands stay fp32 in HBM, so every other kernel is unchanged.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-template <int I> struct IntC { static constexpr int value = I; };
-template <int B, int E, typename F>
-__device__ __forceinline__ void static_for(F&& f) {     // f(IntC<B>) ... f(IntC<E-1>): indices that must be compile-time constants
-    if constexpr (B < E) {
-        f(IntC<B>{});
-        static_for<B + 1, E>(f);
-    }
-}
-struct SplitBf16 {        // 8 reduction positions of one operand row/column: 4 dwords of bf16 pairs, head and tail
-    int hi[4], lo[4];
-};
-template <bool TAIL>
-__device__ __forceinline__ void split_pair(float x0, float x1, int& hi, int& lo) {
-    const f32x2 v = {x0, x1};
-    const uint32_t h = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));      // round to nearest even
-    hi = (int)h;
-    if (TAIL) {
-        const f32x2 r = {x0 - __uint_as_float(h << 16), x1 - __uint_as_float(h & 0xffff0000u)};
-        lo = (int)__builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2));
-    }
-}
-__device__ __forceinline__ f32x16 mfma_bf16(const int (&a)[4], const int (&b)[4], const f32x16& c) {
-    const i32x4 av = {a[0], a[1], a[2], a[3]}, bv = {b[0], b[1], b[2], b[3]};
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), c, 0, 0, 0);
-}
 
 template <int SR>   // reduction rows per stage: 64 (one workgroup per CU) or 32 (two: one's epilogue under the other's MFMAs)
 __global__ __launch_bounds__(NT, 64 / SR) void conv_dma_kernel(const ConvDmaParams pa, const ConvGeom g, const EpiConvNCHW::Params pe,
@@ -1422,6 +1479,21 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ ws, float* __restr
     }
 }
 
+// contraction arithmetic of conv forward / dgrad: 0 = fp32 MFMA (default, the parity path), 3 = bf16x3 split products
+// (vl_set_conv_math; VL_CONV_MATH=bf16x3 presets it)
+static int g_conv_math = [] {
+    const char* e = getenv("VL_CONV_MATH");
+    return e != nullptr && strcmp(e, "bf16x3") == 0 ? 3 : 0;
+}();
+
+extern "C" int vl_set_conv_math(int math) {
+    VL_CHECK(math == 0 || math == 3, "vl_set_conv_math: 0 (fp32) or 3 (bf16x3)");
+    g_conv_math = math;
+    return 0;
+}
+
+extern "C" int vl_conv_math(void) { return g_conv_math; }
+
 // ---- convolution descriptor -------------------------------------------------------------------
 struct vl_conv_desc {
     int cin, h, w, cout, kh, kw, stride, groups;
@@ -1851,20 +1923,6 @@ __global__ __launch_bounds__(NT, 2) void conv_dma16_kernel(const ConvDmaParams p
     }
 }
 
-// contraction arithmetic of conv forward / dgrad: 0 = fp32 MFMA (default, the parity path), 3 = bf16x3 split products
-// (vl_set_conv_math; VL_CONV_MATH=bf16x3 presets it)
-static int g_conv_math = [] {
-    const char* e = getenv("VL_CONV_MATH");
-    return e != nullptr && strcmp(e, "bf16x3") == 0 ? 3 : 0;
-}();
-
-extern "C" int vl_set_conv_math(int math) {
-    VL_CHECK(math == 0 || math == 3, "vl_set_conv_math: 0 (fp32) or 3 (bf16x3)");
-    g_conv_math = math;
-    return 0;
-}
-
-extern "C" int vl_conv_math(void) { return g_conv_math; }
 
 template <int BM>   // 128: conv_dma_kernel (32x32 MFMA tiles); 48 / 96: conv_dma16_kernel (16x16 tiles)
 static int launch_conv_dma(const ConvGeom& g, const float* w, int64_t w_ld, int w_grp_stride, const int* row_tab, int Cog,
@@ -2070,11 +2128,12 @@ static int launch_wgrad_dma(const vl_conv_desc* d, const ConvGeom& g, const floa
     EpiRowMajor::Params pe{splits > 1 ? ws : dw, d->cout, d->K, d->cog, nullptr, nullptr, 0, d->cog, splits > 1 ? slab : 0};
     const int tiles_i = ceil_div(d->K, C::BM), tiles_j = ceil_div(d->cog, BN);
     const int rtiles = ceil_div(g.M, C::BR);
-    static bool attr_set = false;
-    auto kern = wgrad_dma_kernel<BN, WM, WN>;
-    if (!attr_set) {
+    static bool attr_set[2] = {false, false};
+    const int v = g_conv_math == 3;
+    auto kern = v ? wgrad_dma_kernel<BN, WM, WN, 3> : wgrad_dma_kernel<BN, WM, WN, 0>;
+    if (!attr_set[v]) {
         VL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
-        attr_set = true;
+        attr_set[v] = true;
     }
     float* db_slabs = db ? (splits > 1 ? ws + (int64_t)splits * slab : db) : nullptr;   // [splits][Cout_total] behind the weight slabs
     const int units = d->groups * splits;
