@@ -19,7 +19,7 @@ rocprofv3 --kernel-trace --stats -d "$out/prof" -o runc -- python3 bench.py --st
 echo "kernel-trace pass done"
 for c in FETCH_SIZE WRITE_SIZE; do
   d="$out/pmc_$(echo $c | tr 'A-Z' 'a-z' | cut -d_ -f1)"
-  rocprofv3 --kernel-trace --pmc $c -d "$d" -o runc -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline \
+  rocprofv3 --kernel-trace --pmc $c -d "$d" -o runc -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-split-math \
       > "$d.json" 2> "$d.err"
   echo "pmc pass $c done"
 done
@@ -30,4 +30,8 @@ tail -c 300 "$out/bench_torchrun1.json"; echo
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES \
     SQ_INSTS_VALU SQ_INSTS_MFMA -d "$out/pmc_sq_conv3fwd" -o runc -- python3 tools/conv_probe.py conv3 fwd 1024 3 \
     > "$out/pmc_sq_conv3fwd.log" 2>&1
+# 6. the same counters for the opt-in bf16x3 kernel of the same launch
+VL_CONV_MATH=bf16x3 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES \
+    SQ_INSTS_VALU SQ_INSTS_MFMA -d "$out/pmc_sq_conv3fwd_bf16x3" -o runc -- python3 tools/conv_probe.py conv3 fwd 1024 3 \
+    > "$out/pmc_sq_conv3fwd_bf16x3.log" 2>&1
 echo "profile_round $tag done"

@@ -105,7 +105,7 @@ def main():
             w = csv.writer(f)
             w.writerow(["Name", "Counter", "Launches", "AvgValue"])
             for n, cn, c, v in con.execute(q):
-                if "mfma" in n or "wgrad" in n or "pool" in n or "lrn" in n:
+                if "mfma" in n or "wgrad" in n or "pool" in n or "lrn" in n or "conv_" in n:
                     w.writerow([short(n), cn, c, round(v, 1)])
 
 

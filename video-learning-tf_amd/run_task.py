@@ -32,7 +32,8 @@ def net_config(settings, dataset):
         error("Only a single dcnn pipeline on the main dataset is built (multi-pipeline description models are out of scope).")
     kw = dict(image_shape=tuple(dataset.get_image_shape()), num_classes=settings.num_classes, fpc=dataset.num_frames_per_clip,
               frame_encoding_layer=p.frame_encoding_layer, classifier=p.classifier or defs.classifier.fc,
-              dropout_keep_prob=settings.get_dropout(), optimizer=settings.train.optimizer if settings.train else "sgd")
+              dropout_keep_prob=settings.get_dropout(), optimizer=settings.train.optimizer if settings.train else "sgd",
+              conv_math=os.environ.get("VLTF_CONV_MATH", "f32"))     # "bf16x3": opt-in split-bf16 conv products (not a reference key)
     if p.classifier == defs.classifier.lstm:
         if p.frame_fusion and p.frame_fusion[0] != defs.fusion_type.none:
             error("The LSTM classifier should be used only with [none] fusion, but it's [%s]" % p.frame_fusion[0])
