@@ -694,6 +694,7 @@ __device__ __forceinline__ void split_pair(float x0, float x1, int& hi, int& lo)
     const uint32_t h = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));      // round to nearest even
     hi = (int)h;
     if (TAIL) {
+        // (left to hipcc, which pairs the two subtractions into one v_pk_add_f32: two scalar v_sub_f32 measured 3-10 % slower)
         const f32x2 r = {x0 - __uint_as_float(h << 16), x1 - __uint_as_float(h & 0xffff0000u)};
         lo = (int)__builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2));
     }
@@ -1229,12 +1230,18 @@ struct ConvRingParams {
     int nstages;             // ceil(K / 16)
 };
 
-template <int MATH>
+// BM = 128: 2 x 4 waves, 128 channels x 256 pixels, ring of 5 x 24 KB.  BM = 64 (48-channel groups: conv2 dgrad): 1 x 8 waves,
+// 64 channels x 512 pixels, ring of 4 x 36 KB; waves 4-7 re-fetch the weight pieces of waves 0-3 (same bytes to the same place)
+// so that every wave issues the same number of fetches per stage.
+template <int MATH, int BM>
 __global__ __launch_bounds__(512, 1) void conv_ring_kernel(const ConvRingParams pa, const ConvGeom g, const EpiConvNCHW::Params pe,
                                                            int tiles_i, int OWp, int Mp, FastDiv dOHWp, FastDiv dOWp) {
-    constexpr int BM = 128, BN = 256, SR = 16, NBUF = 5;
+    constexpr int BN = BM == 128 ? 256 : 512, SR = 16, NBUF = BM == 128 ? 5 : 4;
+    constexpr int NH = BN / 256;                                      // 256-pixel fetches per im2col row
+    static_assert(BM == 128 || BM == 64, "channel tile");
     constexpr int ABUF = SR * BM, BUF = SR * (BM + BN);               // dwords
-    constexpr int FW = 3;                                             // fetches per wave per stage: one weight piece, im2col rows 2w, 2w + 1
+    constexpr int FW = 1 + 2 * NH;                                    // fetches per wave per stage: one weight piece, im2col rows 2w, 2w + 1
+    constexpr int VMW = (NBUF - 2) * FW;                              // fetches that may stay in flight at a stage's end: NBUF - 2 stages
     constexpr int NP = MATH == 3 ? 3 : 1;
     constexpr int NM = 4 * NP;                                        // MFMAs per wave per stage
     static_assert(SR == KBLK, "one stage = one block of the reduction order");
@@ -1245,22 +1252,26 @@ __global__ __launch_bounds__(512, 1) void conv_ring_kernel(const ConvRingParams 
     const int i0 = ti_blk * BM, j0 = tj_blk * BN;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = BM == 128 ? wave >> 2 : 0, wn = BM == 128 ? wave & 3 : wave;
     const int OHWp = g.OHW / g.OW * OWp;
     const int nstages = pa.nstages;
 
-    // weights: wave w fetches piece w of a stage's image = (plane w >> 2, lane half (w >> 1) & 1, channels 64 (w & 1) ..+63),
-    // 16 B per lane; the piece lands at dword 256 w of the slot, i.e. the slot holds [plane][h][128 channels][4 pairs]
+    // weights: wave w fetches one 1 KB piece of a stage's image, 16 B per lane.  BM = 128: piece w = (plane w >> 2, lane half
+    // (w >> 1) & 1, channels 64 (w & 1) ..+63); BM = 64: piece w & 3 = (plane, lane half), 64 channels.  It lands at byte
+    // 1024 piece of the slot, i.e. the slot holds [plane][h][BM channels][4 pairs]
     const int64_t stage_dw = (int64_t)16 * pa.CogP;                   // dwords per stage of the image
     const uint32_t* wbase = pa.wsplit + (int64_t)zg * nstages * stage_dw;
     const i32x4 rs_w = rsrc_words(reinterpret_cast<const float*>(wbase), nstages * stage_dw * 4);
-    const uint32_t voff_a = (uint32_t)(((wave >> 1) * pa.CogP + i0 + (wave & 1) * 64 + lane) * 16);
+    const int piece = BM == 128 ? wave : wave & 3;
+    const uint32_t voff_a = BM == 128 ? (uint32_t)(((wave >> 1) * pa.CogP + i0 + (wave & 1) * 64 + lane) * 16)
+                                      : (uint32_t)((piece * pa.CogP + i0 + lane) * 16);
     const int stage_bytes = (int)(stage_dw * 4);
     const i32x4 rs_x = rsrc_words(g.x + (int64_t)zg * g.grp_stride, (g.total - (int64_t)zg * g.grp_stride) * 4);
-    // pixels 4 lane .. 4 lane + 3 of the tile, in the padded-row enumeration
-    uint32_t voff_b;
-    {
-        const int m = j0 + 4 * lane;
+    // pixels 256 hf + 4 lane .. + 3 of the tile, in the padded-row enumeration
+    uint32_t voff_b[NH];
+#pragma unroll
+    for (int hf = 0; hf < NH; ++hf) {
+        const int m = j0 + 256 * hf + 4 * lane;
         const bool vm = m < Mp;
         const uint32_t mm = vm ? m : 0;
         const uint32_t n = fd_div(mm, dOHWp);
@@ -1268,7 +1279,7 @@ __global__ __launch_bounds__(512, 1) void conv_ring_kernel(const ConvRingParams 
         const uint32_t oh = fd_div(p, dOWp);
         const uint32_t ow = p - oh * OWp;
         const int ih0 = (int)oh * g.stride - g.pt + g.halo, iw0 = (int)ow * g.col_mul + g.col_add;
-        voff_b = vm ? (uint32_t)((int64_t)n * g.img_stride + (int64_t)ih0 * g.Wp + iw0) * 4u : OOB_OFF;
+        voff_b[hf] = vm ? (uint32_t)((int64_t)n * g.img_stride + (int64_t)ih0 * g.Wp + iw0) * 4u : OOB_OFF;
     }
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)ldsr;
 
@@ -1285,20 +1296,27 @@ __global__ __launch_bounds__(512, 1) void conv_ring_kernel(const ConvRingParams 
         asm volatile("" : "+s"(tab0));
         asm volatile("" : "+s"(tab1));
     };
-    // fetch f of stage st into the ring slot at byte offset wr: 0 = the weight piece, 1 / 2 = im2col rows 2w / 2w + 1.
+    // fetch f of stage st into the ring slot at byte offset wr: 0 = the weight piece; 1 + NH r + hf = pixels 256 hf ..+255 of
+    // im2col row 2w + r.
     // Reduction positions past K (tail of the last stage): the weight image holds zeros there and the im2col side fetches
     // zeros through the per-lane range check (an offset of OOB_OFF).
     auto dma = [&](const uint32_t wr, const int f, int st) __attribute__((always_inline)) {
         if (f == 0) {
-            lds_dma_row4(rs_w, lds0 + wr + (uint32_t)wave * 1024u, voff_a, st * stage_bytes);
+            lds_dma_row4(rs_w, lds0 + wr + (uint32_t)piece * 1024u, voff_a, st * stage_bytes);
         } else {
-            const bool live = st * SR + wrow + (f - 1) < g.K;
-            lds_dma_row4(rs_x, lds0 + wr + (uint32_t)(ABUF + (wrow + f - 1) * BN) * 4u, live ? voff_b : OOB_OFF, f == 1 ? tab0 : tab1);
+            const int r = (f - 1) / NH, hf = (f - 1) % NH;
+            const bool live = st * SR + wrow + r < g.K;
+            lds_dma_row4(rs_x, lds0 + wr + (uint32_t)(ABUF + (wrow + r) * BN + 256 * hf) * 4u, live ? voff_b[hf] : OOB_OFF,
+                         r == 0 ? tab0 : tab1);
         }
     };
     auto dma_fast = [&](const uint32_t wr, const int f, int st) __attribute__((always_inline)) {   // every position of the stage lies below K
-        if (f == 0) lds_dma_row4(rs_w, lds0 + wr + (uint32_t)wave * 1024u, voff_a, st * stage_bytes);
-        else lds_dma_row4(rs_x, lds0 + wr + (uint32_t)(ABUF + (wrow + f - 1) * BN) * 4u, voff_b, f == 1 ? tab0 : tab1);
+        if (f == 0) {
+            lds_dma_row4(rs_w, lds0 + wr + (uint32_t)piece * 1024u, voff_a, st * stage_bytes);
+        } else {
+            const int r = (f - 1) / NH, hf = (f - 1) % NH;
+            lds_dma_row4(rs_x, lds0 + wr + (uint32_t)(ABUF + (wrow + r) * BN + 256 * hf) * 4u, voff_b[hf], r == 0 ? tab0 : tab1);
+        }
     };
 
     f32x16 acc[2][2];
@@ -1342,8 +1360,8 @@ __global__ __launch_bounds__(512, 1) void conv_ring_kernel(const ConvRingParams 
         }
     };
 
-    // ---- prologue: stages 0 .. 4 in flight; stages 0 and 1 landed -> stage 0 split in registers, stage 1 raw in registers;
-    // then stage 5 into slot 0, and stage 2 landed
+    // ---- prologue: stages 0 .. NBUF-1 in flight; stages 0 and 1 landed -> stage 0 split in registers, stage 1 raw in registers;
+    // then stage NBUF into slot 0, and stage 2 landed
     for (int s0 = 0; s0 < NBUF; ++s0) {
         load_table(s0);
         pin_table();
@@ -1354,7 +1372,7 @@ __global__ __launch_bounds__(512, 1) void conv_ring_kernel(const ConvRingParams 
     }
     load_table(NBUF);
     pin_table();
-    if (nstages >= NBUF) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");               // groups 0, 1 of 5 done
+    if (nstages >= NBUF) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMW) : "memory");      // groups 0, 1 of NBUF done
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     SplitBf16 A[2] = {}, B[2] = {}, An[2] = {}, Bn[2] = {};
@@ -1370,12 +1388,12 @@ __global__ __launch_bounds__(512, 1) void conv_ring_kernel(const ConvRingParams 
     }
     load_table(NBUF + 1);
     pin_table();
-    if (nstages > NBUF) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");                // groups 2 .. 5 issued since: stage 2 done
+    if (nstages > NBUF) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMW) : "memory");       // groups 2 .. NBUF issued since: stage 2 done
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     int rd = 2 * BUF;                                                 // ring slot (dwords) of stage st + 2
-    uint32_t wr = BUF * 4;                                            // ring slot (bytes) of stage st + 6 = the one of stage st + 1
+    uint32_t wr = BUF * 4;                                            // ring slot (bytes) of stage st + D = the one of stage st + 1
     constexpr int D = NBUF + 1;
     // Ac / Bc: operands of stage st; An / Bn receive stage st + 1, split from Rc; Rn receives the LDS reads of stage st + 2.
     // The register sets swap roles every stage.
@@ -1401,9 +1419,9 @@ __global__ __launch_bounds__(512, 1) void conv_ring_kernel(const ConvRingParams 
     auto finish = [&](int st) __attribute__((always_inline)) {
         // groups issued so far end with stage min(st + D, nstages - 1); stage st + 3 must have landed
         const int after = min(st + D, nstages - 1) - (st + 3);
-        if (after >= 3) asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");
-        else if (after == 2) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-        else if (after == 1) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+        if (after >= 3 && NBUF - 2 >= 3) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(3 * FW) : "memory");
+        else if (after >= 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * FW) : "memory");
+        else if (after == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(FW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __syncthreads();
     };
@@ -1412,10 +1430,10 @@ __global__ __launch_bounds__(512, 1) void conv_ring_kernel(const ConvRingParams 
     int st = 0;
     for (; st + 1 + D < nfull; st += 2) {
         stage(true, st, A, B, An, Bn, R1, R0);
-        asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(VMW) : "memory");
         __syncthreads();
         stage(true, st + 1, An, Bn, A, B, R0, R1);
-        asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(VMW) : "memory");
         __syncthreads();
     }
     for (; st < nstages; st += 2) {
@@ -1951,10 +1969,11 @@ static int launch_conv_dma(const ConvGeom& g, const float* w, int64_t w_ld, int 
     return 0;
 }
 
+template <int BM>
 static int launch_conv_ring(const ConvGeom& g, const float* w, int64_t w_ld, int w_grp_stride, const int* row_tab, int Cog,
                             int Cout_total, const ConvOut& o, uint32_t* wsplit, hipStream_t s) {
-    constexpr int BM = 128, BN = 256;
-    constexpr size_t lds = (size_t)5 * 16 * (BM + BN) * sizeof(float);       // 120 KB: one workgroup per CU
+    constexpr int BN = BM == 128 ? 256 : 512;
+    constexpr size_t lds = (size_t)(BM == 128 ? 5 : 4) * 16 * (BM + BN) * sizeof(float);       // 120 / 144 KB: one workgroup per CU
     const int groups = Cout_total / Cog, nstages = ceil_div(g.K, KBLK), CogP = ceil_div(Cog, BM) * BM;
     hipLaunchKernelGGL(conv_wsplit_kernel, dim3(nstages, groups), dim3(256), 0, s, w, w_ld, (int64_t)w_grp_stride, row_tab, g.K, Cog,
                        CogP, nstages, wsplit);
@@ -1967,7 +1986,7 @@ static int launch_conv_ring(const ConvGeom& g, const float* w, int64_t w_ld, int
     pe.y_halo = o.y_halo; pe.y_wp = o.OW + 2 * o.y_halo; pe.y_plane = (int64_t)(o.OH + 2 * o.y_halo) * pe.y_wp;
     pe.m_halo = o.m_halo; pe.m_wp = o.OW + 2 * o.m_halo; pe.m_plane = (int64_t)(o.OH + 2 * o.m_halo) * pe.m_wp;
     static bool attr_set = false;
-    auto kern = conv_ring_kernel<3>;
+    auto kern = conv_ring_kernel<3, BM>;
     if (!attr_set) {
         VL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
@@ -1986,8 +2005,10 @@ static int dispatch_conv(const ConvGeom& g, const float* w, int64_t w_ld, int w_
     // output-channel tile: 128 when it divides well, else 96 (conv1: 96, conv4: 192) or 64 (conv2 dgrad: 48)
     const int w128 = ceil_div(Cog, 128) * 128, w96 = ceil_div(Cog, 96) * 96, w64 = ceil_div(Cog, 64) * 64;
     // split products: the ring kernel (128-channel tiles; its 16-byte im2col fetches need unit column stride in memory)
-    if (g_conv_math == 3 && PADDED && Cog >= 96 && g.col_mul == 1)
-        return launch_conv_ring(g, w, w_ld, w_grp_stride, row_tab, Cog, Cout_total, o, wsplit, s);
+    if (g_conv_math == 3 && PADDED && g.col_mul == 1) {
+        if (Cog >= 96) return launch_conv_ring<128>(g, w, w_ld, w_grp_stride, row_tab, Cog, Cout_total, o, wsplit, s);
+        if (Cog >= 40 && Cog <= 64) return launch_conv_ring<64>(g, w, w_ld, w_grp_stride, row_tab, Cog, Cout_total, o, wsplit, s);
+    }
     if (w128 <= w96 && w128 <= w64) {
         // 128-wide tiles in the padded layout: the LDS-DMA kernel
         if (PADDED && (int64_t)g.K * w_ld * 4 < MAX_BUF_BYTES && getenv("VL_CONV_STAGED") == nullptr) {
