@@ -1243,7 +1243,7 @@ __global__ __launch_bounds__(512, 1) void conv_ring_kernel(const ConvRingParams 
     constexpr int FW = 1 + 2 * NH;                                    // fetches per wave per stage: one weight piece, im2col rows 2w, 2w + 1
     constexpr int VMW = (NBUF - 2) * FW;                              // fetches that may stay in flight at a stage's end: NBUF - 2 stages
     constexpr int NP = MATH == 3 ? 3 : 1;
-    constexpr int NM = 4 * NP;                                        // MFMAs per wave per stage
+    constexpr int NM = (BM / 32) * (BN / 256) * NP;                   // MFMAs per wave per stage (TA x TB blocks x products)
     static_assert(SR == KBLK, "one stage = one block of the reduction order");
     extern __shared__ __attribute__((aligned(16))) float ldsr[];
     const int bid = xcd_swizzle(blockIdx.x, gridDim.x);
@@ -1252,7 +1252,10 @@ __global__ __launch_bounds__(512, 1) void conv_ring_kernel(const ConvRingParams 
     const int i0 = ti_blk * BM, j0 = tj_blk * BN;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = BM == 128 ? wave >> 2 : 0, wn = BM == 128 ? wave & 3 : wave;
+    // A wave's tile is TA x TB blocks of 32 x 32: all BM channels x 32 pixels (BM = 128: 4 x 1) or x 64 pixels (BM = 64: 2 x 2).
+    // Every im2col element is then split by ONE wave only (in a 2 x 4 wave grid two waves split the same pixels, and the
+    // split, not the MFMA, is what a stage's time is made of).
+    constexpr int TA = BM / 32, TB = BN / 8 / 32, WPX = 32 * TB;     // blocks along channels / pixels; pixels per wave
     const int OHWp = g.OHW / g.OW * OWp;
     const int nstages = pa.nstages;
 
@@ -1319,44 +1322,45 @@ __global__ __launch_bounds__(512, 1) void conv_ring_kernel(const ConvRingParams 
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[TA][TB];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < TA; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < TB; ++b)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
 
-    // lane half h = lane >> 5 owns reduction rows 8 h .. 8 h + 7 of a stage.  Weights: block a of this wave = channels
-    // 64 wm + 32 a + (lane & 31); its operand is the 16 B at [plane][h][channel].  im2col: rows 8 h + j, pixel 64 wn + 32 b + (lane & 31).
-    const float* fa = ldsr + ((lane >> 5) * BM + wm * 64 + (lane & 31)) * 4;
-    const float* fb = ldsr + ABUF + (lane >> 5) * 8 * BN + wn * 64 + (lane & 31);
+    // lane half h = lane >> 5 owns reduction rows 8 h .. 8 h + 7 of a stage.  Weights: block a = channels 32 a + (lane & 31); its
+    // operand is the 16 B at [plane][h][channel].  im2col: rows 8 h + j, pixel WPX wave + 32 b + (lane & 31).
+    const float* fa = ldsr + ((lane >> 5) * BM + (lane & 31)) * 4;
+    const float* fb = ldsr + ABUF + (lane >> 5) * 8 * BN + wave * WPX + (lane & 31);
     struct Raw {                                                      // a stage's operands of this lane as read from LDS
-        i32x4 ahi[2], alo[2];
-        float2 b[8];
+        i32x4 ahi[TA], alo[TA];
+        float b[8][TB];
     };
     auto load_raw = [&](int rd, Raw& r) __attribute__((always_inline)) {                  // rd: ring slot offset in dwords
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
+        for (int a = 0; a < TA; ++a) {
             r.ahi[a] = *reinterpret_cast<const i32x4*>(fa + rd + a * 32 * 4);
             if constexpr (NP == 3) r.alo[a] = *reinterpret_cast<const i32x4*>(fa + rd + 2 * BM * 4 + a * 32 * 4);
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float* q = fb + rd + j * BN;
-            r.b[j] = float2{q[0], q[32]};
+#pragma unroll
+            for (int b = 0; b < TB; ++b) r.b[j][b] = q[32 * b];
         }
     };
-    auto split = [&](const Raw& r, SplitBf16 (&A)[2], SplitBf16 (&B)[2]) __attribute__((always_inline)) {
+    auto split = [&](const Raw& r, SplitBf16 (&A)[TA], SplitBf16 (&B)[TB]) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
 #pragma unroll
-            for (int a = 0; a < 2; ++a) {
+            for (int a = 0; a < TA; ++a) {
                 A[a].hi[j] = r.ahi[a][j];
                 if constexpr (NP == 3) A[a].lo[j] = r.alo[a][j];
             }
-            split_pair<NP == 3>(r.b[2 * j].x, r.b[2 * j + 1].x, B[0].hi[j], B[0].lo[j]);
-            split_pair<NP == 3>(r.b[2 * j].y, r.b[2 * j + 1].y, B[1].hi[j], B[1].lo[j]);
+#pragma unroll
+            for (int b = 0; b < TB; ++b) split_pair<NP == 3>(r.b[2 * j][b], r.b[2 * j + 1][b], B[b].hi[j], B[b].lo[j]);
         }
     };
 
@@ -1375,7 +1379,7 @@ __global__ __launch_bounds__(512, 1) void conv_ring_kernel(const ConvRingParams 
     if (nstages >= NBUF) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMW) : "memory");      // groups 0, 1 of NBUF done
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    SplitBf16 A[2] = {}, B[2] = {}, An[2] = {}, Bn[2] = {};
+    SplitBf16 A[TA] = {}, B[TB] = {}, An[TA] = {}, Bn[TB] = {};
     Raw R0 = {}, R1 = {};
     load_raw(0, R0);
     load_raw(BUF, R1);
@@ -1397,12 +1401,12 @@ __global__ __launch_bounds__(512, 1) void conv_ring_kernel(const ConvRingParams 
     constexpr int D = NBUF + 1;
     // Ac / Bc: operands of stage st; An / Bn receive stage st + 1, split from Rc; Rn receives the LDS reads of stage st + 2.
     // The register sets swap roles every stage.
-    auto stage = [&](const bool fast, int st, SplitBf16 (&Ac)[2], SplitBf16 (&Bc)[2], SplitBf16 (&An)[2], SplitBf16 (&Bn)[2],
+    auto stage = [&](const bool fast, int st, SplitBf16 (&Ac)[TA], SplitBf16 (&Bc)[TB], SplitBf16 (&An)[TA], SplitBf16 (&Bn)[TB],
                      const Raw& Rc, Raw& Rn) __attribute__((always_inline)) {
         load_raw(rd, Rn);                                             // garbage past the end: never multiplied
         static_for<0, NM>([&](auto MI) __attribute__((always_inline)) {
             constexpr int m = decltype(MI)::value;
-            constexpr int prod = m >> 2, a = (m >> 1) & 1, b = m & 1;
+            constexpr int prod = m / (TA * TB), a = (m % (TA * TB)) / TB, b = m % TB;
             acc[a][b] = mfma_bf16(prod == 2 ? Ac[a].lo : Ac[a].hi, prod == 1 ? Bc[b].lo : Bc[b].hi, acc[a][b]);
             if constexpr (m < FW) {                                   // one fetch in the shadow of each of the first three MFMAs
                 if (fast) dma_fast(wr, m, st + D);
@@ -1445,11 +1449,11 @@ __global__ __launch_bounds__(512, 1) void conv_ring_kernel(const ConvRingParams 
         }
     }
 
-    // ---- epilogue: NCHW (+ halo), bias, ReLU, ReluGrad mask.  Accumulator (a, b, q) of lane l: channel 64 wm + 32 a + i,
-    // i = (q & 3) + 8 (q >> 2) + 4 (l >> 5); pixel 64 wn + 32 b + (l & 31) of the padded-row enumeration
+    // ---- epilogue: NCHW (+ halo), bias, ReLU, ReluGrad mask.  Accumulator (a, b, q) of lane l: channel 32 a + i,
+    // i = (q & 3) + 8 (q >> 2) + 4 (l >> 5); pixel WPX wave + 32 b + (l & 31) of the padded-row enumeration
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        const int m = j0 + wn * 64 + 32 * b + (lane & 31);
+    for (int b = 0; b < TB; ++b) {
+        const int m = j0 + wave * WPX + 32 * b + (lane & 31);
         if (m >= Mp) continue;
         const uint32_t n = fd_div((uint32_t)m, dOHWp);
         const uint32_t p = m - n * OHWp;
@@ -1460,11 +1464,11 @@ __global__ __launch_bounds__(512, 1) void conv_ring_kernel(const ConvRingParams 
         const int64_t ybase = c0 * pe.y_plane + (int64_t)(oh + pe.y_halo) * pe.y_wp + ow + pe.y_halo;
         const int64_t mbase = c0 * pe.m_plane + (int64_t)(oh + pe.m_halo) * pe.m_wp + ow + pe.m_halo;
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
+        for (int a = 0; a < TA; ++a) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int i = (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-                const int co = i0 + wm * 64 + 32 * a + i;
+                const int co = i0 + 32 * a + i;
                 if (co < pe.Cog) {
                     float v = acc[a][b][q];
                     if (pe.bias) v += pe.bias[zg * pe.Cog + co];
