@@ -685,8 +685,8 @@ __device__ __forceinline__ void static_for(F&& f) {     // f(IntC<B>) ... f(IntC
         static_for<B + 1, E>(f);
     }
 }
-struct SplitBf16 {        // 8 reduction positions of one operand row/column: 4 dwords of bf16 pairs, head and tail
-    int hi[4], lo[4];
+struct SplitBf16 {        // 8 reduction positions of one operand row/column: 4 dwords of bf16 pairs, head and tail (MFMA operand tuples)
+    i32x4 hi, lo;
 };
 template <bool TAIL>
 __device__ __forceinline__ void split_pair(float x0, float x1, int& hi, int& lo) {
@@ -699,9 +699,8 @@ __device__ __forceinline__ void split_pair(float x0, float x1, int& hi, int& lo)
         lo = (int)__builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2));
     }
 }
-__device__ __forceinline__ f32x16 mfma_bf16(const int (&a)[4], const int (&b)[4], const f32x16& c) {
-    const i32x4 av = {a[0], a[1], a[2], a[3]}, bv = {b[0], b[1], b[2], b[3]};
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), c, 0, 0, 0);
+__device__ __forceinline__ f32x16 mfma_bf16(const i32x4& a, const i32x4& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
 template <int BN, int WM, int WN, int MATH = 0>   // MATH 3: split bf16 products (vl_set_conv_math), see tile_split
@@ -884,14 +883,20 @@ __global__ __launch_bounds__(NT, 1) void wgrad_dma_kernel(const ConvGeom g, cons
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float2 v = *reinterpret_cast<const float2*>(fa3 + cur * BUF + a * 32 * STR + 16 * st + 2 * q);
-                    split_pair<true>(v.x, v.y, A[a].hi[q], A[a].lo[q]);
+                    int hi, lo;
+                    split_pair<true>(v.x, v.y, hi, lo);
+                    A[a].hi[q] = hi;
+                    A[a].lo[q] = lo;
                 }
 #pragma unroll
             for (int b = 0; b < TN; ++b)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float2 v = *reinterpret_cast<const float2*>(fb3 + cur * BUF + b * 32 * STR + 16 * st + 2 * q);
-                    split_pair<true>(v.x, v.y, B[b].hi[q], B[b].lo[q]);
+                    int hi, lo;
+                    split_pair<true>(v.x, v.y, hi, lo);
+                    B[b].hi[q] = hi;
+                    B[b].lo[q] = lo;
                 }
         };
         load_split(0, As[0], Bs[0]);
@@ -1193,9 +1198,9 @@ __global__ __launch_bounds__(NT, 64 / SR) void conv_dma_kernel(const ConvDmaPara
 //    memory (stride-1 layers, or the phase-split x0 of conv1).  It is split in registers (5 VALU per pair);
 //  * the LDS is spent on latency: ONE workgroup of 8 waves per CU, stages of 16 reduction rows (24 KB), a ring of NBUF = 5.
 // Stage st: MFMAs on the operands of stage st (registers) while the VALU splits the im2col operands of stage st + 1 (read
-// from LDS one stage ago), the LDS reads of stage st + 2 are in flight, and stage st + 6 streams into the slot stage st + 1
-// occupied.  The barrier at the end of stage st waits (vmcnt) only for stage st + 3.  Every wave issues exactly FW = 3
-// fetches per stage, in stage order, so "all but the last 9" means stage st + 3 has landed.
+// from LDS one stage ago), the LDS reads of stage st + 1 (weights) and st + 2 (im2col) are in flight, and stage st + NBUF
+// streams into the slot stage st occupied.  The barrier at the end of stage st waits (vmcnt) only for stage st + 3.  Every
+// wave issues exactly FW fetches per stage, in stage order, so "all but the last (NBUF - 3) FW" means stage st + 3 has landed.
 // Reduction position p = 16 st + 8 h + 2 q + e of a stage belongs to lane half h, bf16 pair q, element e of the MFMA operand.
 __device__ __forceinline__ void lds_dma_row4(i32x4 rs, uint32_t lds_byte_addr, uint32_t voff, int soff) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_byte_addr), "v"(voff), "s"(rs), "s"(soff)
@@ -1241,7 +1246,7 @@ __global__ __launch_bounds__(512, 1) void conv_ring_kernel(const ConvRingParams 
     static_assert(BM == 128 || BM == 64, "channel tile");
     constexpr int ABUF = SR * BM, BUF = SR * (BM + BN);               // dwords
     constexpr int FW = 1 + 2 * NH;                                    // fetches per wave per stage: one weight piece, im2col rows 2w, 2w + 1
-    constexpr int VMW = (NBUF - 2) * FW;                              // fetches that may stay in flight at a stage's end: NBUF - 2 stages
+    constexpr int VMW = (NBUF - 3) * FW;                              // fetches that may stay in flight at a stage's end: NBUF - 3 stages
     constexpr int NP = MATH == 3 ? 3 : 1;
     constexpr int NM = (BM / 32) * (BN / 256) * NP;                   // MFMAs per wave per stage (TA x TB blocks x products)
     static_assert(SR == KBLK, "one stage = one block of the reduction order");
@@ -1334,16 +1339,10 @@ __global__ __launch_bounds__(512, 1) void conv_ring_kernel(const ConvRingParams 
     // operand is the 16 B at [plane][h][channel].  im2col: rows 8 h + j, pixel WPX wave + 32 b + (lane & 31).
     const float* fa = ldsr + ((lane >> 5) * BM + (lane & 31)) * 4;
     const float* fb = ldsr + ABUF + (lane >> 5) * 8 * BN + wave * WPX + (lane & 31);
-    struct Raw {                                                      // a stage's operands of this lane as read from LDS
-        i32x4 ahi[TA], alo[TA];
+    struct Raw {                                                      // a stage's im2col operands of this lane as read from LDS
         float b[8][TB];
     };
     auto load_raw = [&](int rd, Raw& r) __attribute__((always_inline)) {                  // rd: ring slot offset in dwords
-#pragma unroll
-        for (int a = 0; a < TA; ++a) {
-            r.ahi[a] = *reinterpret_cast<const i32x4*>(fa + rd + a * 32 * 4);
-            if constexpr (NP == 3) r.alo[a] = *reinterpret_cast<const i32x4*>(fa + rd + 2 * BM * 4 + a * 32 * 4);
-        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float* q = fb + rd + j * BN;
@@ -1351,21 +1350,27 @@ __global__ __launch_bounds__(512, 1) void conv_ring_kernel(const ConvRingParams 
             for (int b = 0; b < TB; ++b) r.b[j][b] = q[32 * b];
         }
     };
-    auto split = [&](const Raw& r, SplitBf16 (&A)[TA], SplitBf16 (&B)[TB]) __attribute__((always_inline)) {
+    auto load_a = [&](int rd, SplitBf16 (&A)[TA]) __attribute__((always_inline)) {       // the weight operands come split: no VALU
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-#pragma unroll
-            for (int a = 0; a < TA; ++a) {
-                A[a].hi[j] = r.ahi[a][j];
-                if constexpr (NP == 3) A[a].lo[j] = r.alo[a][j];
-            }
-#pragma unroll
-            for (int b = 0; b < TB; ++b) split_pair<NP == 3>(r.b[2 * j][b], r.b[2 * j + 1][b], B[b].hi[j], B[b].lo[j]);
+        for (int a = 0; a < TA; ++a) {
+            A[a].hi = *reinterpret_cast<const i32x4*>(fa + rd + a * 32 * 4);
+            if constexpr (NP == 3) A[a].lo = *reinterpret_cast<const i32x4*>(fa + rd + 2 * BM * 4 + a * 32 * 4);
         }
     };
+    auto split = [&](const Raw& r, SplitBf16 (&B)[TB]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int b = 0; b < TB; ++b) {
+                int hi, lo = 0;
+                split_pair<NP == 3>(r.b[2 * j][b], r.b[2 * j + 1][b], hi, lo);
+                B[b].hi[j] = hi;
+                B[b].lo[j] = lo;
+            }
+    };
 
-    // ---- prologue: stages 0 .. NBUF-1 in flight; stages 0 and 1 landed -> stage 0 split in registers, stage 1 raw in registers;
-    // then stage NBUF into slot 0, and stage 2 landed
+    // ---- prologue: stages 0 .. NBUF-1 in flight; stages 0, 1, 2 landed -> stage 0's operands in registers (weights as
+    // fetched, im2col split), stage 1's im2col operands raw in registers
     for (int s0 = 0; s0 < NBUF; ++s0) {
         load_table(s0);
         pin_table();
@@ -1376,56 +1381,52 @@ __global__ __launch_bounds__(512, 1) void conv_ring_kernel(const ConvRingParams 
     }
     load_table(NBUF);
     pin_table();
-    if (nstages >= NBUF) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMW) : "memory");      // groups 0, 1 of NBUF done
+    if (nstages >= NBUF) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMW) : "memory");      // groups 0, 1, 2 of NBUF done
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     SplitBf16 A[TA] = {}, B[TB] = {}, An[TA] = {}, Bn[TB] = {};
     Raw R0 = {}, R1 = {};
+    load_a(0, A);
     load_raw(0, R0);
     load_raw(BUF, R1);
-    split(R0, A, B);
+    split(R0, B);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
-    if (NBUF < nstages) {
-#pragma unroll
-        for (int f = 0; f < FW; ++f) dma(0u, f, NBUF);
-    }
-    load_table(NBUF + 1);
-    pin_table();
-    if (nstages > NBUF) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMW) : "memory");       // groups 2 .. NBUF issued since: stage 2 done
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
 
-    int rd = 2 * BUF;                                                 // ring slot (dwords) of stage st + 2
-    uint32_t wr = BUF * 4;                                            // ring slot (bytes) of stage st + D = the one of stage st + 1
-    constexpr int D = NBUF + 1;
-    // Ac / Bc: operands of stage st; An / Bn receive stage st + 1, split from Rc; Rn receives the LDS reads of stage st + 2.
-    // The register sets swap roles every stage.
+    // Stage st: MFMAs on the operands of stage st (Ac / Bc) while the weight operands of stage st + 1 are read from LDS into
+    // An, the VALU splits the im2col operands of stage st + 1 (Rc, read one stage ago) into Bn, the LDS reads of the im2col
+    // operands of stage st + 2 fill Rn, and stage st + NBUF streams into the slot of stage st (its weights were read one stage
+    // ago, its im2col rows two).  The barrier at the end of stage st waits (vmcnt) for stage st + 3 only.  The register sets
+    // swap roles every stage.
+    int rda = BUF, rdb = 2 * BUF;                                     // ring slots (dwords) of stages st + 1, st + 2
+    uint32_t wr = 0;                                                  // ring slot (bytes) of stage st + NBUF = the one of stage st
+    constexpr int D = NBUF;
     auto stage = [&](const bool fast, int st, SplitBf16 (&Ac)[TA], SplitBf16 (&Bc)[TB], SplitBf16 (&An)[TA], SplitBf16 (&Bn)[TB],
                      const Raw& Rc, Raw& Rn) __attribute__((always_inline)) {
-        load_raw(rd, Rn);                                             // garbage past the end: never multiplied
+        load_a(rda, An);
+        load_raw(rdb, Rn);                                            // garbage past the end: never multiplied
         static_for<0, NM>([&](auto MI) __attribute__((always_inline)) {
             constexpr int m = decltype(MI)::value;
             constexpr int prod = m / (TA * TB), a = (m % (TA * TB)) / TB, b = m % TB;
             acc[a][b] = mfma_bf16(prod == 2 ? Ac[a].lo : Ac[a].hi, prod == 1 ? Bc[b].lo : Bc[b].hi, acc[a][b]);
-            if constexpr (m < FW) {                                   // one fetch in the shadow of each of the first three MFMAs
+            if constexpr (m < FW) {                                   // one fetch in the shadow of each of the first FW MFMAs
                 if (fast) dma_fast(wr, m, st + D);
                 else if (st + D < nstages) dma(wr, m, st + D);
             }
             __builtin_amdgcn_sched_barrier(0x106);                    // VALU / SALU / LDS reads may move across, MFMAs and fetches stay put
         });
-        split(Rc, An, Bn);
+        split(Rc, Bn);
         load_table(st + D + 1);
         pin_table();
-        rd = rd + BUF == NBUF * BUF ? 0 : rd + BUF;
+        rda = rda + BUF == NBUF * BUF ? 0 : rda + BUF;
+        rdb = rdb + BUF == NBUF * BUF ? 0 : rdb + BUF;
         wr = wr + BUF * 4 == NBUF * BUF * 4 ? 0u : wr + BUF * 4;
     };
     auto finish = [&](int st) __attribute__((always_inline)) {
         // groups issued so far end with stage min(st + D, nstages - 1); stage st + 3 must have landed
         const int after = min(st + D, nstages - 1) - (st + 3);
-        if (after >= 3 && NBUF - 2 >= 3) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(3 * FW) : "memory");
-        else if (after >= 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * FW) : "memory");
-        else if (after == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(FW) : "memory");
+        if (after >= 2 && NBUF - 3 >= 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * FW) : "memory");
+        else if (after >= 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(FW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __syncthreads();
     };
