@@ -90,6 +90,8 @@ CONV_CASES = [
     (3, 13, 13, 256, 384, 3, 1, 1),     # conv3
     (3, 13, 13, 384, 384, 3, 1, 2),     # conv4
     (3, 13, 13, 384, 256, 3, 1, 2),     # conv5
+    (1, 10, 7, 40, 100, 3, 1, 1),       # ragged everything: 100 / 40 channels, K = 360 / 900 (tail stages), one partial pixel tile
+    (2, 6, 5, 40, 96, 1, 1, 1),         # 1x1: K = 40 -> fewer reduction stages than the split-product kernel's ring has slots
 ]
 
 

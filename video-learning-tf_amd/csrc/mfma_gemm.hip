@@ -1502,6 +1502,11 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ ws, float* __restr
     }
 }
 
+// A/B switches for measurements, read once: VL_CONV_STAGED=1 runs conv forward / dgrad on the register-staged mfma_contract
+// template instead of the LDS-DMA kernels, VL_GEMM_NOSPLIT=1 disables the split-K of small dense GEMMs.
+static const bool kConvStaged = getenv("VL_CONV_STAGED") != nullptr;
+static const bool kGemmNoSplit = getenv("VL_GEMM_NOSPLIT") != nullptr;
+
 // contraction arithmetic of conv forward / dgrad: 0 = fp32 MFMA (default, the parity path), 3 = bf16x3 split products
 // (vl_set_conv_math; VL_CONV_MATH=bf16x3 presets it)
 static int g_conv_math = [] {
@@ -1951,9 +1956,8 @@ template <int BM>   // 128: conv_dma_kernel (32x32 MFMA tiles); 48 / 96: conv_dm
 static int launch_conv_dma(const ConvGeom& g, const float* w, int64_t w_ld, int w_grp_stride, const int* row_tab, int Cog,
                            int Cout_total, const ConvOut& o, hipStream_t s) {
     constexpr int BN = 128, SR = 32;
-    constexpr int BMA = BM < 0 ? -BM : BM;                              // BM = -128: experiment, the 128-wide tile on 16x16 MFMAs
     constexpr size_t lds = BM == 128 ? (size_t)2 * SR * (BM + BN) * sizeof(float)    // 64 KB: two workgroups per CU
-                                     : (size_t)2 * SR * ((BMA + 63) / 64 * 64 + 16 + 144) * sizeof(float);   // 56 / 72 KB
+                                     : (size_t)2 * SR * ((BM + 63) / 64 * 64 + 16 + 144) * sizeof(float);   // 56 / 72 KB
     ConvDmaParams pa{w, w_ld, (int64_t)w_grp_stride, (int64_t)g.K * w_ld * 4, row_tab, ceil_div(g.K, KBLK)};
     EpiConvNCHW::Params pe;
     pe.y = o.y; pe.bias = o.bias; pe.mask = o.mask; pe.relu = o.relu;
@@ -1962,12 +1966,12 @@ static int launch_conv_dma(const ConvGeom& g, const float* w, int64_t w_ld, int 
     pe.y_halo = o.y_halo; pe.y_wp = o.OW + 2 * o.y_halo; pe.y_plane = (int64_t)(o.OH + 2 * o.y_halo) * pe.y_wp;
     pe.m_halo = o.m_halo; pe.m_wp = o.OW + 2 * o.m_halo; pe.m_plane = (int64_t)(o.OH + 2 * o.m_halo) * pe.m_wp;
     static bool attr_set = false;
-    auto kern = BM == 128 ? conv_dma_kernel<SR> : conv_dma16_kernel<BM == 128 ? 3 : BMA / 16>;
+    auto kern = BM == 128 ? conv_dma_kernel<SR> : conv_dma16_kernel<BM == 128 ? 3 : BM / 16>;
     if (!attr_set) {
         VL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    const int tiles_i = ceil_div(Cog, BMA), tiles_j = ceil_div(g.M, BN);
+    const int tiles_i = ceil_div(Cog, BM), tiles_j = ceil_div(g.M, BN);
     dim3 grid(tiles_i * tiles_j, (unsigned)(Cout_total / Cog), 1);
     hipLaunchKernelGGL(kern, grid, dim3(NT), lds, s, pa, g, pe, tiles_i);
     VL_LAUNCH_CHECK();
@@ -2016,18 +2020,17 @@ static int dispatch_conv(const ConvGeom& g, const float* w, int64_t w_ld, int w_
     }
     if (w128 <= w96 && w128 <= w64) {
         // 128-wide tiles in the padded layout: the LDS-DMA kernel
-        if (PADDED && (int64_t)g.K * w_ld * 4 < MAX_BUF_BYTES && getenv("VL_CONV_STAGED") == nullptr) {
-            if (getenv("VL_CONV128_16")) return launch_conv_dma<-128>(g, w, w_ld, w_grp_stride, row_tab, Cog, Cout_total, o, s);
+        if (PADDED && (int64_t)g.K * w_ld * 4 < MAX_BUF_BYTES && !kConvStaged) {
             return launch_conv_dma<128>(g, w, w_ld, w_grp_stride, row_tab, Cog, Cout_total, o, s);
         }
         return launch_conv<128, 2, 2, PADDED>(g, w, w_ld, w_grp_stride, row_tab, Cog, Cout_total, o, s);
     }
     // 48-wide tiles beat the 64-wide ones whenever they waste fewer rows (conv2 dgrad: 48 channels per group)
     if (PADDED && ceil_div(Cog, 48) * 48 < w64 && ceil_div(Cog, 48) * 48 < w96 &&
-        (int64_t)g.K * w_ld * 4 < MAX_BUF_BYTES && getenv("VL_CONV_STAGED") == nullptr)
+        (int64_t)g.K * w_ld * 4 < MAX_BUF_BYTES && !kConvStaged)
         return launch_conv_dma<48>(g, w, w_ld, w_grp_stride, row_tab, Cog, Cout_total, o, s);
     if (w96 <= w64) {
-        if (PADDED && (int64_t)g.K * w_ld * 4 < MAX_BUF_BYTES && getenv("VL_CONV_STAGED") == nullptr)
+        if (PADDED && (int64_t)g.K * w_ld * 4 < MAX_BUF_BYTES && !kConvStaged)
             return launch_conv_dma<96>(g, w, w_ld, w_grp_stride, row_tab, Cog, Cout_total, o, s);
         return launch_conv<96, 1, 4, PADDED>(g, w, w_ld, w_grp_stride, row_tab, Cog, Cout_total, o, s);
     }
@@ -2299,7 +2302,7 @@ extern "C" int vl_gemm(int transa, int transb, int m, int n, int k, const float*
     // was provided
     int splits = 1;
     const int want = 3 * device_cus();
-    if (ws && tiles < want && getenv("VL_GEMM_NOSPLIT") == nullptr) {
+    if (ws && tiles < want && !kGemmNoSplit) {
         splits = ceil_div(want, tiles);
         const int maxs = k / 256 > 0 ? k / 256 : 1;
         if (splits > maxs) splits = maxs;

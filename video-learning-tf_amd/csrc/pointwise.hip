@@ -5,6 +5,11 @@
 
 #include "common.h"
 
+// A/B switches for measurements, read once: VL_POOL_LRN_CHUNKED=1 runs the fused pool+LRN backward on the older chunked
+// kernel, VL_POOL_LRN_CHK16=1 forces the 16-channel chunk of the channel-stream kernel.
+static const bool kPoolLrnChunked = getenv("VL_POOL_LRN_CHUNKED") != nullptr;
+static const bool kPoolLrnChk16 = getenv("VL_POOL_LRN_CHK16") != nullptr;
+
 static inline int grid_for(int64_t work, int threads, int cap) {
     int64_t b = (work + threads - 1) / threads;
     if (b > cap) b = cap;
@@ -462,7 +467,7 @@ extern "C" int vl_pool_lrn_bwd(const float* x, const float* dp, const uint8_t* a
         const int64_t bytes_x = (int64_t)(c + 24) * h * w * 4, bytes_dx = (int64_t)(c + 24) * (h + 2 * dx_halo) * (w + 2 * dx_halo) * 4;
         const int64_t pooled_f = ((int64_t)c * pplane - origin) * 4;
         const bool ok = beta == 0.75f && bytes_x < (1ll << 31) && bytes_dx < (1ll << 31) && pooled_f < (1ll << 31) && pplane < (1 << 24) &&
-                        getenv("VL_POOL_LRN_CHUNKED") == nullptr;
+                        !kPoolLrnChunked;
         const dim3 grid(ceil_div((int64_t)h * w, 256), n);
         const int64_t psn = (int64_t)c * pplane;
 #define VL_PLB_LAUNCH(CHK, NST)                                                                                                     \
@@ -477,7 +482,7 @@ extern "C" int vl_pool_lrn_bwd(const float* x, const float* dp, const uint8_t* a
         return 0;                                                                                                                   \
     } while (0)
         // chunk = 20 channels when C + 4 is a multiple of it (96 and 256 are): no idle tail iterations
-        if (ok && (c + 4) % 20 == 0 && (int64_t)20 * max_prow * ow <= 11 * 256 && getenv("VL_POOL_LRN_CHK16") == nullptr) VL_PLB_LAUNCH(20, 11);
+        if (ok && (c + 4) % 20 == 0 && (int64_t)20 * max_prow * ow <= 11 * 256 && !kPoolLrnChk16) VL_PLB_LAUNCH(20, 11);
         if (ok && (int64_t)16 * max_prow * ow <= 9 * 256) VL_PLB_LAUNCH(16, 9);
 #undef VL_PLB_LAUNCH
     }
