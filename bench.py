@@ -181,7 +181,7 @@ def main():
     torch.cuda.synchronize()
     fwd_ms = (time.perf_counter() - tf0) / args.steps * 1e3
 
-    # Opt-in arithmetic (NetConfig.conv_math = "bf16x3": conv forward / dgrad as split bf16 products, everything else unchanged):
+    # Opt-in arithmetic (NetConfig.conv_math = "bf16x3": the three conv contractions as split bf16 products, everything else unchanged):
     # the same job timed the same way, reported BESIDE `value` (which stays the fp32 path), with its own loss / gradient norm
     # after the same number of steps from the same initial parameters as evidence of what the arithmetic changes.
     split = None
@@ -209,7 +209,7 @@ def main():
         eng_x.set_probe(None)
         out_x = eng_x.train_step_u8(frames, onehot, lr=1e-3, clip_norm=10.0, mean_bgr=MEAN_BGR, fetch=True)
         split = {"value": round(clips * args.steps / tx, 2), "unit": "clips/s", "ms_per_step": round(tx / args.steps * 1e3, 3),
-                 "dtype": "bf16x3 (conv fwd/dgrad: split bf16 products, fp32 accumulate) + f32 (wgrad, GEMMs, pointwise)",
+                 "dtype": "bf16x3 (conv fwd/dgrad/wgrad: split bf16 products, fp32 accumulate) + f32 (dense GEMMs, LSTM, pointwise)",
                  "per_launch_ms": {k: round(sum(v) / len(v), 3) for k, v in sorted(per_x.items())},
                  "check": {"loss": round(out_x["loss"], 4), "grad_norm": round(out_x["grad_norm"], 3)},
                  "first_step_check": {k: {"loss": round(v["loss"], 5), "grad_norm": round(v["grad_norm"], 4)} for k, v in first.items()},
