@@ -1482,6 +1482,214 @@ __global__ __launch_bounds__(512, 1) void conv_ring_kernel(const ConvRingParams 
     }
 }
 
+// ---- the 128-channel split-product kernel with TWO workgroups per CU ---------------------------------------------------
+// conv_ring_kernel<3, 128> reads the whole weight slab in every one of its 8 waves (a wave tile is 128 channels x 32 pixels):
+// 72 KB of LDS reads per 96 MFMAs, and with one workgroup per CU nothing runs while its waves sit at a barrier.  Here a
+// workgroup is 4 waves, each 128 channels x 64 pixels (4 x 2 blocks, 128 accumulator registers): 48 KB of LDS reads per 96
+// MFMAs, 8 split pairs per 24 MFMAs, and two workgroups share a CU (3 slots of 24 KB each), one's barrier under the other's
+// MFMAs.  Two-level pipeline: during stage st the operands of stage st + 1 are read (weights: straight into MFMA tuples) and
+// split, and stage st + 3 streams into the slot of stage st; the barrier at the end of stage st waits for stage st + 2.
+// Same weight image, same im2col fetch (16 B per lane, padded pixel rows) as conv_ring_kernel.
+template <int MATH>
+__global__ __launch_bounds__(256, 2) void conv_ring4_kernel(const ConvRingParams pa, const ConvGeom g, const EpiConvNCHW::Params pe,
+                                                            int tiles_i, int OWp, int Mp, FastDiv dOHWp, FastDiv dOWp) {
+    constexpr int BM = 128, BN = 256, SR = 16, NBUF = 3, D = 3;
+    constexpr int ABUF = SR * BM, BUF = SR * (BM + BN);               // dwords
+    constexpr int TA = 4, TB = 2, WPX = 64;
+    constexpr int FW = 6;                                             // fetches per wave per stage: 2 weight pieces, im2col rows 4w .. 4w + 3
+    constexpr int NP = MATH == 3 ? 3 : 1;
+    constexpr int NM = TA * TB * NP;
+    static_assert(SR == KBLK, "one stage = one block of the reduction order");
+    extern __shared__ __attribute__((aligned(16))) float ldsq[];
+    const int bid = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int ti_blk = bid % tiles_i, tj_blk = bid / tiles_i;
+    const int zg = blockIdx.y;
+    const int i0 = ti_blk * BM, j0 = tj_blk * BN;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int OHWp = g.OHW / g.OW * OWp;
+    const int nstages = pa.nstages;
+
+    const int64_t stage_dw = (int64_t)16 * pa.CogP;
+    const uint32_t* wbase = pa.wsplit + (int64_t)zg * nstages * stage_dw;
+    const i32x4 rs_w = rsrc_words(reinterpret_cast<const float*>(wbase), nstages * stage_dw * 4);
+    // wave w fetches pieces 2w, 2w + 1 of a stage's weight image = (plane w >> 1, lane half w & 1), channels 0-63 / 64-127 of the tile
+    uint32_t voff_a[2];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) voff_a[hf] = (uint32_t)((wave * pa.CogP + i0 + hf * 64 + lane) * 16);
+    const int stage_bytes = (int)(stage_dw * 4);
+    const i32x4 rs_x = rsrc_words(g.x + (int64_t)zg * g.grp_stride, (g.total - (int64_t)zg * g.grp_stride) * 4);
+    uint32_t voff_b;
+    {
+        const int m = j0 + 4 * lane;
+        const bool vm = m < Mp;
+        const uint32_t mm = vm ? m : 0;
+        const uint32_t n = fd_div(mm, dOHWp);
+        const uint32_t p = mm - n * OHWp;
+        const uint32_t oh = fd_div(p, dOWp);
+        const uint32_t ow = p - oh * OWp;
+        const int ih0 = (int)oh * g.stride - g.pt + g.halo, iw0 = (int)ow * g.col_mul + g.col_add;
+        voff_b = vm ? (uint32_t)((int64_t)n * g.img_stride + (int64_t)ih0 * g.Wp + iw0) * 4u : OOB_OFF;
+    }
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)ldsq;
+
+    int tab[4] = {0, 0, 0, 0};
+    const int wrow = wave * 4;
+    auto load_table = [&](int st) __attribute__((always_inline)) {
+        const int sc = min(st, nstages - 1) + st * g.zero;
+        const const_int_ptr tt = as_const(g.ktab) + sc * SR + wrow;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tab[r] = tt[r];
+    };
+    auto pin_table = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) asm volatile("" : "+s"(tab[r]));
+    };
+    // fetch f of stage st into the slot at byte offset wr: 0, 1 = weight pieces 2w, 2w + 1; 2 + r = im2col row 4w + r
+    auto dma = [&](const uint32_t wr, const int f, int st, const bool fast) __attribute__((always_inline)) {
+        if (f < 2) {
+            lds_dma_row4(rs_w, lds0 + wr + (uint32_t)(2 * wave + f) * 1024u, voff_a[f], st * stage_bytes);
+        } else {
+            const int r = f - 2;
+            const bool live = fast || st * SR + wrow + r < g.K;
+            lds_dma_row4(rs_x, lds0 + wr + (uint32_t)(ABUF + (wrow + r) * BN) * 4u, live ? voff_b : OOB_OFF, tab[r]);
+        }
+    };
+
+    f32x16 acc[TA][TB];
+#pragma unroll
+    for (int a = 0; a < TA; ++a)
+#pragma unroll
+        for (int b = 0; b < TB; ++b)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
+
+    const float* fa = ldsq + ((lane >> 5) * BM + (lane & 31)) * 4;
+    const float* fb = ldsq + ABUF + (lane >> 5) * 8 * BN + wave * WPX + (lane & 31);
+    auto load_ops = [&](int rd, SplitBf16 (&A)[TA], float (&rb)[8][TB]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int a = 0; a < TA; ++a) {
+            A[a].hi = *reinterpret_cast<const i32x4*>(fa + rd + a * 32 * 4);
+            if constexpr (NP == 3) A[a].lo = *reinterpret_cast<const i32x4*>(fa + rd + 2 * BM * 4 + a * 32 * 4);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int b = 0; b < TB; ++b) rb[j][b] = fb[rd + j * BN + 32 * b];
+    };
+    auto split = [&](const float (&rb)[8][TB], SplitBf16 (&B)[TB]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int b = 0; b < TB; ++b) {
+                int hi, lo = 0;
+                split_pair<NP == 3>(rb[2 * j][b], rb[2 * j + 1][b], hi, lo);
+                B[b].hi[j] = hi;
+                B[b].lo[j] = lo;
+            }
+    };
+
+    // ---- prologue: stages 0, 1, 2 in flight; stage 0 landed -> its operands in registers; stage 1 landed
+    for (int s0 = 0; s0 < NBUF; ++s0) {
+        load_table(s0);
+        pin_table();
+        if (s0 < nstages) {
+#pragma unroll
+            for (int f = 0; f < FW; ++f) dma((uint32_t)(s0 * BUF * 4), f, s0, false);
+        }
+    }
+    load_table(NBUF);
+    pin_table();
+    if (nstages >= NBUF) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * FW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    SplitBf16 A[TA] = {}, B[TB] = {}, An[TA] = {}, Bn[TB] = {};
+    {
+        float rb[8][TB];
+        load_ops(0, A, rb);
+        split(rb, B);
+    }
+    if (nstages >= NBUF) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(FW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    int rd = BUF;                                                     // slot (dwords) of stage st + 1
+    uint32_t wr = 0;                                                  // slot (bytes) of stage st + 3 = the one of stage st
+    auto stage = [&](const bool fast, int st, SplitBf16 (&Ac)[TA], SplitBf16 (&Bc)[TB], SplitBf16 (&An)[TA], SplitBf16 (&Bn)[TB])
+                     __attribute__((always_inline)) {
+        float rb[8][TB];
+        load_ops(rd, An, rb);                                         // garbage past the end: never multiplied
+        static_for<0, NM>([&](auto MI) __attribute__((always_inline)) {
+            constexpr int m = decltype(MI)::value;
+            constexpr int prod = m / (TA * TB), a = (m % (TA * TB)) / TB, b = m % TB;
+            acc[a][b] = mfma_bf16(prod == 2 ? Ac[a].lo : Ac[a].hi, prod == 1 ? Bc[b].lo : Bc[b].hi, acc[a][b]);
+            if constexpr (m < FW) {
+                if (fast || st + D < nstages) dma(wr, m, st + D, fast);
+            }
+            __builtin_amdgcn_sched_barrier(0x106);
+        });
+        split(rb, Bn);
+        load_table(st + D + 1);
+        pin_table();
+        rd = rd + BUF == NBUF * BUF ? 0 : rd + BUF;
+        wr = wr + BUF * 4 == NBUF * BUF * 4 ? 0u : wr + BUF * 4;
+    };
+    auto finish = [&](int st) __attribute__((always_inline)) {
+        // groups issued so far end with stage min(st + D, nstages - 1); stage st + 2 must have landed
+        if (min(st + D, nstages - 1) - (st + 2) >= 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(FW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+    const int nfull = g.K / SR;
+    int st = 0;
+    for (; st + 1 + D < nfull; st += 2) {
+        stage(true, st, A, B, An, Bn);
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(FW) : "memory");
+        __syncthreads();
+        stage(true, st + 1, An, Bn, A, B);
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(FW) : "memory");
+        __syncthreads();
+    }
+    for (; st < nstages; st += 2) {
+        stage(false, st, A, B, An, Bn);
+        finish(st);
+        if (st + 1 < nstages) {
+            stage(false, st + 1, An, Bn, A, B);
+            finish(st + 1);
+        }
+    }
+
+    // ---- epilogue (as conv_ring_kernel): channel 32 a + i, pixel 64 wave + 32 b + (l & 31) of the padded-row enumeration
+#pragma unroll
+    for (int b = 0; b < TB; ++b) {
+        const int m = j0 + wave * WPX + 32 * b + (lane & 31);
+        if (m >= Mp) continue;
+        const uint32_t n = fd_div((uint32_t)m, dOHWp);
+        const uint32_t p = m - n * OHWp;
+        const uint32_t oh = fd_div(p, dOWp);
+        const uint32_t ow = p - oh * OWp;
+        if ((int)ow >= pe.OW) continue;
+        const int64_t c0 = (int64_t)n * pe.Cout_total + (int64_t)zg * pe.Cog;
+        const int64_t ybase = c0 * pe.y_plane + (int64_t)(oh + pe.y_halo) * pe.y_wp + ow + pe.y_halo;
+        const int64_t mbase = c0 * pe.m_plane + (int64_t)(oh + pe.m_halo) * pe.m_wp + ow + pe.m_halo;
+#pragma unroll
+        for (int a = 0; a < TA; ++a) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int i = (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+                const int co = i0 + 32 * a + i;
+                if (co < pe.Cog) {
+                    float v = acc[a][b][q];
+                    if (pe.bias) v += pe.bias[zg * pe.Cog + co];
+                    if (pe.relu) v = fmaxf(v, 0.f);
+                    if (pe.mask) v = pe.mask[mbase + (int64_t)co * pe.m_plane] > 0.f ? v : 0.f;
+                    pe.y[ybase + (int64_t)co * pe.y_plane] = v;
+                }
+            }
+        }
+    }
+}
+
 // out[e] = sum_s slab[s][e] (+bias[e % n_cols]) (relu) (mask) : deterministic split reduction.
 __global__ void reduce_slabs_kernel(const float* __restrict__ ws, float* __restrict__ out, int64_t count, int splits,
                                     int64_t slab_stride, const float* __restrict__ bias, int ncols, int64_t ldc,
@@ -1506,6 +1714,7 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ ws, float* __restr
 // template instead of the LDS-DMA kernels, VL_GEMM_NOSPLIT=1 disables the split-K of small dense GEMMs.
 static const bool kConvStaged = getenv("VL_CONV_STAGED") != nullptr;
 static const bool kGemmNoSplit = getenv("VL_GEMM_NOSPLIT") != nullptr;
+static const bool kRing8 = getenv("VL_CONV_RING8") != nullptr;      // bf16x3, 128-channel layers: the 8-wave conv_ring_kernel instead of conv_ring4_kernel
 
 // contraction arithmetic of conv forward / dgrad: 0 = fp32 MFMA (default, the parity path), 3 = bf16x3 split products
 // (vl_set_conv_math; VL_CONV_MATH=bf16x3 presets it)
@@ -1994,15 +2203,27 @@ static int launch_conv_ring(const ConvGeom& g, const float* w, int64_t w_ld, int
     pe.dOHW = g.dOHW; pe.dOW = g.dOW;
     pe.y_halo = o.y_halo; pe.y_wp = o.OW + 2 * o.y_halo; pe.y_plane = (int64_t)(o.OH + 2 * o.y_halo) * pe.y_wp;
     pe.m_halo = o.m_halo; pe.m_wp = o.OW + 2 * o.m_halo; pe.m_plane = (int64_t)(o.OH + 2 * o.m_halo) * pe.m_wp;
+    const int OH = g.OHW / g.OW, OWp = (g.OW + 3) / 4 * 4, Mp = g.M / g.OW * OWp;
+    const int tiles_i = ceil_div(Cog, BM), tiles_j = ceil_div(Mp, BN);
+    dim3 grid(tiles_i * tiles_j, (unsigned)groups, 1);
+    if (BM == 128 && !kRing8) {                                          // 4-wave workgroups, two per CU (VL_CONV_RING8=1: the 8-wave form)
+        constexpr size_t lds4 = (size_t)3 * 16 * (128 + 256) * sizeof(float);    // 72 KB
+        static bool attr4 = false;
+        auto k4 = conv_ring4_kernel<3>;
+        if (!attr4) {
+            VL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
+            attr4 = true;
+        }
+        hipLaunchKernelGGL(k4, grid, dim3(256), lds4, s, pa, g, pe, tiles_i, OWp, Mp, make_fastdiv(OH * OWp), make_fastdiv(OWp));
+        VL_LAUNCH_CHECK();
+        return 0;
+    }
     static bool attr_set = false;
     auto kern = conv_ring_kernel<3, BM>;
     if (!attr_set) {
         VL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    const int OH = g.OHW / g.OW, OWp = (g.OW + 3) / 4 * 4, Mp = g.M / g.OW * OWp;
-    const int tiles_i = ceil_div(Cog, BM), tiles_j = ceil_div(Mp, BN);
-    dim3 grid(tiles_i * tiles_j, (unsigned)groups, 1);
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, pa, g, pe, tiles_i, OWp, Mp, make_fastdiv(OH * OWp), make_fastdiv(OWp));
     VL_LAUNCH_CHECK();
     return 0;
