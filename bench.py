@@ -181,40 +181,48 @@ def main():
     torch.cuda.synchronize()
     fwd_ms = (time.perf_counter() - tf0) / args.steps * 1e3
 
-    # Opt-in arithmetic (NetConfig.conv_math = "bf16x3": the three conv contractions as split bf16 products, everything else unchanged):
+    # Opt-in arithmetics (NetConfig.conv_math = "bf16x3": the three conv contractions as split bf16 products; "bf16": plain bf16
+    # products, BASELINE config 5's reduced-precision conv path; everything else unchanged):
     # the same job timed the same way, reported BESIDE `value` (which stays the fp32 path), with its own loss / gradient norm
     # after the same number of steps from the same initial parameters as evidence of what the arithmetic changes.
-    split = None
+    split, plain = None, None
     if world == 1 and not args.no_split_math:
         import dataclasses
-        eng_x = LRCNEngine(dataclasses.replace(cfg, conv_math="bf16x3"), max_clips=clips, device=dev)
-        eng_x.load_params(init_params(cfg, seed=2))
-        # first step from the SAME parameters in both arithmetics (later steps of this chaotic sigma-0.05 initialisation drift
-        # apart under any rounding difference, so only the first one is a like-for-like comparison)
+
+        def side_run(math, first_of):
+            eng_x = LRCNEngine(dataclasses.replace(cfg, conv_math=math), max_clips=clips, device=dev)
+            eng_x.load_params(init_params(cfg, seed=2))
+            # first step from the SAME parameters in both arithmetics (later steps of this chaotic sigma-0.05 initialisation
+            # drift apart under any rounding difference, so only the first one is a like-for-like comparison)
+            first = dict(first_of)
+            first[math] = eng_x.train_step_u8(frames, onehot, lr=1e-3, clip_norm=10.0, mean_bgr=MEAN_BGR, fetch=True)
+            for _ in range(args.warmup):
+                eng_x.train_step_u8(frames, onehot, lr=1e-3, clip_norm=10.0, mean_bgr=MEAN_BGR, fetch=False)
+            eng_x.set_probe([l + p for l in CONV_MACS for p in (".fwd", ".dgrad", ".wgrad")])
+            torch.cuda.synchronize()
+            tx0 = time.perf_counter()
+            for _ in range(args.steps):
+                eng_x.train_step_u8(frames, onehot, lr=1e-3, clip_norm=10.0, mean_bgr=MEAN_BGR, fetch=False)
+            torch.cuda.synchronize()
+            tx = time.perf_counter() - tx0
+            per_x = {}
+            for label, ms in eng_x.probe_times_ms():
+                per_x.setdefault(label, []).append(ms)
+            eng_x.set_probe(None)
+            out_x = eng_x.train_step_u8(frames, onehot, lr=1e-3, clip_norm=10.0, mean_bgr=MEAN_BGR, fetch=True)
+            del eng_x
+            what = "split bf16 products" if math == "bf16x3" else "plain bf16 products (reduced precision)"
+            return {"value": round(clips * args.steps / tx, 2), "unit": "clips/s", "ms_per_step": round(tx / args.steps * 1e3, 3),
+                    "dtype": "%s (conv fwd/dgrad/wgrad: %s, fp32 accumulate) + f32 (dense GEMMs, LSTM, pointwise)" % (math, what),
+                    "per_launch_ms": {k: round(sum(v) / len(v), 3) for k, v in sorted(per_x.items())},
+                    "check": {"loss": round(out_x["loss"], 4), "grad_norm": round(out_x["grad_norm"], 3)},
+                    "first_step_check": {k: {"loss": round(v["loss"], 5), "grad_norm": round(v["grad_norm"], 4)} for k, v in first.items()},
+                    "note": "opt-in NetConfig.conv_math; never `value`"}
+
         eng.load_params(init_params(cfg, seed=2))
-        first = {"f32": eng.train_step_u8(frames, onehot, lr=1e-3, clip_norm=10.0, mean_bgr=MEAN_BGR, fetch=True),
-                 "bf16x3": eng_x.train_step_u8(frames, onehot, lr=1e-3, clip_norm=10.0, mean_bgr=MEAN_BGR, fetch=True)}
-        for _ in range(args.warmup):
-            eng_x.train_step_u8(frames, onehot, lr=1e-3, clip_norm=10.0, mean_bgr=MEAN_BGR, fetch=False)
-        eng_x.set_probe([l + p for l in CONV_MACS for p in (".fwd", ".dgrad", ".wgrad")])
-        torch.cuda.synchronize()
-        tx0 = time.perf_counter()
-        for _ in range(args.steps):
-            eng_x.train_step_u8(frames, onehot, lr=1e-3, clip_norm=10.0, mean_bgr=MEAN_BGR, fetch=False)
-        torch.cuda.synchronize()
-        tx = time.perf_counter() - tx0
-        per_x = {}
-        for label, ms in eng_x.probe_times_ms():
-            per_x.setdefault(label, []).append(ms)
-        eng_x.set_probe(None)
-        out_x = eng_x.train_step_u8(frames, onehot, lr=1e-3, clip_norm=10.0, mean_bgr=MEAN_BGR, fetch=True)
-        split = {"value": round(clips * args.steps / tx, 2), "unit": "clips/s", "ms_per_step": round(tx / args.steps * 1e3, 3),
-                 "dtype": "bf16x3 (conv fwd/dgrad/wgrad: split bf16 products, fp32 accumulate) + f32 (dense GEMMs, LSTM, pointwise)",
-                 "per_launch_ms": {k: round(sum(v) / len(v), 3) for k, v in sorted(per_x.items())},
-                 "check": {"loss": round(out_x["loss"], 4), "grad_norm": round(out_x["grad_norm"], 3)},
-                 "first_step_check": {k: {"loss": round(v["loss"], 5), "grad_norm": round(v["grad_norm"], 4)} for k, v in first.items()},
-                 "note": "opt-in NetConfig.conv_math; never `value`"}
-        del eng_x
+        f32_first = {"f32": eng.train_step_u8(frames, onehot, lr=1e-3, clip_norm=10.0, mean_bgr=MEAN_BGR, fetch=True)}
+        split = side_run("bf16x3", f32_first)
+        plain = side_run("bf16", f32_first)
 
     # N > 1, weak run: also time the STRONG-scaling form of the same job (BASELINE config 3: the reference's global batch of 64
     # clips split over the ranks) -- reported beside `value`, never as `value`
@@ -290,6 +298,7 @@ def main():
                          if args.fpc == 16 else None},
         "strong_scaling": strong,
         "bf16x3": split,
+        "bf16": plain,
         "check": {"loss": round(out["loss"], 4), "grad_norm": round(out["grad_norm"], 3)},
     }
     if world == 1 and not args.no_cpu_baseline:

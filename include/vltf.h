@@ -74,14 +74,16 @@ int vl_conv_set_halo(vl_conv_desc* d, int x_halo, int y_halo, int dy_halo, int d
  * for stride 1.  vl_conv_x_phase returns the phase count in force (1 = plain). */
 int vl_conv_set_x_phase_split(vl_conv_desc* d, int on);
 int vl_conv_x_phase(const vl_conv_desc* d);
-/* Arithmetic of the contraction in vl_conv_fwd / vl_conv_dgrad (process-wide; wgrad and the dense GEMMs stay fp32):
+/* Arithmetic of the contraction in vl_conv_fwd / vl_conv_dgrad / vl_conv_wgrad (process-wide; the dense GEMMs stay fp32):
  *   0  fp32 MFMA (default; the reference's arithmetic, alexnet.py:21 tf.nn.conv2d on float32)
  *   3  "bf16x3": each fp32 operand is split into a bf16 head and tail (x = hi + lo + O(2^-17 |x|)) and a product is
  *      hi*hi + hi*lo + lo*hi on the bf16 matrix pipe with fp32 accumulation -- results agree with mode 0 to ~5e-6
  *      relative L2 per layer, inside every parity tolerance of tests/, but it is NOT fp32 arithmetic and is opt-in.
  *      Applies to layers in the padded layout with >= 96 output channels per group and unit column stride in memory
  *      (stride 1, or the phase-split x of a strided conv); other layers keep mode 0.
- * The environment variable VL_CONV_MATH=bf16x3 presets mode 3. */
+ *   1  plain bf16 products (heads only), fp32 accumulation: ~2.3e-3 relative L2 per layer -- the reduced-precision conv path
+ *      of BASELINE config 5; outside the fp32 parity tolerances by design (tests hold it to 3e-2 on logits).
+ * The environment variable VL_CONV_MATH=bf16x3 | bf16 presets mode 3 | 1. */
 int vl_set_conv_math(int math);
 int vl_conv_math(void);
 /* y[n][cout][oh][ow] = conv(x[n][cin][h][w], w_hwio) + bias, optional fused ReLU (alexnet.py:77). */

@@ -130,6 +130,26 @@ def test_fc_classifier_train_step(layer, ff):
         np.testing.assert_allclose(got[k], newp[k], rtol=1e-4, atol=1e-5, err_msg="param " + k)
 
 
+def test_plain_bf16_conv_mode_runs_close():
+    """NetConfig.conv_math = "bf16" (BASELINE config 5: bf16-MFMA conv path): reduced precision by design -- logits within 3e-2
+    of the oracle (fp32 path: 1e-3), loss within 1 %, and the step trains."""
+    rng = np.random.default_rng(5)
+    shape, ncls, fpc, b = (67, 67, 3), 7, 3, 2
+    cfg, eng = make(dict(num_classes=ncls, fpc=fpc, lstm_hidden=8, conv_math="bf16"), shape, b)
+    p = oracle_params(rng, cfg, shape)
+    eng.load_params(p)
+    frames = rng.integers(0, 256, (b * fpc,) + shape, dtype=np.uint8)
+    onehot = O.labels_to_one_hot([[l] for l in rng.integers(0, ncls, b)], ncls)
+    x = frames.astype(np.float32) - MEAN
+    _, loss, gn, _, logits, _ = O.lrcn_train_step(p, x, onehot, fpc, lr=0.01, clip_norm=0.5)
+    fd = torch.tensor(frames, device=DEV)
+    got = eng.forward_u8(fd, MEAN).cpu().numpy()
+    np.testing.assert_allclose(got, logits, rtol=3e-2, atol=3e-2)
+    assert np.abs(got - logits).max() > 1e-6                      # not the fp32 path
+    out = eng.train_step_u8(fd, torch.tensor(onehot, device=DEV), lr=0.01, clip_norm=0.5, mean_bgr=MEAN)
+    assert abs(out["loss"] - loss) < 1e-2 * max(1, abs(loss)) and abs(out["grad_norm"] - gn) < 5e-2 * gn
+
+
 _FULL = {}
 
 

@@ -201,6 +201,35 @@ def test_conv_fwd_bwd(ops, conv_math, padded, n, h, w, cin, cout, k, s, g):
             conv.dgrad(dyd, wd, torch.empty_like(xd))
 
 
+@pytest.mark.parametrize("conv_math", ["bf16"], indirect=True)
+@pytest.mark.parametrize("n,h,w,cin,cout,k,s,g", [(2, 28, 28, 96, 256, 5, 1, 2), (3, 13, 13, 256, 384, 3, 1, 1)])
+def test_conv_plain_bf16_mode(ops, conv_math, n, h, w, cin, cout, k, s, g):
+    """vl_set_conv_math(1): plain bf16 products with fp32 accumulation (BASELINE config 5's reduced-precision conv path).
+    Outside the fp32 tolerances by design: each contraction must land within 6e-3 relative L2 of the oracle (bf16 rounding of
+    both operands: ~2.3e-3 measured) and NOT within 1e-4 (i.e. the mode really is in force)."""
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal((n, h, w, cin)).astype(np.float32)
+    wt = (rng.standard_normal((k, k, cin // g, cout)) / math.sqrt(k * k * cin / g)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    dy = rng.standard_normal((n, h, w, cout)).astype(np.float32)
+    conv = ops.Conv(cin, h, w, cout, k, k, s, g)
+    pad = conv.same_pad()
+    conv.set_halo(pad, 0, k - 1, 0)
+    xd, wd, dyd = dev(pad_nchw(nchw(x), pad)), dev(wt), dev(pad_nchw(nchw(dy), k - 1))
+    y = torch.empty((n, cout, h, w), device=DEV)
+    conv.fwd(xd, wd, dev(b), y, relu=False)
+    dxo, dwo, _ = O.grouped_conv_grad(x, wt, dy, s, g, need_dx=True)
+    wtt = torch.empty(wd.numel(), device=DEV)
+    conv.wt_transpose(wd, wtt)
+    dx = torch.empty((n, cin, h, w), device=DEV)
+    conv.dgrad(dyd, wtt, dx)
+    dw = torch.empty_like(wd)
+    conv.wgrad(xd, dyd, dw, torch.empty(max(conv.wgrad_ws_bytes(n) // 4, 1), device=DEV))
+    for name, got, want in (("fwd", nhwc(host(y)), O.grouped_conv(x, wt, b, s, g)), ("dgrad", nhwc(host(dx)), dxo), ("wgrad", host(dw), dwo)):
+        err = np.linalg.norm(got - want) / np.linalg.norm(want)
+        assert 1e-4 < err < 6e-3, (name, err)
+
+
 # ---- LRN / pool ------------------------------------------------------------------------------------
 @pytest.mark.parametrize("n,h,w,c", [(2, 5, 4, 11), (2, 9, 7, 96), (1, 6, 6, 256), (3, 3, 3, 33)])
 def test_lrn(ops, n, h, w, c):

@@ -873,9 +873,13 @@ __global__ __launch_bounds__(NT, 1) void wgrad_dma_kernel(const ConvGeom g, cons
     const float* fa3 = ldsw + (wi0 + (lane & 31)) * STR + 8 * (lane >> 5);
     const float* fb3 = ldsw + SA + (wj0 + (lane & 31)) * STR + 8 * (lane >> 5);
     auto tile_split = [&](const int cur, int rt_next) __attribute__((always_inline)) {
-        constexpr int NMS = 3 * TM * TN, NTOT = 4 * NMS, NF = RA + RB;
-        constexpr int FPM = (NF + NTOT - 15) / (NTOT - 14);
-        static_assert((NF + FPM - 1) / FPM <= NTOT - 12, "fetches must end before the table is replaced");
+        constexpr int NP = MATH == 3 ? 3 : 1;                          // MATH 1: heads only (plain bf16 products)
+        constexpr int NMS = NP * TM * TN, NTOT = 4 * NMS, NF = RA + RB;
+        constexpr int FSPAN = NTOT >= 28 ? NTOT - 14 : NTOT / 2;      // the fetches ride on the first FSPAN MFMAs of the tile
+        constexpr int FPM = (NF + FSPAN - 1) / FSPAN, FEND = (NF + FPM - 1) / FPM;
+        constexpr int LT = FEND > NTOT - 12 ? FEND : NTOT - 12;       // table of the tile after next: once the fetches are out
+        constexpr int PIN = LT + 2 > NTOT - 6 ? LT + 2 : NTOT - 6;
+        static_assert(PIN < NTOT, "the tile must leave room to load and pin the next table");
         SplitBf16 As[2][TM], Bs[2][TN];
         auto load_split = [&](const int st, SplitBf16 (&A)[TM], SplitBf16 (&B)[TN]) __attribute__((always_inline)) {
 #pragma unroll
@@ -883,8 +887,8 @@ __global__ __launch_bounds__(NT, 1) void wgrad_dma_kernel(const ConvGeom g, cons
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float2 v = *reinterpret_cast<const float2*>(fa3 + cur * BUF + a * 32 * STR + 16 * st + 2 * q);
-                    int hi, lo;
-                    split_pair<true>(v.x, v.y, hi, lo);
+                    int hi, lo = 0;
+                    split_pair<NP == 3>(v.x, v.y, hi, lo);
                     A[a].hi[q] = hi;
                     A[a].lo[q] = lo;
                 }
@@ -893,8 +897,8 @@ __global__ __launch_bounds__(NT, 1) void wgrad_dma_kernel(const ConvGeom g, cons
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float2 v = *reinterpret_cast<const float2*>(fb3 + cur * BUF + b * 32 * STR + 16 * st + 2 * q);
-                    int hi, lo;
-                    split_pair<true>(v.x, v.y, hi, lo);
+                    int hi, lo = 0;
+                    split_pair<NP == 3>(v.x, v.y, hi, lo);
                     B[b].hi[q] = hi;
                     B[b].lo[q] = lo;
                 }
@@ -913,8 +917,8 @@ __global__ __launch_bounds__(NT, 1) void wgrad_dma_kernel(const ConvGeom g, cons
                     if constexpr (f < NF) dma(cur ^ 1, f, rt_next);
                 });
                 __builtin_amdgcn_sched_barrier(0x106);        // VALU / SALU / LDS reads may move across, MFMAs and fetches stay put
-                if constexpr (idx == NTOT - 12) load_table(rt_next + 1);
-                if constexpr (idx == NTOT - 6) {
+                if constexpr (idx == LT) load_table(rt_next + 1);
+                if constexpr (idx == PIN) {
                     int rtn = rt_next + 1;
                     asm volatile("" : "+s"(rtn));
                     decode(rtn);
@@ -925,7 +929,7 @@ __global__ __launch_bounds__(NT, 1) void wgrad_dma_kernel(const ConvGeom g, cons
         finish_tile(cur ^ 1);
     };
     auto run_tile = [&](const int cur, int rt_next) __attribute__((always_inline)) {
-        if constexpr (MATH == 3) tile_split(cur, rt_next);
+        if constexpr (MATH != 0) tile_split(cur, rt_next);
         else tile(cur, rt_next);
     };
     int rt = rt0;
@@ -1340,14 +1344,14 @@ __global__ __launch_bounds__(512, 1) void conv_ring_kernel(const ConvRingParams 
     const float* fa = ldsr + ((lane >> 5) * BM + (lane & 31)) * 4;
     const float* fb = ldsr + ABUF + (lane >> 5) * 8 * BN + wave * WPX + (lane & 31);
     struct Raw {                                                      // a stage's im2col operands of this lane as read from LDS
-        float b[8][TB];
+        float b[TB][8];
     };
     auto load_raw = [&](int rd, Raw& r) __attribute__((always_inline)) {                  // rd: ring slot offset in dwords
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float* q = fb + rd + j * BN;
 #pragma unroll
-            for (int b = 0; b < TB; ++b) r.b[j][b] = q[32 * b];
+            for (int b = 0; b < TB; ++b) r.b[b][j] = q[32 * b];
         }
     };
     auto load_a = [&](int rd, SplitBf16 (&A)[TA]) __attribute__((always_inline)) {       // the weight operands come split: no VALU
@@ -1363,7 +1367,7 @@ __global__ __launch_bounds__(512, 1) void conv_ring_kernel(const ConvRingParams 
 #pragma unroll
             for (int b = 0; b < TB; ++b) {
                 int hi, lo = 0;
-                split_pair<NP == 3>(r.b[2 * j][b], r.b[2 * j + 1][b], hi, lo);
+                split_pair<NP == 3>(r.b[b][2 * j], r.b[b][2 * j + 1], hi, lo);
                 B[b].hi[j] = hi;
                 B[b].lo[j] = lo;
             }
@@ -1405,10 +1409,12 @@ __global__ __launch_bounds__(512, 1) void conv_ring_kernel(const ConvRingParams 
                      const Raw& Rc, Raw& Rn) __attribute__((always_inline)) {
         load_a(rda, An);
         load_raw(rdb, Rn);                                            // garbage past the end: never multiplied
-        static_for<0, NM>([&](auto MI) __attribute__((always_inline)) {
+        static_for<0, (NM > FW ? NM : FW)>([&](auto MI) __attribute__((always_inline)) {
             constexpr int m = decltype(MI)::value;
-            constexpr int prod = m / (TA * TB), a = (m % (TA * TB)) / TB, b = m % TB;
-            acc[a][b] = mfma_bf16(prod == 2 ? Ac[a].lo : Ac[a].hi, prod == 1 ? Bc[b].lo : Bc[b].hi, acc[a][b]);
+            if constexpr (m < NM) {
+                constexpr int prod = m / (TA * TB), a = (m % (TA * TB)) / TB, b = m % TB;
+                acc[a][b] = mfma_bf16(prod == 2 ? Ac[a].lo : Ac[a].hi, prod == 1 ? Bc[b].lo : Bc[b].hi, acc[a][b]);
+            }
             if constexpr (m < FW) {                                   // one fetch in the shadow of each of the first FW MFMAs
                 if (fast) dma_fast(wr, m, st + D);
                 else if (st + D < nstages) dma(wr, m, st + D);
@@ -1566,7 +1572,7 @@ __global__ __launch_bounds__(256, 2) void conv_ring4_kernel(const ConvRingParams
 
     const float* fa = ldsq + ((lane >> 5) * BM + (lane & 31)) * 4;
     const float* fb = ldsq + ABUF + (lane >> 5) * 8 * BN + wave * WPX + (lane & 31);
-    auto load_ops = [&](int rd, SplitBf16 (&A)[TA], float (&rb)[8][TB]) __attribute__((always_inline)) {
+    auto load_ops = [&](int rd, SplitBf16 (&A)[TA], float (&rb)[TB][8]) __attribute__((always_inline)) {
 #pragma unroll
         for (int a = 0; a < TA; ++a) {
             A[a].hi = *reinterpret_cast<const i32x4*>(fa + rd + a * 32 * 4);
@@ -1575,15 +1581,15 @@ __global__ __launch_bounds__(256, 2) void conv_ring4_kernel(const ConvRingParams
 #pragma unroll
         for (int j = 0; j < 8; ++j)
 #pragma unroll
-            for (int b = 0; b < TB; ++b) rb[j][b] = fb[rd + j * BN + 32 * b];
+            for (int b = 0; b < TB; ++b) rb[b][j] = fb[rd + j * BN + 32 * b];
     };
-    auto split = [&](const float (&rb)[8][TB], SplitBf16 (&B)[TB]) __attribute__((always_inline)) {
+    auto split = [&](const float (&rb)[TB][8], SplitBf16 (&B)[TB]) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int b = 0; b < TB; ++b) {
                 int hi, lo = 0;
-                split_pair<NP == 3>(rb[2 * j][b], rb[2 * j + 1][b], hi, lo);
+                split_pair<NP == 3>(rb[b][2 * j], rb[b][2 * j + 1], hi, lo);
                 B[b].hi[j] = hi;
                 B[b].lo[j] = lo;
             }
@@ -1605,7 +1611,7 @@ __global__ __launch_bounds__(256, 2) void conv_ring4_kernel(const ConvRingParams
     __syncthreads();
     SplitBf16 A[TA] = {}, B[TB] = {}, An[TA] = {}, Bn[TB] = {};
     {
-        float rb[8][TB];
+        float rb[TB][8];
         load_ops(0, A, rb);
         split(rb, B);
     }
@@ -1617,8 +1623,9 @@ __global__ __launch_bounds__(256, 2) void conv_ring4_kernel(const ConvRingParams
     uint32_t wr = 0;                                                  // slot (bytes) of stage st + 3 = the one of stage st
     auto stage = [&](const bool fast, int st, SplitBf16 (&Ac)[TA], SplitBf16 (&Bc)[TB], SplitBf16 (&An)[TA], SplitBf16 (&Bn)[TB])
                      __attribute__((always_inline)) {
-        float rb[8][TB];
+        float rb[TB][8];
         load_ops(rd, An, rb);                                         // garbage past the end: never multiplied
+        static_assert(NM >= FW, "a fetch rides on each of the first FW MFMAs");
         static_for<0, NM>([&](auto MI) __attribute__((always_inline)) {
             constexpr int m = decltype(MI)::value;
             constexpr int prod = m / (TA * TB), a = (m % (TA * TB)) / TB, b = m % TB;
@@ -1716,15 +1723,15 @@ static const bool kConvStaged = getenv("VL_CONV_STAGED") != nullptr;
 static const bool kGemmNoSplit = getenv("VL_GEMM_NOSPLIT") != nullptr;
 static const bool kRing8 = getenv("VL_CONV_RING8") != nullptr;      // bf16x3, 128-channel layers: the 8-wave conv_ring_kernel instead of conv_ring4_kernel
 
-// contraction arithmetic of conv forward / dgrad: 0 = fp32 MFMA (default, the parity path), 3 = bf16x3 split products
-// (vl_set_conv_math; VL_CONV_MATH=bf16x3 presets it)
+// contraction arithmetic of the three conv kernels: 0 = fp32 MFMA (default, the parity path), 3 = bf16x3 split products,
+// 1 = plain bf16 products (heads only) (vl_set_conv_math; VL_CONV_MATH=bf16x3 | bf16 presets it)
 static int g_conv_math = [] {
     const char* e = getenv("VL_CONV_MATH");
-    return e != nullptr && strcmp(e, "bf16x3") == 0 ? 3 : 0;
+    return e == nullptr ? 0 : strcmp(e, "bf16x3") == 0 ? 3 : strcmp(e, "bf16") == 0 ? 1 : 0;
 }();
 
 extern "C" int vl_set_conv_math(int math) {
-    VL_CHECK(math == 0 || math == 3, "vl_set_conv_math: 0 (fp32) or 3 (bf16x3)");
+    VL_CHECK(math == 0 || math == 1 || math == 3, "vl_set_conv_math: 0 (fp32), 1 (bf16) or 3 (bf16x3)");
     g_conv_math = math;
     return 0;
 }
@@ -2208,21 +2215,23 @@ static int launch_conv_ring(const ConvGeom& g, const float* w, int64_t w_ld, int
     dim3 grid(tiles_i * tiles_j, (unsigned)groups, 1);
     if (BM == 128 && !kRing8) {                                          // 4-wave workgroups, two per CU (VL_CONV_RING8=1: the 8-wave form)
         constexpr size_t lds4 = (size_t)3 * 16 * (128 + 256) * sizeof(float);    // 72 KB
-        static bool attr4 = false;
-        auto k4 = conv_ring4_kernel<3>;
-        if (!attr4) {
+        static bool attr4[2] = {false, false};
+        const int v4 = g_conv_math == 3;
+        auto k4 = v4 ? conv_ring4_kernel<3> : conv_ring4_kernel<1>;
+        if (!attr4[v4]) {
             VL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
-            attr4 = true;
+            attr4[v4] = true;
         }
         hipLaunchKernelGGL(k4, grid, dim3(256), lds4, s, pa, g, pe, tiles_i, OWp, Mp, make_fastdiv(OH * OWp), make_fastdiv(OWp));
         VL_LAUNCH_CHECK();
         return 0;
     }
-    static bool attr_set = false;
-    auto kern = conv_ring_kernel<3, BM>;
-    if (!attr_set) {
+    static bool attr_set[2] = {false, false};
+    const int v8 = g_conv_math == 3;
+    auto kern = v8 ? conv_ring_kernel<3, BM> : conv_ring_kernel<1, BM>;
+    if (!attr_set[v8]) {
         VL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        attr_set[v8] = true;
     }
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, pa, g, pe, tiles_i, OWp, Mp, make_fastdiv(OH * OWp), make_fastdiv(OWp));
     VL_LAUNCH_CHECK();
@@ -2235,7 +2244,7 @@ static int dispatch_conv(const ConvGeom& g, const float* w, int64_t w_ld, int w_
     // output-channel tile: 128 when it divides well, else 96 (conv1: 96, conv4: 192) or 64 (conv2 dgrad: 48)
     const int w128 = ceil_div(Cog, 128) * 128, w96 = ceil_div(Cog, 96) * 96, w64 = ceil_div(Cog, 64) * 64;
     // split products: the ring kernel (128-channel tiles; its 16-byte im2col fetches need unit column stride in memory)
-    if (g_conv_math == 3 && PADDED && g.col_mul == 1) {
+    if (g_conv_math != 0 && PADDED && g.col_mul == 1) {
         if (Cog >= 96) return launch_conv_ring<128>(g, w, w_ld, w_grp_stride, row_tab, Cog, Cout_total, o, wsplit, s);
         if (Cog >= 40 && Cog <= 64) return launch_conv_ring<64>(g, w, w_ld, w_grp_stride, row_tab, Cog, Cout_total, o, wsplit, s);
     }
@@ -2378,9 +2387,9 @@ static int launch_wgrad_dma(const vl_conv_desc* d, const ConvGeom& g, const floa
     EpiRowMajor::Params pe{splits > 1 ? ws : dw, d->cout, d->K, d->cog, nullptr, nullptr, 0, d->cog, splits > 1 ? slab : 0};
     const int tiles_i = ceil_div(d->K, C::BM), tiles_j = ceil_div(d->cog, BN);
     const int rtiles = ceil_div(g.M, C::BR);
-    static bool attr_set[2] = {false, false};
-    const int v = g_conv_math == 3;
-    auto kern = v ? wgrad_dma_kernel<BN, WM, WN, 3> : wgrad_dma_kernel<BN, WM, WN, 0>;
+    static bool attr_set[3] = {false, false, false};
+    const int v = g_conv_math == 3 ? 2 : g_conv_math == 1 ? 1 : 0;
+    auto kern = v == 2 ? wgrad_dma_kernel<BN, WM, WN, 3> : v == 1 ? wgrad_dma_kernel<BN, WM, WN, 1> : wgrad_dma_kernel<BN, WM, WN, 0>;
     if (!attr_set[v]) {
         VL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
         attr_set[v] = true;

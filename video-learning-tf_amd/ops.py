@@ -337,11 +337,12 @@ def fill(t, value):
     _ffi.call("vl_fill", _p(t), t.numel(), value, stream())
 
 
-CONV_MATH = {"f32": 0, "bf16x3": 3}
+CONV_MATH = {"f32": 0, "bf16": 1, "bf16x3": 3}
 
 
 def set_conv_math(name):
-    """Arithmetic of conv forward / dgrad (vl_set_conv_math): "f32" (default) or "bf16x3" (split bf16 products, opt-in)."""
+    """Arithmetic of the conv contractions (vl_set_conv_math): "f32" (default), "bf16x3" (split bf16 products) or "bf16" (plain
+    bf16 products: reduced precision), both opt-in."""
     if name not in CONV_MATH:
         raise _ffi.VltfError("conv math must be one of %s, not %r" % (sorted(CONV_MATH), name))
     _ffi.call("vl_set_conv_math", CONV_MATH[name])
