@@ -185,7 +185,7 @@ def main():
     # products, BASELINE config 5's reduced-precision conv path; everything else unchanged):
     # the same job timed the same way, reported BESIDE `value` (which stays the fp32 path), with its own loss / gradient norm
     # after the same number of steps from the same initial parameters as evidence of what the arithmetic changes.
-    split, plain = None, None
+    split, split6, plain = None, None, None
     if world == 1 and not args.no_split_math:
         import dataclasses
 
@@ -211,7 +211,8 @@ def main():
             eng_x.set_probe(None)
             out_x = eng_x.train_step_u8(frames, onehot, lr=1e-3, clip_norm=10.0, mean_bgr=MEAN_BGR, fetch=True)
             del eng_x
-            what = "split bf16 products" if math == "bf16x3" else "plain bf16 products (reduced precision)"
+            what = {"bf16x3": "split bf16 products, 2 pieces / 3 products", "bf16x6": "split bf16 products, 3 pieces / 6 products",
+                    "bf16": "plain bf16 products (reduced precision)"}[math]
             return {"value": round(clips * args.steps / tx, 2), "unit": "clips/s", "ms_per_step": round(tx / args.steps * 1e3, 3),
                     "dtype": "%s (conv fwd/dgrad/wgrad: %s, fp32 accumulate) + f32 (dense GEMMs, LSTM, pointwise)" % (math, what),
                     "per_launch_ms": {k: round(sum(v) / len(v), 3) for k, v in sorted(per_x.items())},
@@ -222,6 +223,7 @@ def main():
         eng.load_params(init_params(cfg, seed=2))
         f32_first = {"f32": eng.train_step_u8(frames, onehot, lr=1e-3, clip_norm=10.0, mean_bgr=MEAN_BGR, fetch=True)}
         split = side_run("bf16x3", f32_first)
+        split6 = side_run("bf16x6", f32_first)
         plain = side_run("bf16", f32_first)
 
     # N > 1, weak run: also time the STRONG-scaling form of the same job (BASELINE config 3: the reference's global batch of 64
@@ -298,6 +300,7 @@ def main():
                          if args.fpc == 16 else None},
         "strong_scaling": strong,
         "bf16x3": split,
+        "bf16x6": split6,
         "bf16": plain,
         "check": {"loss": round(out["loss"], 4), "grad_norm": round(out["grad_norm"], 3)},
     }

@@ -81,9 +81,11 @@ int vl_conv_x_phase(const vl_conv_desc* d);
  *      relative L2 per layer, inside every parity tolerance of tests/, but it is NOT fp32 arithmetic and is opt-in.
  *      Applies to layers in the padded layout with >= 96 output channels per group and unit column stride in memory
  *      (stride 1, or the phase-split x of a strided conv); other layers keep mode 0.
+ *   6  "bf16x6": three bf16 pieces per operand and the six products above 2^-23 -- agrees with mode 0 to ~1e-7 relative L2 per
+ *      layer, i.e. to fp32 rounding (as close as two fp32 summation orders are to each other); opt-in like mode 3.
  *   1  plain bf16 products (heads only), fp32 accumulation: ~2.3e-3 relative L2 per layer -- the reduced-precision conv path
  *      of BASELINE config 5; outside the fp32 parity tolerances by design (tests hold it to 3e-2 on logits).
- * The environment variable VL_CONV_MATH=bf16x3 | bf16 presets mode 3 | 1. */
+ * The environment variable VL_CONV_MATH=bf16x3 | bf16x6 | bf16 presets mode 3 | 6 | 1. */
 int vl_set_conv_math(int math);
 int vl_conv_math(void);
 /* y[n][cout][oh][ow] = conv(x[n][cin][h][w], w_hwio) + bias, optional fused ReLU (alexnet.py:77). */

@@ -26,7 +26,7 @@ def oracle_params(rng, cfg, shape):
 
 @pytest.mark.parametrize("layer,layers,fusion,hid,math", [("fc6", 1, "avg", 8, "f32"), ("fc7", 2, "last", 12, "f32"),
                                                           ("fc8", 1, "avg", 7, "f32"), ("fc6", 2, "state", 9, "f32"),
-                                                          ("fc6", 1, "avg", 8, "bf16x3")])
+                                                          ("fc6", 1, "avg", 8, "bf16x3"), ("fc6", 1, "avg", 8, "bf16x6")])
 def test_train_step_small(layer, layers, fusion, hid, math):
     """math="bf16x3": NetConfig.conv_math, the opt-in split-bf16 conv products -- same oracle, same tolerances."""
     rng = np.random.default_rng(5)
@@ -51,7 +51,7 @@ def test_train_step_small(layer, layers, fusion, hid, math):
     g = eng.get_grads()
     for k in p:
         scale = np.abs(grads[k]).max() + 1e-12
-        if math == "f32":
+        if math in ("f32", "bf16x6"):                # bf16x6 (error at fp32 rounding level) is held to the fp32 bound
             np.testing.assert_allclose(g[k], grads[k], rtol=2e-3, atol=2e-4 * scale, err_msg="grad " + k)
         else:
             # split products move a pre-activation by ~5e-6 relative, enough to flip a ReLU / arg-max decision that the fp32
@@ -167,7 +167,7 @@ def full_geometry_case():
     return _FULL["case"]
 
 
-@pytest.mark.parametrize("math", ["f32", "bf16x3"])
+@pytest.mark.parametrize("math", ["f32", "bf16x3", "bf16x6"])
 def test_full_geometry_logits_and_step(math):
     """227x227x3, 2 clips x 4 frames, fc6 -> LSTM(256) -> 101 classes: the real layer shapes; math="bf16x3" is the opt-in
     split-product conv arithmetic (NetConfig.conv_math) held to the same bounds."""

@@ -111,13 +111,13 @@ def conv_math(ops, request):
     ops.set_conv_math("f32")
 
 
-@pytest.mark.parametrize("conv_math,padded", [("f32", False), ("f32", True), ("bf16x3", True)], indirect=["conv_math"])
+@pytest.mark.parametrize("conv_math,padded", [("f32", False), ("f32", True), ("bf16x3", True), ("bf16x6", True)], indirect=["conv_math"])
 @pytest.mark.parametrize("n,h,w,cin,cout,k,s,g", CONV_CASES)
 def test_conv_fwd_bwd(ops, conv_math, padded, n, h, w, cin, cout, k, s, g):
     """padded=False: dense NCHW, bounds-tested gather.  padded=True: every tensor carries a zero halo
     (x/dy: the SAME padding -> test-free gather; y/dx: an arbitrary halo of 1) as the engine lays them out.
-    conv_math="bf16x3": the opt-in split-bf16 products of vl_set_conv_math (padded layout, >= 96 output channels per group:
-    conv1 phase-split, conv2-5 forward, conv3-5 dgrad here) against the SAME oracle at the SAME tolerances."""
+    conv_math="bf16x3" / "bf16x6": the opt-in split-bf16 products of vl_set_conv_math (padded layout, >= 40 output channels per
+    group: conv1 phase-split, conv2-5 forward and dgrad, every wgrad) against the SAME oracle at the SAME tolerances."""
     rng = np.random.default_rng(h * 100 + cin)
     x = rng.standard_normal((n, h, w, cin)).astype(np.float32)
     wt = (rng.standard_normal((k, k, cin // g, cout)) / math.sqrt(k * k * cin / g)).astype(np.float32)

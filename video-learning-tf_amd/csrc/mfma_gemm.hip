@@ -685,20 +685,34 @@ __device__ __forceinline__ void static_for(F&& f) {     // f(IntC<B>) ... f(IntC
         static_for<B + 1, E>(f);
     }
 }
-struct SplitBf16 {        // 8 reduction positions of one operand row/column: 4 dwords of bf16 pairs, head and tail (MFMA operand tuples)
-    i32x4 hi, lo;
+struct SplitBf16 {        // 8 reduction positions of one operand row/column as MFMA operand tuples (4 dwords of bf16 pairs) per piece:
+    i32x4 p[3];           // p[0] head, p[1] = bf16(x - head), p[2] = bf16(x - head - p[1]) (bf16x6 only)
 };
-template <bool TAIL>
-__device__ __forceinline__ void split_pair(float x0, float x1, int& hi, int& lo) {
-    const f32x2 v = {x0, x1};
-    const uint32_t h = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));      // round to nearest even
-    hi = (int)h;
-    if (TAIL) {
-        // (left to hipcc, which pairs the two subtractions into one v_pk_add_f32: two scalar v_sub_f32 measured 3-10 % slower)
-        const f32x2 r = {x0 - __uint_as_float(h << 16), x1 - __uint_as_float(h & 0xffff0000u)};
-        lo = (int)__builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2));
+// NPC pieces of the pair (x0, x1): each piece is the bf16 rounding (to nearest even) of what the previous pieces left over.
+template <int NPC>
+__device__ __forceinline__ void split_pieces(float x0, float x1, int (&out)[3]) {
+    f32x2 r = {x0, x1};
+#pragma unroll
+    for (int k = 0; k < NPC; ++k) {
+        const uint32_t h = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2));
+        out[k] = (int)h;
+        // (the subtraction is left to hipcc, which emits one v_pk_add_f32: two scalar v_sub_f32 measured 3-10 % slower)
+        if (k + 1 < NPC) r = f32x2{r[0] - __uint_as_float(h << 16), r[1] - __uint_as_float(h & 0xffff0000u)};
     }
 }
+template <bool TAIL>
+__device__ __forceinline__ void split_pair(float x0, float x1, int& hi, int& lo) {
+    int o[3] = {0, 0, 0};
+    split_pieces<TAIL ? 2 : 1>(x0, x1, o);
+    hi = o[0];
+    if (TAIL) lo = o[1];
+}
+// products of a split contraction, in issue order: piece of the A operand x piece of the B operand.  The first NP entries are
+// the mode: NP = 1 plain bf16, 3 bf16x3 (drops tail*tail, ~2^-18), 6 bf16x6 (drops terms below ~2^-23: fp32 rounding level)
+__device__ constexpr int kProdA[6] = {0, 0, 1, 1, 0, 2};
+__device__ constexpr int kProdB[6] = {0, 1, 0, 1, 2, 0};
+constexpr int split_products(int math) { return math == 6 ? 6 : math == 3 ? 3 : 1; }
+constexpr int split_pieces_of(int math) { return math == 6 ? 3 : math == 3 ? 2 : 1; }
 __device__ __forceinline__ f32x16 mfma_bf16(const i32x4& a, const i32x4& b, const f32x16& c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
@@ -873,7 +887,7 @@ __global__ __launch_bounds__(NT, 1) void wgrad_dma_kernel(const ConvGeom g, cons
     const float* fa3 = ldsw + (wi0 + (lane & 31)) * STR + 8 * (lane >> 5);
     const float* fb3 = ldsw + SA + (wj0 + (lane & 31)) * STR + 8 * (lane >> 5);
     auto tile_split = [&](const int cur, int rt_next) __attribute__((always_inline)) {
-        constexpr int NP = MATH == 3 ? 3 : 1;                          // MATH 1: heads only (plain bf16 products)
+        constexpr int NP = split_products(MATH), NPC = split_pieces_of(MATH);   // MATH 1: heads only (plain bf16 products)
         constexpr int NMS = NP * TM * TN, NTOT = 4 * NMS, NF = RA + RB;
         constexpr int FSPAN = NTOT >= 28 ? NTOT - 14 : NTOT / 2;      // the fetches ride on the first FSPAN MFMAs of the tile
         constexpr int FPM = (NF + FSPAN - 1) / FSPAN, FEND = (NF + FPM - 1) / FPM;
@@ -887,20 +901,20 @@ __global__ __launch_bounds__(NT, 1) void wgrad_dma_kernel(const ConvGeom g, cons
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float2 v = *reinterpret_cast<const float2*>(fa3 + cur * BUF + a * 32 * STR + 16 * st + 2 * q);
-                    int hi, lo = 0;
-                    split_pair<NP == 3>(v.x, v.y, hi, lo);
-                    A[a].hi[q] = hi;
-                    A[a].lo[q] = lo;
+                    int pc[3] = {0, 0, 0};
+                    split_pieces<NPC>(v.x, v.y, pc);
+#pragma unroll
+                    for (int k = 0; k < NPC; ++k) A[a].p[k][q] = pc[k];
                 }
 #pragma unroll
             for (int b = 0; b < TN; ++b)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float2 v = *reinterpret_cast<const float2*>(fb3 + cur * BUF + b * 32 * STR + 16 * st + 2 * q);
-                    int hi, lo = 0;
-                    split_pair<NP == 3>(v.x, v.y, hi, lo);
-                    B[b].hi[q] = hi;
-                    B[b].lo[q] = lo;
+                    int pc[3] = {0, 0, 0};
+                    split_pieces<NPC>(v.x, v.y, pc);
+#pragma unroll
+                    for (int k = 0; k < NPC; ++k) B[b].p[k][q] = pc[k];
                 }
         };
         load_split(0, As[0], Bs[0]);
@@ -910,7 +924,7 @@ __global__ __launch_bounds__(NT, 1) void wgrad_dma_kernel(const ConvGeom g, cons
             static_for<0, NMS>([&](auto MI) __attribute__((always_inline)) {
                 constexpr int m = decltype(MI)::value;
                 constexpr int prod = m / (TM * TN), a = (m % (TM * TN)) / TN, b = m % TN;
-                acc[a][b] = mfma_bf16(prod == 2 ? As[c][a].lo : As[c][a].hi, prod == 1 ? Bs[c][b].lo : Bs[c][b].hi, acc[a][b]);
+                acc[a][b] = mfma_bf16(As[c][a].p[kProdA[prod]], Bs[c][b].p[kProdB[prod]], acc[a][b]);
                 constexpr int idx = st * NMS + m;
                 static_for<0, FPM>([&](auto EI) __attribute__((always_inline)) {
                     constexpr int f = idx * FPM + decltype(EI)::value;
@@ -1211,12 +1225,13 @@ __device__ __forceinline__ void lds_dma_row4(i32x4 rs, uint32_t lds_byte_addr, u
                  : "m0");
 }
 
-// out[group][stage][plane: head, tail][h][co < CogP][q] = bf16 pair of weight rows row_tab[stage] + 8 h + 2 q, + 1 (zero past K / Cog)
+// out[group][stage][plane < planes][h][co < CogP][q] = bf16 pair of weight rows row_tab[stage] + 8 h + 2 q, + 1 (zero past K / Cog);
+// plane 0 = heads, 1 = tails, 2 = what heads + tails leave over (bf16x6)
 __global__ void conv_wsplit_kernel(const float* __restrict__ w, int64_t w_ld, int64_t w_grp_stride, const int* __restrict__ row_tab,
-                                   int K, int Cog, int CogP, int nstages, uint32_t* __restrict__ out) {
+                                   int K, int Cog, int CogP, int nstages, int planes, uint32_t* __restrict__ out) {
     const int st = blockIdx.x, zg = blockIdx.y;
     const int row0 = row_tab[st];
-    uint32_t* o = out + ((int64_t)zg * nstages + st) * 16 * CogP;
+    uint32_t* o = out + ((int64_t)zg * nstages + st) * planes * 8 * CogP;
     for (int idx = threadIdx.x; idx < 8 * CogP; idx += blockDim.x) {
         const int q = idx & 3, co = (idx >> 2) % CogP, h = idx / (4 * CogP);
         const int r = 8 * h + 2 * q, p = st * 16 + r;
@@ -1226,10 +1241,9 @@ __global__ void conv_wsplit_kernel(const float* __restrict__ w, int64_t w_ld, in
             if (p < K) x0 = src[0];
             if (p + 1 < K) x1 = src[w_ld];
         }
-        int hi, lo;
-        split_pair<true>(x0, x1, hi, lo);
-        o[(int64_t)(h * CogP + co) * 4 + q] = (uint32_t)hi;
-        o[(int64_t)((2 + h) * CogP + co) * 4 + q] = (uint32_t)lo;
+        int pc[3] = {0, 0, 0};
+        split_pieces<3>(x0, x1, pc);
+        for (int k = 0; k < planes; ++k) o[(int64_t)((2 * k + h) * CogP + co) * 4 + q] = (uint32_t)pc[k];
     }
 }
 
@@ -1248,10 +1262,12 @@ __global__ __launch_bounds__(512, 1) void conv_ring_kernel(const ConvRingParams 
     constexpr int BN = BM == 128 ? 256 : 512, SR = 16, NBUF = BM == 128 ? 5 : 4;
     constexpr int NH = BN / 256;                                      // 256-pixel fetches per im2col row
     static_assert(BM == 128 || BM == 64, "channel tile");
-    constexpr int ABUF = SR * BM, BUF = SR * (BM + BN);               // dwords
-    constexpr int FW = 1 + 2 * NH;                                    // fetches per wave per stage: one weight piece, im2col rows 2w, 2w + 1
+    constexpr int NPL = MATH == 6 ? 3 : 2;                            // planes of the weight image (heads, tails[, leftovers])
+    constexpr int ABUF = NPL * 8 * BM, BUF = ABUF + SR * BN;          // dwords
+    constexpr int NAF = (NPL * 2 * (BM / 64) + 7) / 8;                // weight pieces (1 KB) each wave fetches per stage: 1, or 2 (bf16x6, BM = 128)
+    constexpr int FW = NAF + 2 * NH;                                  // fetches per wave per stage: weight pieces, im2col rows 2w, 2w + 1
     constexpr int VMW = (NBUF - 3) * FW;                              // fetches that may stay in flight at a stage's end: NBUF - 3 stages
-    constexpr int NP = MATH == 3 ? 3 : 1;
+    constexpr int NP = split_products(MATH), NPC = split_pieces_of(MATH);
     constexpr int NM = (BM / 32) * (BN / 256) * NP;                   // MFMAs per wave per stage (TA x TB blocks x products)
     static_assert(SR == KBLK, "one stage = one block of the reduction order");
     extern __shared__ __attribute__((aligned(16))) float ldsr[];
@@ -1271,12 +1287,20 @@ __global__ __launch_bounds__(512, 1) void conv_ring_kernel(const ConvRingParams 
     // weights: wave w fetches one 1 KB piece of a stage's image, 16 B per lane.  BM = 128: piece w = (plane w >> 2, lane half
     // (w >> 1) & 1, channels 64 (w & 1) ..+63); BM = 64: piece w & 3 = (plane, lane half), 64 channels.  It lands at byte
     // 1024 piece of the slot, i.e. the slot holds [plane][h][BM channels][4 pairs]
-    const int64_t stage_dw = (int64_t)16 * pa.CogP;                   // dwords per stage of the image
+    const int64_t stage_dw = (int64_t)NPL * 8 * pa.CogP;              // dwords per stage of the image
     const uint32_t* wbase = pa.wsplit + (int64_t)zg * nstages * stage_dw;
     const i32x4 rs_w = rsrc_words(reinterpret_cast<const float*>(wbase), nstages * stage_dw * 4);
-    const int piece = BM == 128 ? wave : wave & 3;
-    const uint32_t voff_a = BM == 128 ? (uint32_t)(((wave >> 1) * pa.CogP + i0 + (wave & 1) * 64 + lane) * 16)
-                                      : (uint32_t)((piece * pa.CogP + i0 + lane) * 16);
+    // a stage's image is NPL * 2 * (BM / 64) pieces of 1 KB; wave w takes piece w (mod the count: surplus waves re-fetch a piece,
+    // same bytes to the same place) and, with three planes of 128 channels (12 pieces), also piece 8 + (w & 3)
+    constexpr int NPIECE = NPL * 2 * (BM / 64);
+    int piece[NAF];
+    uint32_t voff_a[NAF];
+#pragma unroll
+    for (int e = 0; e < NAF; ++e) {
+        piece[e] = e == 0 ? wave % NPIECE : 8 + (wave & 3);
+        voff_a[e] = BM == 128 ? (uint32_t)(((piece[e] >> 1) * pa.CogP + i0 + (piece[e] & 1) * 64 + lane) * 16)
+                              : (uint32_t)((piece[e] * pa.CogP + i0 + lane) * 16);
+    }
     const int stage_bytes = (int)(stage_dw * 4);
     const i32x4 rs_x = rsrc_words(g.x + (int64_t)zg * g.grp_stride, (g.total - (int64_t)zg * g.grp_stride) * 4);
     // pixels 256 hf + 4 lane .. + 3 of the tile, in the padded-row enumeration
@@ -1308,25 +1332,25 @@ __global__ __launch_bounds__(512, 1) void conv_ring_kernel(const ConvRingParams 
         asm volatile("" : "+s"(tab0));
         asm volatile("" : "+s"(tab1));
     };
-    // fetch f of stage st into the ring slot at byte offset wr: 0 = the weight piece; 1 + NH r + hf = pixels 256 hf ..+255 of
-    // im2col row 2w + r.
+    // fetch f of stage st into the ring slot at byte offset wr: f < NAF = a weight piece; NAF + NH r + hf = pixels 256 hf ..+255
+    // of im2col row 2w + r.
     // Reduction positions past K (tail of the last stage): the weight image holds zeros there and the im2col side fetches
     // zeros through the per-lane range check (an offset of OOB_OFF).
     auto dma = [&](const uint32_t wr, const int f, int st) __attribute__((always_inline)) {
-        if (f == 0) {
-            lds_dma_row4(rs_w, lds0 + wr + (uint32_t)piece * 1024u, voff_a, st * stage_bytes);
+        if (f < NAF) {
+            lds_dma_row4(rs_w, lds0 + wr + (uint32_t)piece[f] * 1024u, voff_a[f], st * stage_bytes);
         } else {
-            const int r = (f - 1) / NH, hf = (f - 1) % NH;
+            const int r = (f - NAF) / NH, hf = (f - NAF) % NH;
             const bool live = st * SR + wrow + r < g.K;
             lds_dma_row4(rs_x, lds0 + wr + (uint32_t)(ABUF + (wrow + r) * BN + 256 * hf) * 4u, live ? voff_b[hf] : OOB_OFF,
                          r == 0 ? tab0 : tab1);
         }
     };
     auto dma_fast = [&](const uint32_t wr, const int f, int st) __attribute__((always_inline)) {   // every position of the stage lies below K
-        if (f == 0) {
-            lds_dma_row4(rs_w, lds0 + wr + (uint32_t)piece * 1024u, voff_a, st * stage_bytes);
+        if (f < NAF) {
+            lds_dma_row4(rs_w, lds0 + wr + (uint32_t)piece[f] * 1024u, voff_a[f], st * stage_bytes);
         } else {
-            const int r = (f - 1) / NH, hf = (f - 1) % NH;
+            const int r = (f - NAF) / NH, hf = (f - NAF) % NH;
             lds_dma_row4(rs_x, lds0 + wr + (uint32_t)(ABUF + (wrow + r) * BN + 256 * hf) * 4u, voff_b[hf], r == 0 ? tab0 : tab1);
         }
     };
@@ -1357,8 +1381,8 @@ __global__ __launch_bounds__(512, 1) void conv_ring_kernel(const ConvRingParams 
     auto load_a = [&](int rd, SplitBf16 (&A)[TA]) __attribute__((always_inline)) {       // the weight operands come split: no VALU
 #pragma unroll
         for (int a = 0; a < TA; ++a) {
-            A[a].hi = *reinterpret_cast<const i32x4*>(fa + rd + a * 32 * 4);
-            if constexpr (NP == 3) A[a].lo = *reinterpret_cast<const i32x4*>(fa + rd + 2 * BM * 4 + a * 32 * 4);
+#pragma unroll
+            for (int k = 0; k < NPC; ++k) A[a].p[k] = *reinterpret_cast<const i32x4*>(fa + rd + k * 2 * BM * 4 + a * 32 * 4);
         }
     };
     auto split = [&](const Raw& r, SplitBf16 (&B)[TB]) __attribute__((always_inline)) {
@@ -1366,10 +1390,10 @@ __global__ __launch_bounds__(512, 1) void conv_ring_kernel(const ConvRingParams 
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int b = 0; b < TB; ++b) {
-                int hi, lo = 0;
-                split_pair<NP == 3>(r.b[b][2 * j], r.b[b][2 * j + 1], hi, lo);
-                B[b].hi[j] = hi;
-                B[b].lo[j] = lo;
+                int pc[3] = {0, 0, 0};
+                split_pieces<NPC>(r.b[b][2 * j], r.b[b][2 * j + 1], pc);
+#pragma unroll
+                for (int k = 0; k < NPC; ++k) B[b].p[k][j] = pc[k];
             }
     };
 
@@ -1413,7 +1437,7 @@ __global__ __launch_bounds__(512, 1) void conv_ring_kernel(const ConvRingParams 
             constexpr int m = decltype(MI)::value;
             if constexpr (m < NM) {
                 constexpr int prod = m / (TA * TB), a = (m % (TA * TB)) / TB, b = m % TB;
-                acc[a][b] = mfma_bf16(prod == 2 ? Ac[a].lo : Ac[a].hi, prod == 1 ? Bc[b].lo : Bc[b].hi, acc[a][b]);
+                acc[a][b] = mfma_bf16(Ac[a].p[kProdA[prod]], Bc[b].p[kProdB[prod]], acc[a][b]);
             }
             if constexpr (m < FW) {                                   // one fetch in the shadow of each of the first FW MFMAs
                 if (fast) dma_fast(wr, m, st + D);
@@ -1503,7 +1527,8 @@ __global__ __launch_bounds__(256, 2) void conv_ring4_kernel(const ConvRingParams
     constexpr int ABUF = SR * BM, BUF = SR * (BM + BN);               // dwords
     constexpr int TA = 4, TB = 2, WPX = 64;
     constexpr int FW = 6;                                             // fetches per wave per stage: 2 weight pieces, im2col rows 4w .. 4w + 3
-    constexpr int NP = MATH == 3 ? 3 : 1;
+    constexpr int NP = split_products(MATH), NPC = split_pieces_of(MATH);
+    static_assert(NPC <= 2, "the two-workgroup form has LDS for two weight planes");
     constexpr int NM = TA * TB * NP;
     static_assert(SR == KBLK, "one stage = one block of the reduction order");
     extern __shared__ __attribute__((aligned(16))) float ldsq[];
@@ -1575,8 +1600,8 @@ __global__ __launch_bounds__(256, 2) void conv_ring4_kernel(const ConvRingParams
     auto load_ops = [&](int rd, SplitBf16 (&A)[TA], float (&rb)[TB][8]) __attribute__((always_inline)) {
 #pragma unroll
         for (int a = 0; a < TA; ++a) {
-            A[a].hi = *reinterpret_cast<const i32x4*>(fa + rd + a * 32 * 4);
-            if constexpr (NP == 3) A[a].lo = *reinterpret_cast<const i32x4*>(fa + rd + 2 * BM * 4 + a * 32 * 4);
+#pragma unroll
+            for (int k = 0; k < NPC; ++k) A[a].p[k] = *reinterpret_cast<const i32x4*>(fa + rd + k * 2 * BM * 4 + a * 32 * 4);
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j)
@@ -1588,10 +1613,10 @@ __global__ __launch_bounds__(256, 2) void conv_ring4_kernel(const ConvRingParams
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int b = 0; b < TB; ++b) {
-                int hi, lo = 0;
-                split_pair<NP == 3>(rb[b][2 * j], rb[b][2 * j + 1], hi, lo);
-                B[b].hi[j] = hi;
-                B[b].lo[j] = lo;
+                int pc[3] = {0, 0, 0};
+                split_pieces<NPC>(rb[b][2 * j], rb[b][2 * j + 1], pc);
+#pragma unroll
+                for (int k = 0; k < NPC; ++k) B[b].p[k][j] = pc[k];
             }
     };
 
@@ -1629,7 +1654,7 @@ __global__ __launch_bounds__(256, 2) void conv_ring4_kernel(const ConvRingParams
         static_for<0, NM>([&](auto MI) __attribute__((always_inline)) {
             constexpr int m = decltype(MI)::value;
             constexpr int prod = m / (TA * TB), a = (m % (TA * TB)) / TB, b = m % TB;
-            acc[a][b] = mfma_bf16(prod == 2 ? Ac[a].lo : Ac[a].hi, prod == 1 ? Bc[b].lo : Bc[b].hi, acc[a][b]);
+            acc[a][b] = mfma_bf16(Ac[a].p[kProdA[prod]], Bc[b].p[kProdB[prod]], acc[a][b]);
             if constexpr (m < FW) {
                 if (fast || st + D < nstages) dma(wr, m, st + D, fast);
             }
@@ -1723,15 +1748,15 @@ static const bool kConvStaged = getenv("VL_CONV_STAGED") != nullptr;
 static const bool kGemmNoSplit = getenv("VL_GEMM_NOSPLIT") != nullptr;
 static const bool kRing8 = getenv("VL_CONV_RING8") != nullptr;      // bf16x3, 128-channel layers: the 8-wave conv_ring_kernel instead of conv_ring4_kernel
 
-// contraction arithmetic of the three conv kernels: 0 = fp32 MFMA (default, the parity path), 3 = bf16x3 split products,
-// 1 = plain bf16 products (heads only) (vl_set_conv_math; VL_CONV_MATH=bf16x3 | bf16 presets it)
+// contraction arithmetic of the three conv kernels: 0 = fp32 MFMA (default, the parity path), 3 = bf16x3 and 6 = bf16x6 split
+// products, 1 = plain bf16 products (heads only) (vl_set_conv_math; VL_CONV_MATH=bf16x3 | bf16x6 | bf16 presets it)
 static int g_conv_math = [] {
     const char* e = getenv("VL_CONV_MATH");
-    return e == nullptr ? 0 : strcmp(e, "bf16x3") == 0 ? 3 : strcmp(e, "bf16") == 0 ? 1 : 0;
+    return e == nullptr ? 0 : strcmp(e, "bf16x3") == 0 ? 3 : strcmp(e, "bf16x6") == 0 ? 6 : strcmp(e, "bf16") == 0 ? 1 : 0;
 }();
 
 extern "C" int vl_set_conv_math(int math) {
-    VL_CHECK(math == 0 || math == 1 || math == 3, "vl_set_conv_math: 0 (fp32), 1 (bf16) or 3 (bf16x3)");
+    VL_CHECK(math == 0 || math == 1 || math == 3 || math == 6, "vl_set_conv_math: 0 (fp32), 1 (bf16), 3 (bf16x3) or 6 (bf16x6)");
     g_conv_math = math;
     return 0;
 }
@@ -1887,9 +1912,9 @@ extern "C" int vl_conv_create(vl_conv_desc** out, int cin, int h, int w, int cou
     d->cog = cout / groups;
     d->K = kh * kw * d->cig;
     d->Kd = kh * kw * d->cog;
-    // weight images of the split-product kernels: [groups][ceil(K / 16)][16][channels rounded up to 128] dwords each
-    const size_t sf = (size_t)groups * ceil_div(d->K, KBLK) * 16 * (ceil_div(d->cog, 128) * 128) * 4;
-    const size_t sb = (size_t)groups * ceil_div(d->Kd, KBLK) * 16 * (ceil_div(d->cig, 128) * 128) * 4;
+    // weight images of the split-product kernels: [groups][ceil(K / 16)][8 x planes][channels rounded up to 128] dwords each
+    const size_t sf = (size_t)groups * ceil_div(d->K, KBLK) * 24 * (ceil_div(d->cog, 128) * 128) * 4;     // up to three planes (bf16x6)
+    const size_t sb = (size_t)groups * ceil_div(d->Kd, KBLK) * 24 * (ceil_div(d->cig, 128) * 128) * 4;
     if (rebuild_tables(d) || hipMalloc((void**)&d->wsplit_fwd, sf) != hipSuccess || hipMalloc((void**)&d->wsplit_bwd, sb) != hipSuccess) {
         vl_conv_destroy(d);
         vl_set_error("vl_conv_create: device table allocation failed");
@@ -2198,10 +2223,10 @@ template <int BM>
 static int launch_conv_ring(const ConvGeom& g, const float* w, int64_t w_ld, int w_grp_stride, const int* row_tab, int Cog,
                             int Cout_total, const ConvOut& o, uint32_t* wsplit, hipStream_t s) {
     constexpr int BN = BM == 128 ? 256 : 512;
-    constexpr size_t lds = (size_t)(BM == 128 ? 5 : 4) * 16 * (BM + BN) * sizeof(float);       // 120 / 144 KB: one workgroup per CU
+    const int math = g_conv_math, planes = math == 6 ? 3 : 2;
     const int groups = Cout_total / Cog, nstages = ceil_div(g.K, KBLK), CogP = ceil_div(Cog, BM) * BM;
     hipLaunchKernelGGL(conv_wsplit_kernel, dim3(nstages, groups), dim3(256), 0, s, w, w_ld, (int64_t)w_grp_stride, row_tab, g.K, Cog,
-                       CogP, nstages, wsplit);
+                       CogP, nstages, planes, wsplit);
     VL_LAUNCH_CHECK();
     ConvRingParams pa{wsplit, CogP, nstages};
     EpiConvNCHW::Params pe;
@@ -2213,10 +2238,10 @@ static int launch_conv_ring(const ConvGeom& g, const float* w, int64_t w_ld, int
     const int OH = g.OHW / g.OW, OWp = (g.OW + 3) / 4 * 4, Mp = g.M / g.OW * OWp;
     const int tiles_i = ceil_div(Cog, BM), tiles_j = ceil_div(Mp, BN);
     dim3 grid(tiles_i * tiles_j, (unsigned)groups, 1);
-    if (BM == 128 && !kRing8) {                                          // 4-wave workgroups, two per CU (VL_CONV_RING8=1: the 8-wave form)
+    if (BM == 128 && math != 6 && !kRing8) {                            // 4-wave workgroups, two per CU (VL_CONV_RING8=1: the 8-wave form)
         constexpr size_t lds4 = (size_t)3 * 16 * (128 + 256) * sizeof(float);    // 72 KB
         static bool attr4[2] = {false, false};
-        const int v4 = g_conv_math == 3;
+        const int v4 = math == 3;
         auto k4 = v4 ? conv_ring4_kernel<3> : conv_ring4_kernel<1>;
         if (!attr4[v4]) {
             VL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
@@ -2226,9 +2251,11 @@ static int launch_conv_ring(const ConvGeom& g, const float* w, int64_t w_ld, int
         VL_LAUNCH_CHECK();
         return 0;
     }
-    static bool attr_set[2] = {false, false};
-    const int v8 = g_conv_math == 3;
-    auto kern = v8 ? conv_ring_kernel<3, BM> : conv_ring_kernel<1, BM>;
+    // the 8-wave form, one workgroup per CU: ring slots x (weight planes + 16 im2col rows): 120 / 144 KB, bf16x6 140 / 152 KB
+    const size_t lds = (size_t)(BM == 128 ? 5 : 4) * (planes * 8 * BM + 16 * BN) * sizeof(float);
+    static bool attr_set[3] = {false, false, false};
+    const int v8 = math == 6 ? 2 : math == 3 ? 1 : 0;
+    auto kern = v8 == 2 ? conv_ring_kernel<6, BM> : v8 == 1 ? conv_ring_kernel<3, BM> : conv_ring_kernel<1, BM>;
     if (!attr_set[v8]) {
         VL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set[v8] = true;
@@ -2387,9 +2414,10 @@ static int launch_wgrad_dma(const vl_conv_desc* d, const ConvGeom& g, const floa
     EpiRowMajor::Params pe{splits > 1 ? ws : dw, d->cout, d->K, d->cog, nullptr, nullptr, 0, d->cog, splits > 1 ? slab : 0};
     const int tiles_i = ceil_div(d->K, C::BM), tiles_j = ceil_div(d->cog, BN);
     const int rtiles = ceil_div(g.M, C::BR);
-    static bool attr_set[3] = {false, false, false};
-    const int v = g_conv_math == 3 ? 2 : g_conv_math == 1 ? 1 : 0;
-    auto kern = v == 2 ? wgrad_dma_kernel<BN, WM, WN, 3> : v == 1 ? wgrad_dma_kernel<BN, WM, WN, 1> : wgrad_dma_kernel<BN, WM, WN, 0>;
+    static bool attr_set[4] = {false, false, false, false};
+    const int v = g_conv_math == 6 ? 3 : g_conv_math == 3 ? 2 : g_conv_math == 1 ? 1 : 0;
+    auto kern = v == 3 ? wgrad_dma_kernel<BN, WM, WN, 6> : v == 2 ? wgrad_dma_kernel<BN, WM, WN, 3>
+              : v == 1 ? wgrad_dma_kernel<BN, WM, WN, 1> : wgrad_dma_kernel<BN, WM, WN, 0>;
     if (!attr_set[v]) {
         VL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
         attr_set[v] = true;

@@ -49,7 +49,7 @@ class NetConfig:
     frame_fusion: Optional[Tuple[str, str]] = None   # classifier fc: (early|late, avg|last) (model.py:103-106,149-151)
     dropout_keep_prob: float = 0.0              # <= 0 disables (lstm.py:52)
     optimizer: str = "sgd"                      # defs.optim.{sgd, adam}
-    conv_math: str = "f32"                      # "f32" | "bf16x3" | "bf16" (ops.set_conv_math: opt-in bf16-MFMA conv products)
+    conv_math: str = "f32"                      # "f32" | "bf16x3" | "bf16x6" | "bf16" (ops.set_conv_math: opt-in bf16-MFMA conv products)
 
     def encode_dim(self):
         return FC_DIM if self.frame_encoding_layer in ("fc6", "fc7") else self.num_classes

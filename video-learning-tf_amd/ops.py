@@ -337,7 +337,7 @@ def fill(t, value):
     _ffi.call("vl_fill", _p(t), t.numel(), value, stream())
 
 
-CONV_MATH = {"f32": 0, "bf16": 1, "bf16x3": 3}
+CONV_MATH = {"f32": 0, "bf16": 1, "bf16x3": 3, "bf16x6": 6}
 
 
 def set_conv_math(name):
