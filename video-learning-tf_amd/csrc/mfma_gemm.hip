@@ -670,9 +670,10 @@ __device__ __forceinline__ void lds_dma_row(i32x4 rs, uint32_t lds_byte_addr, ui
                  : "m0");
 }
 
-// Helpers of the split-product ("bf16x3") convolution, conv_ring_kernel below: an fp32 operand x is split into a bf16 head
-// and a bf16 tail, x = hi + lo + O(2^-17 |x|), and a product is hi*hi + hi*lo + lo*hi on the bf16 matrix pipe (16x the fp32
-// MFMA rate) with fp32 accumulators.  Operands stay fp32 in HBM, so every other kernel is unchanged.
+// Helpers of the split-product convolutions (vl_set_conv_math; wgrad_dma_kernel's tile_split, conv_ring_kernel and
+// conv_ring4_kernel below): an fp32 operand x is split into bf16 pieces, x = p0 + p1 (+ p2) + O(2^-17 (2^-26) |x|), and a product
+// is the sum of the piece products above a threshold (kProdA / kProdB) on the bf16 matrix pipe (16x the fp32 MFMA rate) with
+// fp32 accumulators.  Operands stay fp32 in HBM, so every other kernel is unchanged.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -699,13 +700,6 @@ __device__ __forceinline__ void split_pieces(float x0, float x1, int (&out)[3]) 
         // (the subtraction is left to hipcc, which emits one v_pk_add_f32: two scalar v_sub_f32 measured 3-10 % slower)
         if (k + 1 < NPC) r = f32x2{r[0] - __uint_as_float(h << 16), r[1] - __uint_as_float(h & 0xffff0000u)};
     }
-}
-template <bool TAIL>
-__device__ __forceinline__ void split_pair(float x0, float x1, int& hi, int& lo) {
-    int o[3] = {0, 0, 0};
-    split_pieces<TAIL ? 2 : 1>(x0, x1, o);
-    hi = o[0];
-    if (TAIL) lo = o[1];
 }
 // products of a split contraction, in issue order: piece of the A operand x piece of the B operand.  The first NP entries are
 // the mode: NP = 1 plain bf16, 3 bf16x3 (drops tail*tail, ~2^-18), 6 bf16x6 (drops terms below ~2^-23: fp32 rounding level)
