@@ -38,11 +38,13 @@ def write_cfg(folder, name, data_path, phase, resume=None, epochs=2):
     return path
 
 
-@pytest.mark.parametrize("prefetch", ["2", "0"])
-def test_train_resume_validate(tmp_path, monkeypatch, prefetch):
+@pytest.mark.parametrize("prefetch,math", [("2", "f32"), ("0", "f32"), ("2", "bf16x3")])
+def test_train_resume_validate(tmp_path, monkeypatch, prefetch, math):
     """prefetch 2: batches read and uploaded ahead of the loop by the feeder's background thread (the default);
-    prefetch 0: the reference's synchronous feed.  Same checkpoints, logs, resume behaviour and validation results."""
+    prefetch 0: the reference's synchronous feed.  Same checkpoints, logs, resume behaviour and validation results.
+    math bf16x3: the whole workflow with the opt-in split-bf16 conv arithmetic (VLTF_CONV_MATH), same checks."""
     monkeypatch.setenv("VLTF_PREFETCH", prefetch)
+    monkeypatch.setenv("VLTF_CONV_MATH", math)
     from vltf_amd import run_task
     folder = str(tmp_path)
     train_path, _, _ = make_dataset(folder, "train.txt", shape=RAW, seed=1)
