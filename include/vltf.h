@@ -74,7 +74,8 @@ int vl_conv_set_halo(vl_conv_desc* d, int x_halo, int y_halo, int dy_halo, int d
  * for stride 1.  vl_conv_x_phase returns the phase count in force (1 = plain). */
 int vl_conv_set_x_phase_split(vl_conv_desc* d, int on);
 int vl_conv_x_phase(const vl_conv_desc* d);
-/* Arithmetic of the contraction in vl_conv_fwd / vl_conv_dgrad / vl_conv_wgrad (process-wide; the dense GEMMs stay fp32):
+/* Arithmetic of the contraction in vl_conv_fwd / vl_conv_dgrad / vl_conv_wgrad and, given the workspace of
+ * vl_gemm_split_ws_bytes, of the large vl_gemm products (process-wide):
  *   0  fp32 MFMA (default; the reference's arithmetic, alexnet.py:21 tf.nn.conv2d on float32)
  *   3  "bf16x3": each fp32 operand is split into a bf16 head and tail (x = hi + lo + O(2^-17 |x|)) and a product is
  *      hi*hi + hi*lo + lo*hi on the bf16 matrix pipe with fp32 accumulation -- results agree with mode 0 to ~5e-6
@@ -154,6 +155,9 @@ int vl_maxpool_bwd(const float* dy, const uint8_t* argmax, float* dx, const floa
 int vl_gemm(int transa, int transb, int m, int n, int k, const float* a, int64_t lda, const float* b, int64_t ldb,
             float* c, int64_t ldc, const float* bias, int relu, const float* relu_mask, void* ws, size_t ws_bytes,
             vl_stream_t stream);
+/* Workspace (bytes) with which vl_gemm runs an m x n x k product in the split-bf16 arithmetic selected by vl_set_conv_math
+ * (operand images + split-K slabs); with a smaller workspace, or in mode 0, vl_gemm is the fp32 MFMA kernel. */
+size_t vl_gemm_split_ws_bytes(int m, int n, int k);
 /* out[n] = sum_m a[m][n] (bias gradients of fc layers); ws: float[64*n]. */
 int vl_colsum(const float* a, int64_t lda, float* out, float* ws, int m, int n, vl_stream_t stream);
 

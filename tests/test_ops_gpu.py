@@ -44,6 +44,14 @@ def close(got, want, rtol=3e-5, atol_rel=3e-5, msg=""):
 
 
 # ---- GEMM ------------------------------------------------------------------------------------------
+@pytest.fixture
+def conv_math(ops, request):
+    ops.set_conv_math(request.param)
+    assert ops.conv_math() == request.param
+    yield request.param
+    ops.set_conv_math("f32")
+
+
 @pytest.mark.parametrize("ta", [False, True])
 @pytest.mark.parametrize("tb", [False, True])
 @pytest.mark.parametrize("m,n,k", [(70, 150, 37), (130, 260, 100), (8, 1024, 256), (256, 128, 512), (1, 5, 3)])
@@ -61,6 +69,42 @@ def test_gemm(ops, ta, tb, m, n, k):
     ops.gemm(ad, bd, c, m, n, k, transa=ta, transb=tb, bias=dev(bias), relu=True, relu_mask=dev(mask))
     want = np.maximum(a.astype(np.float64) @ b + bias, 0) * (mask > 0)
     close(host(c), want)
+
+
+@pytest.mark.parametrize("conv_math", ["bf16x3", "bf16x6", "bf16"], indirect=True)
+@pytest.mark.parametrize("ta,tb", [(False, False), (True, False), (False, True), (True, True)])
+@pytest.mark.parametrize("m,n,k", [(130, 300, 200), (256, 512, 4096), (1024, 384, 130)])
+def test_gemm_split_products(ops, conv_math, ta, tb, m, n, k):
+    """vl_gemm under vl_set_conv_math with the workspace of vl_gemm_split_ws_bytes: both operands pre-split into images, the
+    MFMA loop VALU-free.  Ragged m / n / k (zero-padded images), split-K (the 256 x 512 x 4096 case), leading dimensions,
+    bias + ReLU + mask.  bf16x3 / bf16x6 at the fp32 tolerance, plain bf16 at 1e-2 relative L2."""
+    rng = np.random.default_rng(m + n + k)
+    a = rng.standard_normal((m, k)).astype(np.float32)
+    b = rng.standard_normal((k, n)).astype(np.float32)
+    bias = rng.standard_normal(n).astype(np.float32)
+    mask = rng.standard_normal((m, n)).astype(np.float32)
+    ap = np.pad(a.T if ta else a, ((0, 0), (0, 3)))              # lda / ldb / ldc larger than the row
+    bp = np.pad(b.T if tb else b, ((0, 0), (0, 5)))
+    ws = torch.empty(ops.gemm_split_ws_bytes(m, n, k) // 4 + 1, device=DEV)
+    c = torch.zeros((m, n + 2), device=DEV)
+    ops.gemm(dev(ap), dev(bp), c, m, n, k, transa=ta, transb=tb, lda=ap.shape[1], ldb=bp.shape[1], ldc=n + 2, ws=ws)
+    want = a.astype(np.float64) @ b
+    got = host(c)
+    err = np.linalg.norm(got[:, :n] - want) / np.linalg.norm(want)
+    if conv_math == "bf16":
+        assert 1e-4 < err < 1e-2, err
+    else:
+        close(got[:, :n], want)
+        assert err < 2e-5
+    assert np.all(got[:, n:] == 0)
+    ops.gemm(dev(ap), dev(bp), c, m, n, k, transa=ta, transb=tb, lda=ap.shape[1], ldb=bp.shape[1], ldc=n + 2, bias=dev(bias), relu=True,
+             relu_mask=dev(np.pad(mask, ((0, 0), (0, 2)))), ws=ws)
+    want2 = np.maximum(want + bias, 0) * (mask > 0)
+    got2 = host(c)[:, :n]
+    if conv_math == "bf16":
+        assert np.linalg.norm(got2 - want2) / np.linalg.norm(want2) < 1e-2
+    else:
+        close(got2, want2)
 
 
 def test_gemm_ld_and_splitk(ops):
@@ -101,14 +145,6 @@ def pad_nchw(a_nchw, halo):
 
 def interior(t, halo):
     return t if halo == 0 else t[:, :, halo:-halo, halo:-halo]
-
-
-@pytest.fixture
-def conv_math(ops, request):
-    ops.set_conv_math(request.param)
-    assert ops.conv_math() == request.param
-    yield request.param
-    ops.set_conv_math("f32")
 
 
 @pytest.mark.parametrize("conv_math,padded", [("f32", False), ("f32", True), ("bf16x3", True), ("bf16x6", True)], indirect=["conv_math"])

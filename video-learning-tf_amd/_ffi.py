@@ -25,6 +25,7 @@ SIGNATURES = {
     "vl_conv_x_phase": (i32, [p]),
     "vl_set_conv_math": (i32, [i32]),
     "vl_conv_math": (i32, []),
+    "vl_gemm_split_ws_bytes": (C.c_size_t, [i32, i32, i32]),
     "vl_conv_fwd": (i32, [p, p, p, p, p, i32, i32, p]),
     "vl_conv_wt_transpose": (i32, [p, p, p, p]),
     "vl_conv_dgrad": (i32, [p, p, p, p, p, i32, p]),

@@ -2538,6 +2538,249 @@ static int dispatch_gemm_t(int ta, int tb, int m, int n, int k, const float* a, 
     return launch_gemm<BM, WM, WN, DenseKX<BM, BR>, DenseXK<BN, BR>>(m, n, k, a, lda, b, ldb, c, ldc, bias, relu, mask, ws, splits, s);
 }
 
+// ---- dense GEMM in split-bf16 products (vl_set_conv_math 3 / 6 / 1) -------------------------------------------------------
+// Both operands are dense, so both are split ONCE into the image conv_wsplit_kernel makes of conv weights --
+// [stage of 16 k][piece plane][lane half h][row or column][4 bf16 pairs], k = 16 stage + 8 h + 2 q + e -- and the GEMM kernel
+// is conv_ring4_kernel without any VALU in its loop: linear 16-byte LDS-DMA of 1 KB pieces, ds_read_b128 straight into MFMA
+// operand tuples, 128 x 256 tiles, 4 waves of 128 x 64, three slots of 24 KB (36 KB with three planes: then one workgroup
+// per CU), two workgroups per CU, split-K over the stage range when the tiles alone do not fill the chip.
+// X(k, r) = base[k * sk + r * sr]; one of sk, sr is 1.  Rows r >= R and positions k >= K are zero.
+__global__ void gemm_split_image_kernel(const float* __restrict__ x, int64_t sk, int64_t sr, int K, int R, int Rp, int planes,
+                                        uint32_t* __restrict__ out) {
+    const int st = blockIdx.y;
+    uint32_t* o = out + (int64_t)st * planes * 8 * Rp;
+    const int r0 = blockIdx.x * 64;
+    if (sk == 1) {
+        // k is the contiguous axis: thread = (row, group of 4 consecutive k) reads 16 B
+        const int rr = threadIdx.x >> 2, kq = threadIdx.x & 3, r = r0 + rr, k0 = st * 16 + 4 * kq;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (r < R) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (k0 + e < K) v[e] = x[(int64_t)r * sr + k0 + e];
+        }
+        const int h = kq >> 1;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            int pc[3] = {0, 0, 0};
+            split_pieces<3>(v[2 * e], v[2 * e + 1], pc);
+            const int q = (kq & 1) * 2 + e;
+            for (int pl = 0; pl < planes; ++pl) o[(int64_t)((2 * pl + h) * Rp + r) * 4 + q] = (uint32_t)pc[pl];
+        }
+    } else {
+        // r is the contiguous axis: thread = (pair index, row): neighbouring threads read neighbouring rows
+        for (int idx = threadIdx.x; idx < 8 * 64; idx += blockDim.x) {
+            const int rr = idx & 63, hq = idx >> 6, h = hq >> 2, q = hq & 3, r = r0 + rr, k = st * 16 + 8 * h + 2 * q;
+            float x0 = 0.f, x1 = 0.f;
+            if (r < R) {
+                if (k < K) x0 = x[(int64_t)k * sk + r];
+                if (k + 1 < K) x1 = x[(int64_t)(k + 1) * sk + r];
+            }
+            int pc[3] = {0, 0, 0};
+            split_pieces<3>(x0, x1, pc);
+            for (int pl = 0; pl < planes; ++pl) o[(int64_t)((2 * pl + h) * Rp + r) * 4 + q] = (uint32_t)pc[pl];
+        }
+    }
+}
+
+struct GemmSplitParams {
+    const uint32_t* ia;      // image of opA: rows = m (tile 128), pitch Mp
+    const uint32_t* ib;      // image of opB: columns = n (tile 256), pitch Np
+    int Mp, Np, nstages, stages_per_split;
+    float* c;                // output (splits == 1) or slabs [split][m][n]
+    int64_t ldc, slab_stride;
+    const float* bias;
+    const float* mask;
+    int relu, m, n, splits;
+};
+
+template <int MATH>
+__global__ __launch_bounds__(256, MATH == 6 ? 1 : 2) void gemm_split_kernel(const GemmSplitParams P) {
+    constexpr int BM = 128, BN = 256, NBUF = 3, D = 3, TA = 4, TB = 2;
+    constexpr int NP = split_products(MATH), NPC = split_pieces_of(MATH), NPL = MATH == 6 ? 3 : 2;
+    constexpr int APC = NPL * 2 * 2, BPC = NPL * 2 * 4;               // 1 KB pieces of a stage: A (2 per plane and half), B (4)
+    constexpr int ABUF = APC * 256, BUF = (APC + BPC) * 256;          // dwords
+    constexpr int FA = APC / 4, FB = BPC / 4, FW = FA + FB;           // pieces per wave per stage
+    constexpr int NM = TA * TB * NP;
+    static_assert(NM >= FW, "a fetch rides on each of the first FW MFMAs");
+    extern __shared__ __attribute__((aligned(16))) float ldsg[];
+    const int tiles_i = P.Mp / BM;
+    const int bid = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int i0 = (bid % tiles_i) * BM, j0 = (bid / tiles_i) * BN;
+    const int zs = blockIdx.z;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int s_begin = zs * P.stages_per_split;
+    const int nst = min(P.nstages, s_begin + P.stages_per_split) - s_begin;      // stages of this split (>= 1 by construction)
+
+    const int64_t sdw_a = (int64_t)NPL * 8 * P.Mp, sdw_b = (int64_t)NPL * 8 * P.Np;
+    const i32x4 rs_a = rsrc_words(reinterpret_cast<const float*>(P.ia), P.nstages * sdw_a * 4);
+    const i32x4 rs_b = rsrc_words(reinterpret_cast<const float*>(P.ib), P.nstages * sdw_b * 4);
+    // piece p of A = (plane-and-half p >> 1, rows 64 (p & 1) ..+63), of B = (p >> 2, columns 64 (p & 3) ..+63); lands at byte 1024 p
+    uint32_t voff[FW];
+#pragma unroll
+    for (int f = 0; f < FA; ++f) {
+        const int p = wave * FA + f;
+        voff[f] = (uint32_t)(((p >> 1) * P.Mp + i0 + (p & 1) * 64 + lane) * 16);
+    }
+#pragma unroll
+    for (int f = 0; f < FB; ++f) {
+        const int p = wave * FB + f;
+        voff[FA + f] = (uint32_t)(((p >> 2) * P.Np + j0 + (p & 3) * 64 + lane) * 16);
+    }
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)ldsg;
+    const int sb_a = (int)(sdw_a * 4), sb_b = (int)(sdw_b * 4);
+    auto dma = [&](const uint32_t wr, const int f, int st) __attribute__((always_inline)) {        // st: absolute stage
+        if (f < FA) lds_dma_row4(rs_a, lds0 + wr + (uint32_t)(wave * FA + f) * 1024u, voff[f], st * sb_a);
+        else lds_dma_row4(rs_b, lds0 + wr + (uint32_t)(ABUF * 4 + (wave * FB + f - FA) * 1024), voff[f], st * sb_b);
+    };
+
+    f32x16 acc[TA][TB];
+#pragma unroll
+    for (int a = 0; a < TA; ++a)
+#pragma unroll
+        for (int b = 0; b < TB; ++b)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
+
+    const float* fa = ldsg + ((lane >> 5) * BM + (lane & 31)) * 4;
+    const float* fb = ldsg + ABUF + ((lane >> 5) * BN + wave * 64 + (lane & 31)) * 4;
+    auto load_ops = [&](int rd, SplitBf16 (&A)[TA], SplitBf16 (&B)[TB]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < NPC; ++k) {
+#pragma unroll
+            for (int a = 0; a < TA; ++a) A[a].p[k] = *reinterpret_cast<const i32x4*>(fa + rd + k * 2 * BM * 4 + a * 32 * 4);
+#pragma unroll
+            for (int b = 0; b < TB; ++b) B[b].p[k] = *reinterpret_cast<const i32x4*>(fb + rd + k * 2 * BN * 4 + b * 32 * 4);
+        }
+    };
+
+    // prologue: stages 0, 1, 2 (of this split) in flight; stage 0 -> registers; stage 1 landed
+    for (int s0 = 0; s0 < NBUF; ++s0) {
+        if (s0 < nst) {
+#pragma unroll
+            for (int f = 0; f < FW; ++f) dma((uint32_t)(s0 * BUF * 4), f, s_begin + s0);
+        }
+    }
+    if (nst >= NBUF) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * FW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    SplitBf16 A[TA] = {}, B[TB] = {}, An[TA] = {}, Bn[TB] = {};
+    load_ops(0, A, B);
+    if (nst >= NBUF) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(FW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    int rd = BUF;
+    uint32_t wr = 0;
+    auto stage = [&](int st, SplitBf16 (&Ac)[TA], SplitBf16 (&Bc)[TB], SplitBf16 (&An)[TA], SplitBf16 (&Bn)[TB])
+                     __attribute__((always_inline)) {
+        load_ops(rd, An, Bn);                                         // stage st + 1 (garbage past the end: never multiplied)
+        static_for<0, NM>([&](auto MI) __attribute__((always_inline)) {
+            constexpr int m = decltype(MI)::value;
+            constexpr int prod = m / (TA * TB), a = (m % (TA * TB)) / TB, b = m % TB;
+            acc[a][b] = mfma_bf16(Ac[a].p[kProdA[prod]], Bc[b].p[kProdB[prod]], acc[a][b]);
+            if constexpr (m < FW) {
+                if (st + D < nst) dma(wr, m, s_begin + st + D);
+            }
+            __builtin_amdgcn_sched_barrier(0x106);
+        });
+        rd = rd + BUF == NBUF * BUF ? 0 : rd + BUF;
+        wr = wr + BUF * 4 == NBUF * BUF * 4 ? 0u : wr + BUF * 4;
+        // groups issued so far end with stage min(st + D, nst - 1); stage st + 2 must have landed
+        if (min(st + D, nst - 1) - (st + 2) >= 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(FW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+    for (int st = 0; st < nst; st += 2) {
+        stage(st, A, B, An, Bn);
+        if (st + 1 < nst) stage(st + 1, An, Bn, A, B);
+    }
+
+    // epilogue: row 32 a + i of the tile, i = (q & 3) + 8 (q >> 2) + 4 (l >> 5); column 64 wave + 32 b + (l & 31)
+    float* out = P.c + (P.splits > 1 ? (int64_t)zs * P.slab_stride : 0);
+    const int64_t ld = P.splits > 1 ? P.n : P.ldc;
+#pragma unroll
+    for (int b = 0; b < TB; ++b) {
+        const int col = j0 + wave * 64 + 32 * b + (lane & 31);
+        if (col >= P.n) continue;
+        const float bv = (P.splits == 1 && P.bias) ? P.bias[col] : 0.f;
+#pragma unroll
+        for (int a = 0; a < TA; ++a) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int row = i0 + 32 * a + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+                if (row < P.m) {
+                    float v = acc[a][b][q] + bv;
+                    if (P.splits == 1) {
+                        if (P.relu) v = fmaxf(v, 0.f);
+                        if (P.mask) v = P.mask[(int64_t)row * P.ldc + col] > 0.f ? v : 0.f;
+                    }
+                    out[(int64_t)row * ld + col] = v;
+                }
+            }
+        }
+    }
+}
+
+// split-K of the split-product GEMM: as many splits as it takes to fill `slots` workgroup slots, each at least 8 stages deep
+static int gemm_split_splits(int m, int n, int k, int slots) {
+    const int nstages = ceil_div(k, 16), tiles = ceil_div(m, 128) * ceil_div(n, 256);
+    int splits = 1;
+    if (tiles < slots) {
+        splits = ceil_div(slots, tiles);
+        if (splits > 8) splits = 8;
+        if (splits > nstages / 8) splits = nstages / 8 > 0 ? nstages / 8 : 1;
+    }
+    const int sps = ceil_div(nstages, splits);
+    return ceil_div(nstages, sps);                                   // no empty split
+}
+
+// bytes of workspace the split-product GEMM needs in any mode: operand images of three planes + its split-K slabs
+extern "C" size_t vl_gemm_split_ws_bytes(int m, int n, int k) {
+    if (m <= 0 || n <= 0 || k <= 0) return 0;
+    const size_t st = (size_t)ceil_div(k, 16), mp = (size_t)ceil_div(m, 128) * 128, np = (size_t)ceil_div(n, 256) * 256;
+    const int splits = gemm_split_splits(m, n, k, 2 * device_cus());
+    return st * 24 * (mp + np) * 4 + (splits > 1 ? (size_t)splits * m * n * 4 : 0) + 4096;
+}
+
+static int launch_gemm_split(int transa, int transb, int m, int n, int k, const float* a, int64_t lda, const float* b, int64_t ldb,
+                             float* c, int64_t ldc, const float* bias, int relu, const float* relu_mask, void* ws, hipStream_t s) {
+    const int math = g_conv_math, planes = math == 6 ? 3 : 2;
+    const int nstages = ceil_div(k, 16), Mp = ceil_div(m, 128) * 128, Np = ceil_div(n, 256) * 256;
+    uint32_t* ia = (uint32_t*)ws;
+    uint32_t* ib = ia + (size_t)nstages * planes * 8 * Mp;
+    float* slabs = (float*)(ib + (size_t)nstages * planes * 8 * Np);
+    // X(k, r): opA rows = m, opB columns = n
+    hipLaunchKernelGGL(gemm_split_image_kernel, dim3(Mp / 64, nstages), dim3(256), 0, s, a, transa ? lda : (int64_t)1,
+                       transa ? (int64_t)1 : lda, k, m, Mp, planes, ia);
+    hipLaunchKernelGGL(gemm_split_image_kernel, dim3(Np / 64, nstages), dim3(256), 0, s, b, transb ? (int64_t)1 : ldb,
+                       transb ? ldb : (int64_t)1, k, n, Np, planes, ib);
+    VL_LAUNCH_CHECK();
+    const int tiles = (Mp / 128) * (Np / 256);
+    const int splits = gemm_split_splits(m, n, k, device_cus() * (math == 6 ? 1 : 2));
+    const int sps = ceil_div(nstages, splits);
+    GemmSplitParams P{ia, ib, Mp, Np, nstages, sps, splits > 1 ? slabs : c, ldc, (int64_t)m * n, bias, relu_mask, relu, m, n, splits};
+    const size_t lds = (size_t)3 * (planes * 2 * 2 + planes * 2 * 4) * 1024;      // 72 KB (108 KB with three planes)
+    static bool attr_set[3] = {false, false, false};
+    const int v = math == 6 ? 2 : math == 3 ? 1 : 0;
+    auto kern = v == 2 ? gemm_split_kernel<6> : v == 1 ? gemm_split_kernel<3> : gemm_split_kernel<1>;
+    if (!attr_set[v]) {
+        VL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set[v] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles, 1, splits), dim3(256), lds, s, P);
+    VL_LAUNCH_CHECK();
+    if (splits > 1) {
+        const int64_t count = (int64_t)m * n;
+        const int blocks = (int)((count + 255) / 256 < 4096 ? (count + 255) / 256 : 4096);
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, s, slabs, c, count, splits, count, bias, n, ldc, relu,
+                           relu_mask);
+        VL_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
 extern "C" int vl_gemm(int transa, int transb, int m, int n, int k, const float* a, int64_t lda, const float* b, int64_t ldb,
                        float* c, int64_t ldc, const float* bias, int relu, const float* relu_mask, void* ws, size_t ws_bytes,
                        vl_stream_t stream) {
@@ -2547,6 +2790,9 @@ extern "C" int vl_gemm(int transa, int transb, int m, int n, int k, const float*
     const int64_t ea = transa ? (int64_t)(k - 1) * lda + m : (int64_t)(m - 1) * lda + k;
     const int64_t eb = transb ? (int64_t)(n - 1) * ldb + k : (int64_t)(k - 1) * ldb + n;
     VL_CHECK(ea * 4 < MAX_BUF_BYTES && eb * 4 < MAX_BUF_BYTES, "vl_gemm: operand exceeds the buffer-offset range");
+    // split-bf16 products (vl_set_conv_math != 0) for the large GEMMs when the caller's workspace holds the operand images
+    if (g_conv_math != 0 && m >= 128 && n >= 128 && k >= 128 && ws && ws_bytes >= vl_gemm_split_ws_bytes(m, n, k))
+        return launch_gemm_split(transa, transb, m, n, k, a, lda, b, ldb, c, ldc, bias, relu, relu_mask, ws, (hipStream_t)stream);
     const int bm = m <= 64 ? 64 : 128;
     const int tiles = ceil_div(m, bm) * ceil_div(n, 128);
     // split the reduction when the output tiles alone leave fewer than ~3 workgroups per CU (this kernel hides its load and

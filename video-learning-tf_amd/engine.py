@@ -218,7 +218,10 @@ class LRCNEngine:
         self.f8 = buf(N, cfg.num_classes) if cfg.frame_encoding_layer not in ("fc6", "fc7") else None
         self.feat = self.f8 if self.f8 is not None else (self.f7 if self.f7 is not None else self.f6)
         D, C, H, B, T = cfg.encode_dim(), cfg.num_classes, cfg.lstm_hidden, self.B, self.T
-        self.ws = torch.empty(max(ws_bytes, 64 << 20) // 4, device=dev)       # wgrad slabs / split-K slabs
+        if cfg.conv_math != "f32":                                # operand images of the split-product GEMMs (fc6 is the largest)
+            for (gm, gn, gk) in ((N, FC_DIM, self.flat_dim), (N, self.flat_dim, FC_DIM), (self.flat_dim, FC_DIM, N), (N, 4 * H, D)):
+                ws_bytes = max(ws_bytes, ops.gemm_split_ws_bytes(gm, gn, gk))
+        self.ws = torch.empty(max(ws_bytes, 64 << 20) // 4, device=dev)       # wgrad slabs / split-K slabs / GEMM operand images
         self.small_ws = buf(64 * max(4 * H, FC_DIM, 1024, C))                     # colsum / bias / sumsq partials
         if training:
             self.wt = buf(max_w)

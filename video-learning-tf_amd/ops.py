@@ -248,6 +248,11 @@ def gemm(a, b, c, m, n, k, transa=False, transb=False, lda=None, ldb=None, ldc=N
               _p(relu_mask), _p(ws), nbytes, stream())
 
 
+def gemm_split_ws_bytes(m, n, k):
+    """Workspace with which gemm() runs in the split-bf16 arithmetic of set_conv_math (vl_gemm_split_ws_bytes)."""
+    return int(_ffi.lib().vl_gemm_split_ws_bytes(int(m), int(n), int(k)))
+
+
 def colsum(a, out, ws, m, n, lda=None):
     _f32(a, out, ws)
     if ws.numel() < 64 * n:
