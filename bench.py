@@ -29,6 +29,7 @@ CONV_MACS = {"conv1": 113221152, "conv2": 240844800, "conv3": 149520384, "conv4"
 CLIP_TRAIN_FLOP = 2 * 33357755136          # T = 16, fc6 encode
 CLIP_FWD_FLOP = 2 * 11723097856            # forward only
 PEAK_FP32_MFMA_TFLOPS = 157.3              # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0             # MI355X_MICROARCH.md: bf16 dense (v_mfma_f32_32x32x16_bf16); only used with --conv-math
 # launches that share the single-kernel symbol conv_dma_kernel<32> (output-channel tile 128, LDS-DMA operand rows:
 # conv2/3/5 forward and conv3 dgrad, whose output channel count is 256)
 DOMINANT = ("conv2.fwd", "conv3.fwd", "conv5.fwd", "conv3.dgrad")
@@ -109,6 +110,8 @@ def main():
     ap.add_argument("--cpu-clips", type=int, default=16)
     ap.add_argument("--dropout", type=float, default=0.0)
     ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the extra strong-scaling measurement")
+    ap.add_argument("--conv-math", default="f32", choices=["f32", "bf16x3", "bf16x6", "bf16"],
+                    help="arithmetic of the MAIN measurement (default f32 = the headline; anything else is labelled in `dtype`)")
     ap.add_argument("--no-split-math", action="store_true", help="N = 1: skip the extra bf16x3 (opt-in conv arithmetic) measurement")
     args = ap.parse_args()
 
@@ -132,7 +135,8 @@ def main():
         clips = hi - lo
     gar = dpmod.GradAllReduce() if world > 1 else None
     cfg = NetConfig(image_shape=(227, 227, 3), num_classes=args.classes, fpc=args.fpc, frame_encoding_layer="fc6",
-                    classifier="lstm", lstm_hidden=256, lstm_layers=1, fusion="avg", dropout_keep_prob=args.dropout)
+                    classifier="lstm", lstm_hidden=256, lstm_layers=1, fusion="avg", dropout_keep_prob=args.dropout,
+                    conv_math=args.conv_math)
     eng = LRCNEngine(cfg, max_clips=clips, device=dev, dp=gar)
     eng.load_params(init_params(cfg, seed=2))          # reference initialisers; same seed on every rank
     if gar is not None:
@@ -186,7 +190,7 @@ def main():
     # the same job timed the same way, reported BESIDE `value` (which stays the fp32 path), with its own loss / gradient norm
     # after the same number of steps from the same initial parameters as evidence of what the arithmetic changes.
     split, split6, plain = None, None, None
-    if world == 1 and not args.no_split_math:
+    if world == 1 and not args.no_split_math and args.conv_math == "f32":
         import dataclasses
 
         def side_run(math, first_of):
@@ -273,24 +277,31 @@ def main():
     alg_bytes = sum(4.0 * (DOMINANT_ELEMS_PER_FRAME[l] * n + DOMINANT_WEIGHT_ELEMS[l]) for l in DOMINANT) / len(DOMINANT)
     ms_per_step = elapsed / args.steps * 1e3
     value = total_clips * args.steps / elapsed
+    # --conv-math other than f32: the same launches run the split-product kernels; their bound is the bf16 matrix pipe at one
+    # MFMA per product (bf16x3: 3, bf16x6: 6), so the peak of an fp32-equivalent FLOP is the dense bf16 peak / products
+    f32_main = args.conv_math == "f32"
+    peak = PEAK_FP32_MFMA_TFLOPS if f32_main else PEAK_BF16_MFMA_TFLOPS / {"bf16x3": 3, "bf16x6": 6, "bf16": 1}[args.conv_math]
     rec = {
         "metric": "clips/sec (16-frame 227x227) LRCN train step", "value": round(value, 2), "unit": "clips/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-        "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+        "dtype": "f32" if args.conv_math == "f32" else "%s conv / GEMM products (opt-in, --conv-math), fp32 accumulate and elsewhere" % args.conv_math,
+        "data": "synthetic",
         "config": {"workload": "LRCN AlexNet(fc6)+LSTM(256) %d-frame 227x227x3 clips, %d classes, UCF-101-shaped synthetic, "
                                "full train step" % (args.fpc, args.classes),
                    "global_batch": total_clips, "clips_per_gpu": clips, "frames_per_clip": args.fpc,
                    "parallelism": "dp%d" % world, "optimizer": "sgd+clip_by_global_norm(10)", "init": "reference (sigma 0.05)"},
-        "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
-                     "traffic": traffic_rec["bytes_per_launch"] if (traffic_rec and n == 1024) else None,
+        "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                     "frac": round(achieved / peak, 4),
+                     "traffic": traffic_rec["bytes_per_launch"] if (traffic_rec and n == 1024 and f32_main) else None,
                      "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes)",
                      "traffic_source": traffic_src if n == 1024 else None,
                      "algorithmic_bytes_per_launch": alg_bytes,
-                     "kernel": DOMINANT_SYMBOL, "launches": list(DOMINANT),
+                     "kernel": DOMINANT_SYMBOL if f32_main else "conv_ring4_kernel / conv_ring_kernel (%s)" % args.conv_math,
+                     "launches": list(DOMINANT),
                      "flop_per_launch": dom_flop, "ms_per_launch": round(dom_ms, 4),
                      "conv_stack": {"tflops": round(stack_flop / (stack_ms * 1e-3) / 1e12, 2),
-                                    "frac": round(stack_flop / (stack_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                                    "frac": round(stack_flop / (stack_ms * 1e-3) / 1e12 / peak, 4),
                                     "ms_per_step": round(stack_ms, 3),
                                     "per_launch_ms": {k: round(v, 3) for k, v in sorted(avg.items())}},
                      "step_frac_of_mfma_roofline": round(value / world * CLIP_TRAIN_FLOP / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)
