@@ -670,6 +670,12 @@ __device__ __forceinline__ void lds_dma_row(i32x4 rs, uint32_t lds_byte_addr, ui
                  : "m0");
 }
 
+// 16 bytes per lane: lane l lands at M0 + 16 l (tools/ubench/lds_dma_x4.hip)
+__device__ __forceinline__ void lds_dma_row4(i32x4 rs, uint32_t lds_byte_addr, uint32_t voff, int soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_byte_addr), "v"(voff), "s"(rs), "s"(soff)
+                 : "m0");
+}
+
 // Helpers of the split-product convolutions (vl_set_conv_math; wgrad_dma_kernel's tile_split, conv_ring_kernel and
 // conv_ring4_kernel below): an fp32 operand x is split into bf16 pieces, x = p0 + p1 (+ p2) + O(2^-17 (2^-26) |x|), and a product
 // is the sum of the piece products above a threshold (kProdA / kProdB) on the bf16 matrix pipe (16x the fp32 MFMA rate) with
@@ -711,7 +717,13 @@ __device__ __forceinline__ f32x16 mfma_bf16(const i32x4& a, const i32x4& b, cons
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-template <int BN, int WM, int WN, int MATH = 0>   // MATH 3: split bf16 products (vl_set_conv_math), see tile_split
+// X4 (split-product modes, BN = 128, output rows a multiple of 4 pixels wide, unit column stride): 16-byte fetches.  One
+// instruction moves FOUR rows x 64 pixels: lane l = (row slot l >> 4, pixel quad l & 15), i.e. 4 x 256 contiguous bytes of source
+// (about ten cache lines: the texture path's cost follows the lines an instruction touches) landing as 1 KB of LDS.  The four rows
+// of an instruction are g, g + 32, g + 64, g + 96, and group g sits at float 258 g: an MFMA block's 32 lanes (rows g = 0..31 of one
+// slot) then read at a stride of 258 floats, two banks apart -- conflict-free for the float2 operand reads.  16 fetches per wave and
+// tile instead of 64 (the dword form is bound by its fetch instructions at bf16 rates).
+template <int BN, int WM, int WN, int MATH = 0, bool X4 = false>   // MATH != 0: split bf16 products (vl_set_conv_math), see tile_split
 __global__ __launch_bounds__(NT, 1) void wgrad_dma_kernel(const ConvGeom g, const DyParams d, const EpiRowMajor::Params pe,
                                                           int tiles_i, int tiles_j, int groups, int units, int rtiles,
                                                           int rt_per_split, float* db_slabs, int db_stride) {
@@ -721,6 +733,8 @@ __global__ __launch_bounds__(NT, 1) void wgrad_dma_kernel(const ConvGeom g, cons
     constexpr int RA = BM / 4, RB = BN / 4;               // rows each wave fetches per tile (A: 32, B: 32 | 24)
     static_assert(WM * WN == 4 && TM * WM * 32 == BM && TN * WN * 32 == BN, "tile shape");
     static_assert(RA + RB <= 10 * 2 * TM * TN, "row fetches must leave the last third of a tile's MFMAs to cover their latency");
+    static_assert(!X4 || (MATH != 0 && BN == 128 && BM == 128), "the 16-byte fetch form: split-product modes, 128 x 128 tiles");
+    constexpr int GSTR = 258, SA4 = 32 * GSTR, BUF4 = 64 * GSTR;     // X4: floats per row group, per operand region, per buffer
     extern __shared__ __attribute__((aligned(16))) float ldsw[];
 
     // Workgroup -> (unit = (group, split), tile) so that ALL tiles of a unit run on ONE XCD, back to back: workgroup ids are
@@ -752,7 +766,7 @@ __global__ __launch_bounds__(NT, 1) void wgrad_dma_kernel(const ConvGeom g, cons
 
     uint32_t voff_x, voff_dy;
     auto decode = [&](int rt) __attribute__((always_inline)) {                           // per-lane byte offsets of the tile's 64 pixels
-        const int m = rt * 64 + lane;
+        const int m = X4 ? rt * 64 + 4 * (lane & 15) : rt * 64 + lane;       // X4: lane (mod 16) = pixel quad, its first pixel
         const bool vm = m < g.M;
         const uint32_t mm = vm ? m : 0;
         const uint32_t n = fd_div(mm, g.dOHW);
@@ -795,11 +809,38 @@ __global__ __launch_bounds__(NT, 1) void wgrad_dma_kernel(const ConvGeom g, cons
             lds_dma_row(rs_dy, lb + (uint32_t)(nb * BUF + r * STR) * 4u, voff_dy, min(b_row0 + z + r, b_last) * row_bytes);
         }
     };
+    // X4: this wave fetches row groups 8 wave .. 8 wave + 7 of both operands; lane's row of group g is g + 32 (lane >> 4).  The row
+    // part of the address is fixed for the kernel: table entry of the im2col row (rows >= K: out of range -> zeros), plane of the
+    // dy channel (channels >= Cog likewise)
+    uint32_t vrow_a[8], vrow_b[8];
+    if constexpr (X4) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int rl = wave * 8 + j + 32 * (lane >> 4);
+            vrow_a[j] = i0 + rl < g.K ? (uint32_t)g.ktab[i0 + rl] : OOB_OFF;
+            vrow_b[j] = j0 + rl < d.Cog ? (uint32_t)(j0 + rl) * (uint32_t)row_bytes : OOB_OFF;
+        }
+    }
+    // X4 fetch f (0..15) of the next tile: f < 8 = im2col group 8 wave + f, else dy group 8 wave + f - 8
+    auto dma_x4 = [&](const int nb, const int f, int rt_next) __attribute__((always_inline)) {
+        const int z = rt_next * g.zero;
+        if (f < 8) {
+            const uint32_t vo = (vrow_a[f] == OOB_OFF || voff_x == OOB_OFF) ? OOB_OFF : vrow_a[f] + voff_x;
+            lds_dma_row4(rs_x, lds0 + (uint32_t)(nb * BUF4 + (wave * 8 + f) * GSTR + z) * 4u, vo, 0);
+        } else {
+            const uint32_t vo = (vrow_b[f - 8] == OOB_OFF || voff_dy == OOB_OFF) ? OOB_OFF : vrow_b[f - 8] + voff_dy;
+            lds_dma_row4(rs_dy, lds0 + (uint32_t)(nb * BUF4 + SA4 + (wave * 8 + f - 8) * GSTR + z) * 4u, vo, 0);
+        }
+    };
     // bias row: local row K - i0 of the LAST i-tile (uniform)
     const int ones_row = (db_slabs != nullptr && g.K >= i0 && g.K < i0 + BM) ? g.K - i0 : -1;
     auto finish_tile = [&](const int nb) __attribute__((always_inline)) {                // DMAs of buffer nb landed -> visible to every wave
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (ones_row >= 0 && (ones_row / RA) == wave) ldsw[nb * BUF + ones_row * STR + lane] = 1.0f;
+        if constexpr (X4) {         // row r lives in group r % 32 (fetched by wave (r % 32) / 8), slot r / 32
+            if (ones_row >= 0 && ((ones_row & 31) >> 3) == wave) ldsw[nb * BUF4 + (ones_row & 31) * GSTR + (ones_row >> 5) * 64 + lane] = 1.0f;
+        } else {
+            if (ones_row >= 0 && (ones_row / RA) == wave) ldsw[nb * BUF + ones_row * STR + lane] = 1.0f;
+        }
         __syncthreads();
     };
 
@@ -818,8 +859,13 @@ __global__ __launch_bounds__(NT, 1) void wgrad_dma_kernel(const ConvGeom g, cons
         decode(rt0);
         load_table(rt0);
         pin_table();
+        if constexpr (X4) {
 #pragma unroll
-        for (int f = 0; f < RA + RB; ++f) dma(0, f, rt0);
+            for (int f = 0; f < 16; ++f) dma_x4(0, f, rt0);
+        } else {
+#pragma unroll
+            for (int f = 0; f < RA + RB; ++f) dma(0, f, rt0);
+        }
         decode(rt0 + 1);
         finish_tile(0);
     }
@@ -882,7 +928,7 @@ __global__ __launch_bounds__(NT, 1) void wgrad_dma_kernel(const ConvGeom g, cons
     const float* fb3 = ldsw + SA + (wj0 + (lane & 31)) * STR + 8 * (lane >> 5);
     auto tile_split = [&](const int cur, int rt_next) __attribute__((always_inline)) {
         constexpr int NP = split_products(MATH), NPC = split_pieces_of(MATH);   // MATH 1: heads only (plain bf16 products)
-        constexpr int NMS = NP * TM * TN, NTOT = 4 * NMS, NF = RA + RB;
+        constexpr int NMS = NP * TM * TN, NTOT = 4 * NMS, NF = X4 ? 16 : RA + RB;
         constexpr int FSPAN = NTOT >= 28 ? NTOT - 14 : NTOT / 2;      // the fetches ride on the first FSPAN MFMAs of the tile
         constexpr int FPM = (NF + FSPAN - 1) / FSPAN, FEND = (NF + FPM - 1) / FPM;
         constexpr int LT = FEND > NTOT - 12 ? FEND : NTOT - 12;       // table of the tile after next: once the fetches are out
@@ -894,7 +940,10 @@ __global__ __launch_bounds__(NT, 1) void wgrad_dma_kernel(const ConvGeom g, cons
             for (int a = 0; a < TM; ++a)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float2 v = *reinterpret_cast<const float2*>(fa3 + cur * BUF + a * 32 * STR + 16 * st + 2 * q);
+                    // X4: row wi0 + 32 a + i = group i, slot (wi0 + 32 a) / 32
+                    const float2 v = X4 ? *reinterpret_cast<const float2*>(ldsw + cur * BUF4 + (lane & 31) * GSTR + (wi0 / 32 + a) * 64 + 16 * st +
+                                                                            8 * (lane >> 5) + 2 * q)
+                                        : *reinterpret_cast<const float2*>(fa3 + cur * BUF + a * 32 * STR + 16 * st + 2 * q);
                     int pc[3] = {0, 0, 0};
                     split_pieces<NPC>(v.x, v.y, pc);
 #pragma unroll
@@ -904,7 +953,9 @@ __global__ __launch_bounds__(NT, 1) void wgrad_dma_kernel(const ConvGeom g, cons
             for (int b = 0; b < TN; ++b)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float2 v = *reinterpret_cast<const float2*>(fb3 + cur * BUF + b * 32 * STR + 16 * st + 2 * q);
+                    const float2 v = X4 ? *reinterpret_cast<const float2*>(ldsw + cur * BUF4 + SA4 + (lane & 31) * GSTR + (wj0 / 32 + b) * 64 +
+                                                                            16 * st + 8 * (lane >> 5) + 2 * q)
+                                        : *reinterpret_cast<const float2*>(fb3 + cur * BUF + b * 32 * STR + 16 * st + 2 * q);
                     int pc[3] = {0, 0, 0};
                     split_pieces<NPC>(v.x, v.y, pc);
 #pragma unroll
@@ -922,7 +973,10 @@ __global__ __launch_bounds__(NT, 1) void wgrad_dma_kernel(const ConvGeom g, cons
                 constexpr int idx = st * NMS + m;
                 static_for<0, FPM>([&](auto EI) __attribute__((always_inline)) {
                     constexpr int f = idx * FPM + decltype(EI)::value;
-                    if constexpr (f < NF) dma(cur ^ 1, f, rt_next);
+                    if constexpr (f < NF) {
+                        if constexpr (X4) dma_x4(cur ^ 1, f, rt_next);
+                        else dma(cur ^ 1, f, rt_next);
+                    }
                 });
                 __builtin_amdgcn_sched_barrier(0x106);        // VALU / SALU / LDS reads may move across, MFMAs and fetches stay put
                 if constexpr (idx == LT) load_table(rt_next + 1);
@@ -1214,10 +1268,6 @@ __global__ __launch_bounds__(NT, 64 / SR) void conv_dma_kernel(const ConvDmaPara
 // streams into the slot stage st occupied.  The barrier at the end of stage st waits (vmcnt) only for stage st + 3.  Every
 // wave issues exactly FW fetches per stage, in stage order, so "all but the last (NBUF - 3) FW" means stage st + 3 has landed.
 // Reduction position p = 16 st + 8 h + 2 q + e of a stage belongs to lane half h, bf16 pair q, element e of the MFMA operand.
-__device__ __forceinline__ void lds_dma_row4(i32x4 rs, uint32_t lds_byte_addr, uint32_t voff, int soff) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_byte_addr), "v"(voff), "s"(rs), "s"(soff)
-                 : "m0");
-}
 
 // out[group][stage][plane < planes][h][co < CogP][q] = bf16 pair of weight rows row_tab[stage] + 8 h + 2 q, + 1 (zero past K / Cog);
 // plane 0 = heads, 1 = tails, 2 = what heads + tails leave over (bf16x6)
@@ -1740,6 +1790,7 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ ws, float* __restr
 // template instead of the LDS-DMA kernels, VL_GEMM_NOSPLIT=1 disables the split-K of small dense GEMMs.
 static const bool kConvStaged = getenv("VL_CONV_STAGED") != nullptr;
 static const bool kGemmNoSplit = getenv("VL_GEMM_NOSPLIT") != nullptr;
+static const bool kWgradDword = getenv("VL_WGRAD_DWORD") != nullptr;  // split-product wgrad: keep the dword fetches where 16-byte ones apply
 static const bool kRing8 = getenv("VL_CONV_RING8") != nullptr;      // bf16x3, 128-channel layers: the 8-wave conv_ring_kernel instead of conv_ring4_kernel
 
 // contraction arithmetic of the three conv kernels: 0 = fp32 MFMA (default, the parity path), 3 = bf16x3 and 6 = bf16x6 split
@@ -2408,10 +2459,17 @@ static int launch_wgrad_dma(const vl_conv_desc* d, const ConvGeom& g, const floa
     EpiRowMajor::Params pe{splits > 1 ? ws : dw, d->cout, d->K, d->cog, nullptr, nullptr, 0, d->cog, splits > 1 ? slab : 0};
     const int tiles_i = ceil_div(d->K, C::BM), tiles_j = ceil_div(d->cog, BN);
     const int rtiles = ceil_div(g.M, C::BR);
-    static bool attr_set[4] = {false, false, false, false};
-    const int v = g_conv_math == 6 ? 3 : g_conv_math == 3 ? 2 : g_conv_math == 1 ? 1 : 0;
+    static bool attr_set[8] = {false, false, false, false, false, false, false, false};
+    int v = g_conv_math == 6 ? 3 : g_conv_math == 3 ? 2 : g_conv_math == 1 ? 1 : 0;
     auto kern = v == 3 ? wgrad_dma_kernel<BN, WM, WN, 6> : v == 2 ? wgrad_dma_kernel<BN, WM, WN, 3>
               : v == 1 ? wgrad_dma_kernel<BN, WM, WN, 1> : wgrad_dma_kernel<BN, WM, WN, 0>;
+    if constexpr (BN == 128) {
+        // 16-byte fetches: four consecutive output pixels must be four consecutive floats of x and of dy, inside one image row
+        if (v != 0 && g.OW % 4 == 0 && g.col_mul == 1 && !kWgradDword) {
+            kern = v == 3 ? wgrad_dma_kernel<BN, WM, WN, 6, true> : v == 2 ? wgrad_dma_kernel<BN, WM, WN, 3, true> : wgrad_dma_kernel<BN, WM, WN, 1, true>;
+            v += 4;
+        }
+    }
     if (!attr_set[v]) {
         VL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
         attr_set[v] = true;
