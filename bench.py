@@ -5,11 +5,12 @@
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
 
-Workload (configs[1] of BASELINE.json): AlexNet encode at fc6 -> LSTM(256, 1 layer, avg) -> 101 classes,
-T = 16, 64 clips (= 1024 frames) per GPU per step, fp32.  Data parallel: every rank runs the reference's
-batch_size = 64 on its own clips (weak scaling: global batch 64*N), one RCCL all-reduce of the 178 MB
-gradient per step overlapped with the conv backward.  Inputs are resident in HBM before timing starts.
-Prints ONE JSON line on rank 0.
+Workload (configs[1] of BASELINE.json): AlexNet encode at fc6 -> LSTM(256, 1 layer, avg) -> 101 classes, T = 16, the
+reference's batch_size = 64 clips (= 1024 frames) per step, fp32, dropout keep 0.5.  N = 1: the whole batch on one
+GPU.  N > 1 (configs[2]): STRONG scaling -- the same global batch of 64 clips split over the ranks (8 clips per GPU at N = 8),
+RCCL all-reduce of the 178 MB gradient in chunks that overlap the backward pass; the weak-scaling form (64 clips on every rank,
+global batch 64*N) is timed in the same run and reported beside it (`weak_scaling`; `--weak` makes it the headline instead).
+Inputs are resident in HBM before timing starts.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -26,8 +27,17 @@ import torch
 
 # forward MACs per frame; dgrad and wgrad of a layer have the same count
 CONV_MACS = {"conv1": 113221152, "conv2": 240844800, "conv3": 149520384, "conv4": 112140288, "conv5": 74760192}
-CLIP_TRAIN_FLOP = 2 * 33357755136          # T = 16, fc6 encode
-CLIP_FWD_FLOP = 2 * 11723097856            # forward only
+FC6_MACS = 9216 * 4096                     # per frame
+LSTM_STEP_MACS = (4096 + 256) * 1024       # per clip and step (kernel [D+H, 4H])
+
+
+def clip_flops(fpc, classes=101):
+    """(forward, train) FLOP per clip (FLOP = 2 MAC; train = 3 x forward minus conv1's absent dgrad).
+    fpc = 16, 101 classes: 2 x 11,723,097,856 and 2 x 33,357,755,136."""
+    fwd = fpc * (sum(CONV_MACS.values()) + FC6_MACS + LSTM_STEP_MACS) + 256 * classes
+    return 2 * fwd, 2 * (3 * fwd - fpc * CONV_MACS["conv1"])
+
+
 PEAK_FP32_MFMA_TFLOPS = 157.3              # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0             # MI355X_MICROARCH.md: bf16 dense (v_mfma_f32_32x32x16_bf16); only used with --conv-math
 # launches that share the single-kernel symbol conv_dma_kernel<32> (output-channel tile 128, LDS-DMA operand rows:
@@ -97,22 +107,47 @@ def cpu_baseline(clips, fpc, num_classes):
                       "reference's TF op graph, %.1f s" % (steps, clips, fpc, dt)}
 
 
+def oracle_first_step(eng, frames, onehot, clips, fpc, classes):
+    """First step from init_params(seed=2) against the CPU oracle's committed answer for exactly these inputs
+    (tests/golden/lrcn_full.npz case cfg2_ref, made by tests/golden/make_golden_full.py; a data file, not the oracle).
+    Dropout is switched off for this one step (the oracle has no TF RNG) and the parameters are re-loaded afterwards."""
+    path = os.path.join(ROOT, "tests", "golden", "lrcn_full.npz")
+    if (clips, fpc, classes) != (64, 16, 101) or not os.path.exists(path):
+        return None
+    gold = np.load(path)
+    if "cfg2_ref/logits" not in gold.files:
+        return None
+    keep = eng.cfg.dropout_keep_prob
+    eng.cfg.dropout_keep_prob = 0.0
+    out = eng.train_step_u8(frames, onehot, lr=1e-3, clip_norm=10.0, mean_bgr=MEAN_BGR, fetch=True)
+    logits = eng.logits_host()
+    eng.cfg.dropout_keep_prob = keep
+    loss, gn, _ = gold["cfg2_ref/loss_gn_acc"]
+    return {"source": "tests/golden/lrcn_full.npz:cfg2_ref (fp64 CPU oracle on these inputs)",
+            "loss": [round(out["loss"], 6), round(float(loss), 6)], "grad_norm": [round(out["grad_norm"], 5), round(float(gn), 5)],
+            "max_abs_dlogit": float(np.abs(logits - gold["cfg2_ref/logits"]).max()),
+            "ok": bool(abs(out["loss"] - loss) < 1e-4 * max(1.0, abs(loss)) and abs(out["grad_norm"] - gn) < 2e-3 * gn
+                       and np.abs(logits - gold["cfg2_ref/logits"]).max() < 1e-3)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--clips-per-gpu", type=int, default=64)
-    ap.add_argument("--global-batch", type=int, default=0, help="strong scaling: split this many clips over the ranks")
+    ap.add_argument("--global-batch", type=int, default=64, help="the reference's batch_size: clips per step over ALL ranks (strong scaling)")
+    ap.add_argument("--clips-per-gpu", type=int, default=0, help="N = 1: run this many clips instead of --global-batch (e.g. 8 = one rank's "
+                                                                 "shard of the 8-GPU job); with --weak: clips on every rank")
+    ap.add_argument("--weak", action="store_true", help="N > 1: weak scaling (every rank runs a whole batch) is the headline, strong the side field")
     ap.add_argument("--fpc", type=int, default=16)
     ap.add_argument("--classes", type=int, default=101)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-clips", type=int, default=16)
-    ap.add_argument("--dropout", type=float, default=0.0)
-    ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the extra strong-scaling measurement")
+    ap.add_argument("--dropout", type=float, default=0.5, help="dropout keep probability of the timed steps (SURVEY 8d: 0.5; 0 disables)")
+    ap.add_argument("--no-side", action="store_true", help="N > 1: skip the other scaling form's measurement")
     ap.add_argument("--conv-math", default="f32", choices=["f32", "bf16x3", "bf16x6", "bf16"],
                     help="arithmetic of the MAIN measurement (default f32 = the headline; anything else is labelled in `dtype`)")
-    ap.add_argument("--no-split-math", action="store_true", help="N = 1: skip the extra bf16x3 (opt-in conv arithmetic) measurement")
+    ap.add_argument("--no-split-math", action="store_true", help="N = 1: skip the extra bf16x3 / bf16x6 / bf16 (opt-in conv arithmetic) measurements")
     args = ap.parse_args()
 
     from vltf_amd import dp as dpmod
@@ -126,64 +161,92 @@ def main():
     local = local % torch.cuda.device_count()      # ranks beyond the visible GPUs share them (gloo rehearsal on a 1-GPU box only)
     dev = "cuda:%d" % local
     torch.cuda.set_device(local)
-
-    scaling = "weak"
-    clips = args.clips_per_gpu
-    if args.global_batch:
-        scaling = "strong"
-        lo, hi = dpmod.shard_range(args.global_batch, rank, world)
-        clips = hi - lo
     gar = dpmod.GradAllReduce() if world > 1 else None
     cfg = NetConfig(image_shape=(227, 227, 3), num_classes=args.classes, fpc=args.fpc, frame_encoding_layer="fc6",
                     classifier="lstm", lstm_hidden=256, lstm_layers=1, fusion="avg", dropout_keep_prob=args.dropout,
                     conv_math=args.conv_math)
-    eng = LRCNEngine(cfg, max_clips=clips, device=dev, dp=gar)
-    eng.load_params(init_params(cfg, seed=2))          # reference initialisers; same seed on every rank
-    if gar is not None:
-        gar.broadcast_params(eng.w)
-    n = clips * args.fpc
-    frames = torch.from_numpy(np.random.default_rng(rank).integers(0, 256, (n, 227, 227, 3), dtype=np.uint8)).to(dev)
-    lab = np.random.default_rng(1000 + rank).integers(0, args.classes, clips)
-    onehot = torch.zeros((clips, args.classes), dtype=torch.int32)
-    onehot[torch.arange(clips), torch.from_numpy(lab)] = 1
-    onehot = onehot.to(dev)
-
-    def step():
-        eng.train_step_u8(frames, onehot, lr=1e-3, clip_norm=10.0, mean_bgr=MEAN_BGR, fetch=False)
+    fwd_flop, train_flop = clip_flops(args.fpc, args.classes)
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
 
-    for _ in range(args.warmup):
-        step()
-    eng.set_probe([l + p for l in CONV_MACS for p in (".fwd", ".dgrad", ".wgrad")])
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
-    times = eng.probe_times_ms()
-    eng.set_probe(None)
-    out = eng.train_step_u8(frames, onehot, lr=1e-3, clip_norm=10.0, mean_bgr=MEAN_BGR, fetch=True)   # sanity, untimed
+    def job(mode):
+        """(clips on this rank, global clips) of a scaling form.  strong: the global batch split over the ranks; weak: a whole
+        batch on every rank."""
+        if world == 1 or mode == "weak":
+            c = args.clips_per_gpu or args.global_batch
+            return c, c * world
+        lo, hi = dpmod.shard_range(args.global_batch, rank, world)
+        return hi - lo, args.global_batch
+
+    def inputs(clips):
+        n = clips * args.fpc
+        # rank r's clips: its own stream of synthetic frames (rank 0 = the inputs of tests/golden/lrcn_full.npz)
+        fr = torch.from_numpy(np.random.default_rng(rank).integers(0, 256, (max(n, 1), 227, 227, 3), dtype=np.uint8)).to(dev)[:n]
+        lab = np.random.default_rng(1000 + rank).integers(0, args.classes, clips)
+        oh = torch.zeros((clips, args.classes), dtype=torch.int32)
+        oh[torch.arange(clips), torch.from_numpy(lab)] = 1
+        return fr, oh.to(dev)
+
+    def build(clips):
+        eng = LRCNEngine(cfg, max_clips=max(clips, 1), device=dev, dp=gar)
+        eng.load_params(init_params(cfg, seed=2))          # reference initialisers; same seed on every rank
+        if gar is not None:
+            gar.broadcast_params(eng.w)
+        return eng
+
+    def timed(eng, frames, onehot, clips, global_clips, probe):
+        """W warm-up steps, then exactly K steps between barrier + synchronize on both sides; MAX over ranks."""
+        def step(fetch=False):
+            if clips == 0:                                 # more ranks than clips: this rank only joins the exchange
+                return eng.train_step_empty(1e-3, 10.0, fetch=fetch)
+            return eng.train_step_u8(frames, onehot, lr=1e-3, clip_norm=10.0, mean_bgr=MEAN_BGR, fetch=fetch,
+                                     global_rows=global_clips if world > 1 else None)
+        for _ in range(args.warmup):
+            step()
+        if probe:
+            eng.set_probe([l + p for l in CONV_MACS for p in (".fwd", ".dgrad", ".wgrad")])
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            elapsed = float(t.item())
+        times = eng.probe_times_ms() if probe else []
+        eng.set_probe(None)
+        return elapsed, times, step(fetch=True)
+
+    scaling = "weak" if (args.weak and world > 1) else "strong"
+    clips, total_clips = job(scaling)
+    eng = build(clips)
+    frames, onehot = inputs(clips)
+    n = clips * args.fpc
+    oracle_check = None
+    if world == 1 and args.conv_math == "f32":
+        oracle_check = oracle_first_step(eng, frames, onehot, clips, args.fpc, args.classes)
+        eng.load_params(init_params(cfg, seed=2))
+        eng.step_count = 0
+    elapsed, times, out = timed(eng, frames, onehot, clips, total_clips, probe=True)
     # forward only (sess.run(model.logits), run_task.py:95; SURVEY 8d asks for it beside the train step): per rank, untimed for `value`
-    for _ in range(2):
-        eng.forward_u8(frames, mean_bgr=MEAN_BGR)
-    torch.cuda.synchronize()
-    tf0 = time.perf_counter()
-    for _ in range(args.steps):
-        eng.forward_u8(frames, mean_bgr=MEAN_BGR)
-    torch.cuda.synchronize()
-    fwd_ms = (time.perf_counter() - tf0) / args.steps * 1e3
+    fwd_ms = None
+    if clips > 0:
+        for _ in range(2):
+            eng.forward_u8(frames, mean_bgr=MEAN_BGR)
+        torch.cuda.synchronize()
+        tf0 = time.perf_counter()
+        for _ in range(args.steps):
+            eng.forward_u8(frames, mean_bgr=MEAN_BGR)
+        torch.cuda.synchronize()
+        fwd_ms = (time.perf_counter() - tf0) / args.steps * 1e3
 
     # Opt-in arithmetics (NetConfig.conv_math = "bf16x3": the three conv contractions as split bf16 products; "bf16": plain bf16
     # products, BASELINE config 5's reduced-precision conv path; everything else unchanged):
@@ -193,13 +256,19 @@ def main():
     if world == 1 and not args.no_split_math and args.conv_math == "f32":
         import dataclasses
 
+        def first_step(e):
+            keep, e.cfg.dropout_keep_prob = e.cfg.dropout_keep_prob, 0.0
+            r = e.train_step_u8(frames, onehot, lr=1e-3, clip_norm=10.0, mean_bgr=MEAN_BGR, fetch=True)
+            e.cfg.dropout_keep_prob = keep
+            return r
+
         def side_run(math, first_of):
             eng_x = LRCNEngine(dataclasses.replace(cfg, conv_math=math), max_clips=clips, device=dev)
             eng_x.load_params(init_params(cfg, seed=2))
-            # first step from the SAME parameters in both arithmetics (later steps of this chaotic sigma-0.05 initialisation
-            # drift apart under any rounding difference, so only the first one is a like-for-like comparison)
+            # first step from the SAME parameters in both arithmetics, dropout off (later steps of this chaotic sigma-0.05
+            # initialisation drift apart under any rounding difference, so only the first one is a like-for-like comparison)
             first = dict(first_of)
-            first[math] = eng_x.train_step_u8(frames, onehot, lr=1e-3, clip_norm=10.0, mean_bgr=MEAN_BGR, fetch=True)
+            first[math] = first_step(eng_x)
             for _ in range(args.warmup):
                 eng_x.train_step_u8(frames, onehot, lr=1e-3, clip_norm=10.0, mean_bgr=MEAN_BGR, fetch=False)
             eng_x.set_probe([l + p for l in CONV_MACS for p in (".fwd", ".dgrad", ".wgrad")])
@@ -225,41 +294,23 @@ def main():
                     "note": "opt-in NetConfig.conv_math; never `value`"}
 
         eng.load_params(init_params(cfg, seed=2))
-        f32_first = {"f32": eng.train_step_u8(frames, onehot, lr=1e-3, clip_norm=10.0, mean_bgr=MEAN_BGR, fetch=True)}
+        f32_first = {"f32": first_step(eng)}
         split = side_run("bf16x3", f32_first)
         split6 = side_run("bf16x6", f32_first)
         plain = side_run("bf16", f32_first)
 
-    # N > 1, weak run: also time the STRONG-scaling form of the same job (BASELINE config 3: the reference's global batch of 64
-    # clips split over the ranks) -- reported beside `value`, never as `value`
-    strong = None
-    if world > 1 and scaling == "weak" and not args.no_strong:
-        gb = args.clips_per_gpu
-        lo, hi = dpmod.shard_range(gb, rank, world)
-        sc = hi - lo
-        if sc > 0:
-            eng_s = LRCNEngine(cfg, max_clips=sc, device=dev, dp=gar)
-            eng_s.load_params(init_params(cfg, seed=2))
-            f_s, o_s = frames[:sc * args.fpc], onehot[:sc]
-            for _ in range(args.warmup):
-                eng_s.train_step_u8(f_s, o_s, lr=1e-3, clip_norm=10.0, mean_bgr=MEAN_BGR, fetch=False)
-            torch.cuda.synchronize()
-            barrier()
-            ts0 = time.perf_counter()
-            for _ in range(args.steps):
-                eng_s.train_step_u8(f_s, o_s, lr=1e-3, clip_norm=10.0, mean_bgr=MEAN_BGR, fetch=False)
-            torch.cuda.synchronize()
-            barrier()
-            ts = torch.tensor([time.perf_counter() - ts0], dtype=torch.float64, device=dev)
-            torch.distributed.all_reduce(ts, op=torch.distributed.ReduceOp.MAX)
-            strong = {"global_batch": gb, "clips_per_gpu": sc, "value": round(gb * args.steps / float(ts.item()), 2), "unit": "clips/s",
-                      "ms_per_step": round(float(ts.item()) / args.steps * 1e3, 3)}
-            del eng_s
-
-    total_clips = clips * world if scaling == "weak" else args.global_batch
-    if gar is not None:
-        tc = gar.sum_scalars(torch.tensor([float(clips)], device=dev))
-        total_clips = int(tc.item())
+    # N > 1: the other scaling form of the same job, timed the same way, reported beside `value`
+    side = None
+    if world > 1 and not args.no_side:
+        other = "weak" if scaling == "strong" else "strong"
+        sc, stotal = job(other)
+        del eng
+        eng_s = build(sc)
+        f_s, o_s = inputs(sc)
+        es, _, _ = timed(eng_s, f_s, o_s, sc, stotal, probe=False)
+        side = {"scaling": other, "global_batch": stotal, "clips_per_gpu": sc, "value": round(stotal * args.steps / es, 2),
+                "unit": "clips/s", "ms_per_step": round(es / args.steps * 1e3, 3)}
+        del eng_s
     if rank != 0:
         return
 
@@ -282,7 +333,9 @@ def main():
     f32_main = args.conv_math == "f32"
     peak = PEAK_FP32_MFMA_TFLOPS if f32_main else PEAK_BF16_MFMA_TFLOPS / {"bf16x3": 3, "bf16x6": 6, "bf16": 1}[args.conv_math]
     rec = {
-        "metric": "clips/sec (16-frame 227x227) LRCN train step", "value": round(value, 2), "unit": "clips/s",
+        "metric": "clips/sec (16-frame 227x227) LRCN train step" if args.fpc == 16 else
+                  "clips/sec (%d-frame 227x227) LRCN train step" % args.fpc,
+        "value": round(value, 2), "unit": "clips/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": "f32" if args.conv_math == "f32" else "%s conv / GEMM products (opt-in, --conv-math), fp32 accumulate and elsewhere" % args.conv_math,
@@ -290,7 +343,8 @@ def main():
         "config": {"workload": "LRCN AlexNet(fc6)+LSTM(256) %d-frame 227x227x3 clips, %d classes, UCF-101-shaped synthetic, "
                                "full train step" % (args.fpc, args.classes),
                    "global_batch": total_clips, "clips_per_gpu": clips, "frames_per_clip": args.fpc,
-                   "parallelism": "dp%d" % world, "optimizer": "sgd+clip_by_global_norm(10)", "init": "reference (sigma 0.05)"},
+                   "parallelism": "dp%d" % world, "optimizer": "sgd+clip_by_global_norm(10)", "init": "reference (sigma 0.05)",
+                   "dropout_keep_prob": args.dropout},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                      "frac": round(achieved / peak, 4),
                      "traffic": traffic_rec["bytes_per_launch"] if (traffic_rec and n == 1024 and f32_main) else None,
@@ -304,12 +358,13 @@ def main():
                                     "frac": round(stack_flop / (stack_ms * 1e-3) / 1e12 / peak, 4),
                                     "ms_per_step": round(stack_ms, 3),
                                     "per_launch_ms": {k: round(v, 3) for k, v in sorted(avg.items())}},
-                     "step_frac_of_mfma_roofline": round(value / world * CLIP_TRAIN_FLOP / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)
-                     if args.fpc == 16 else None},
-        "forward_only": {"value": round(clips / (fwd_ms * 1e-3), 2), "unit": "clips/s per GPU", "ms_per_batch": round(fwd_ms, 3),
-                         "frac_of_mfma_roofline": round(clips / (fwd_ms * 1e-3) * CLIP_FWD_FLOP / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)
-                         if args.fpc == 16 else None},
-        "strong_scaling": strong,
+                     "flop_per_clip_train": train_flop,
+                     "step_frac_of_mfma_roofline": round(value / world * train_flop / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)},
+        "forward_only": None if fwd_ms is None else
+                        {"value": round(clips / (fwd_ms * 1e-3), 2), "unit": "clips/s per GPU", "ms_per_batch": round(fwd_ms, 3),
+                         "frac_of_mfma_roofline": round(clips / (fwd_ms * 1e-3) * fwd_flop / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)},
+        "oracle_check": oracle_check,
+        ("weak_scaling" if scaling == "strong" else "strong_scaling"): side,
         "bf16x3": split,
         "bf16x6": split6,
         "bf16": plain,

@@ -321,8 +321,19 @@ def alexnet_forward(p, x, final_layer="fc6", dtype=F64, keep=False):
     return fc8, cache
 
 
-def alexnet_backward(p, cache, dout, final_layer="fc6", dtype=F64):
-    """Gradients of alexnet_forward wrt every parameter; dout is d(loss)/d(output)."""
+def alexnet_backward(p, cache, dout, final_layer="fc6", dtype=F64, gates=None):
+    """Gradients of alexnet_forward wrt every parameter; dout is d(loss)/d(output).
+
+    gates (optional, tests only): the DISCRETE decisions of the forward pass taken from another evaluation of the same network
+    -- {"conv1".."conv5", "fc6", "fc7": boolean ReLU masks (output > 0), "pool1_arg", "pool2_arg", "pool5_arg": arg-max maps} in
+    this cache's layouts.  A gradient is a continuous function of the inputs only while those decisions stay fixed; an fp32
+    evaluation may take a near-tie the other way than this fp64 one, which moves gradient elements by O(1) without either being
+    wrong.  With the other evaluation's decisions substituted, the remaining difference is rounding only."""
+    gates = gates or {}
+
+    def rgrad(name, dd):
+        return dd * gates[name] if name in gates else relu_grad(cache[name], dd)
+
     g = {}
     d = dout.astype(dtype)
     if final_layer not in ("fc6", "fc7"):
@@ -330,21 +341,21 @@ def alexnet_backward(p, cache, dout, final_layer="fc6", dtype=F64):
         g["dcnn/fc8b"] = d.sum(0)
         d = d @ p["dcnn/fc8W"].astype(dtype).T
     if final_layer != "fc6":
-        d = relu_grad(cache["fc7"], d)
+        d = rgrad("fc7", d)
         g["dcnn/fc7W"] = cache["fc6"].T @ d
         g["dcnn/fc7b"] = d.sum(0)
         d = d @ p["dcnn/fc7W"].astype(dtype).T
-    d = relu_grad(cache["fc6"], d)
+    d = rgrad("fc6", d)
     g["dcnn/fc6W"] = cache["flat"].T @ d
     g["dcnn/fc6b"] = d.sum(0)
     d = (d @ p["dcnn/fc6W"].astype(dtype).T).reshape(cache["pool5"].shape)
     for name, kh, kw, co, s, grp in reversed(ALEXNET_CONVS):
         i = name[-1]
         if name in ("conv1", "conv2", "conv5"):
-            d = max_pool_valid_grad(cache["pool%s_in_shape" % i], cache["pool%s_arg" % i], d)
+            d = max_pool_valid_grad(cache["pool%s_in_shape" % i], gates.get("pool%s_arg" % i, cache["pool%s_arg" % i]), d)
         if name in ("conv1", "conv2"):
             d = lrn_grad(cache["lrn%s_in" % i], d, dtype=dtype)
-        d = relu_grad(cache[name], d)
+        d = rgrad(name, d)
         dx, dw, db = grouped_conv_grad(cache[name + "_in"], p["dcnn/%sW" % name], d, s, grp, dtype,
                                        need_dx=(name != "conv1"))
         g["dcnn/%sW" % name] = dw
@@ -540,8 +551,9 @@ def lrcn_forward(p, frames, fpc, final_layer="fc6", lstm_layers=1, fusion="avg",
 
 
 def lrcn_backward(p, cache, dlogits, fpc, final_layer="fc6", lstm_layers=1, fusion="avg", dtype=F64, classifier="lstm",
-                  frame_fusion=None):
-    """Gradients of lrcn_forward wrt every parameter (classifier lstm, or fc with early / late frame fusion)."""
+                  frame_fusion=None, gates=None):
+    """Gradients of lrcn_forward wrt every parameter (classifier lstm, or fc with early / late frame fusion).
+    gates: see alexnet_backward; arrays cover ALL frames and are sliced per chunk here."""
     g = {}
     d = dlogits.astype(dtype)
     if classifier == "lstm":
@@ -568,7 +580,8 @@ def lrcn_backward(p, cache, dlogits, fpc, final_layer="fc6", lstm_layers=1, fusi
     dfeat = d.reshape(-1, d.shape[-1])
     chunk = cache["chunk"]
     for ci, cc in enumerate(cache["cnn"]):
-        gc = alexnet_backward(p, cc, dfeat[ci * chunk:(ci + 1) * chunk], final_layer, dtype)
+        gsl = {k: v[ci * chunk:(ci + 1) * chunk] for k, v in gates.items()} if gates else None
+        gc = alexnet_backward(p, cc, dfeat[ci * chunk:(ci + 1) * chunk], final_layer, dtype, gsl)
         for k, v in gc.items():
             g[k] = g[k] + v if k in g else v
     return g

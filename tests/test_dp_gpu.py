@@ -72,3 +72,50 @@ def test_two_rank_step_equals_one_rank():
     # bias is ~1e-4 of the parameter, so one fp32 ulp of the parameter is already ~1e-4 of the update); the global gradient
     # norm agrees to fp32 rounding.  The only difference between the two runs is the summation order across the batch halves.
     assert tag == "ok" and worst < 1e-3 and gn_err < 1e-5, (worst, gn_err)
+
+
+def nccl_worker(port, q):
+    """ONE rank, backend nccl (= RCCL): the collective path of the data-parallel step on a single GPU."""
+    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from vltf_amd import dp
+    from vltf_amd.engine import LRCNEngine, NetConfig
+    r, w, _ = dp.init_from_env(backend="nccl", force=True)
+    assert (r, w) == (0, 1) and torch.distributed.get_backend() == "nccl"
+    shape, ncls, fpc, clips, hid = (67, 67, 3), 5, 2, 4, 6
+    cfg = NetConfig(image_shape=shape, num_classes=ncls, fpc=fpc, lstm_hidden=hid)
+    rng = np.random.default_rng(11)
+    p = O.init_params(rng, ncls, "fc6", hid, 1, shape, well_scaled=True)
+    frames = torch.tensor(rng.integers(0, 256, (clips * fpc,) + shape, dtype=np.uint8), device="cuda:0")
+    onehot = torch.tensor(O.labels_to_one_hot([[l] for l in rng.integers(0, ncls, clips)], ncls), device="cuda:0")
+    gar = dp.GradAllReduce(always=True)
+    eng = LRCNEngine(cfg, max_clips=clips, device="cuda:0", dp=gar)
+    ref = LRCNEngine(cfg, max_clips=clips, device="cuda:0")
+    eng.load_params(p)
+    ref.load_params(p)
+    gar.broadcast_params(eng.w)
+    outs = []
+    for _ in range(3):                                  # several steps: the RCCL stream must also order against the NEXT step's writes
+        a = eng.train_step_u8(frames, onehot, lr=0.05, clip_norm=0.5, mean_bgr=MEAN)
+        b = ref.train_step_u8(frames, onehot, lr=0.05, clip_norm=0.5, mean_bgr=MEAN)
+        outs.append((a["loss"], b["loss"], a["grad_norm"], b["grad_norm"]))
+    got, want = eng.get_params(), ref.get_params()
+    same = all(np.array_equal(got[k], want[k]) for k in want)
+    worst = max(float(np.abs(got[k] - want[k]).max()) for k in want)
+    q.put(("ok", same, worst, outs, gar.issued, len(eng.grad_chunks)))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_one_rank_rccl_step_equals_plain_step():
+    """The first thing RCCL has to get right is ordering: every chunk's all-reduce runs on RCCL's stream behind the GEMM that
+    produced it, and the clip + SGD kernels on the launch stream wait for all of them.  With one rank the sum is the identity, so
+    three data-parallel steps must leave exactly the parameters three plain steps leave."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    pr = ctx.Process(target=nccl_worker, args=(free_port(), q))
+    pr.start()
+    pr.join(300)
+    assert pr.exitcode == 0, "rank exited with %s" % pr.exitcode
+    tag, same, worst, outs, issued, nchunks = q.get(timeout=10)
+    assert tag == "ok" and issued == 3 * nchunks and nchunks >= 3, (issued, nchunks)
+    assert same, "parameters differ from the plain step by up to %.3e; losses / norms per step: %s" % (worst, outs)

@@ -1,0 +1,138 @@
+"""The BENCHMARK job itself against the CPU oracle (tests/golden/lrcn_full.npz, made by tests/golden/make_golden_full.py):
+64 clips x 16 frames of 227x227x3 through AlexNet(fc6) -> LSTM(256) -> 101 classes, one clipped-SGD step -- the launch
+plan, split counts, XCD pinning and persistent LSTM kernels bench.py times are the ones checked here -- and the 32-frame
+clip length of BASELINE config 5.  Then the full-geometry gradient check with the DEVICE's discrete decisions (ReLU masks,
+pool arg-max maps) substituted into the oracle's backward pass, which removes gate flips from the comparison instead of
+budgeting for them.
+
+Tolerances (ours; the reference pins nothing): logits 1e-3 absolute (north_star), loss 1e-4, global and per-tensor
+gradient norms 2e-3 relative; gated gradients 1e-4 relative L2 per tensor."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import lrcn_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+MEAN = np.array([99.197148, 105.293620, 109.503945], np.float32)
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lrcn_full.npz")
+SHAPE, NCLS, HID, LR, CLIP = (227, 227, 3), 101, 256, 1e-3, 10.0
+CASES = {"cfg2_ws": (64, 16, True), "cfg2_ref": (64, 16, False), "t32_ws": (4, 32, True)}     # = make_golden_full.CASES
+
+
+def case_inputs(name):
+    """bench.py's inputs (rank 0): frames default_rng(0), labels default_rng(1000), parameters init_params(cfg, seed=2)."""
+    from vltf_amd.engine import NetConfig, init_params
+    clips, fpc, ws = CASES[name]
+    cfg = NetConfig(image_shape=SHAPE, num_classes=NCLS, fpc=fpc, lstm_hidden=HID)
+    p = init_params(cfg, seed=2, well_scaled=ws)
+    frames = np.random.default_rng(0).integers(0, 256, (clips * fpc,) + SHAPE, dtype=np.uint8)
+    lab = np.random.default_rng(1000).integers(0, NCLS, clips)
+    return cfg, p, frames, O.labels_to_one_hot([[l] for l in lab], NCLS)
+
+
+def device_gates(eng, n):
+    """The discrete decisions the device took in its last forward pass, in the oracle's (NHWC) layouts."""
+    torch.cuda.synchronize()
+    g = {}
+    for L in eng.layers:
+        name = L["name"]
+        hy = L["y_halo"]
+        y = L["y"][:n]
+        if hy:
+            y = y[:, :, hy:-hy, hy:-hy]
+        g[name] = (y > 0).permute(0, 2, 3, 1).cpu().numpy().astype(np.float64)
+        if L["pool"]:
+            a = L["arg"][:n]
+            if not L["hwc"]:
+                hp = L["p_halo"]
+                if hp:
+                    a = a[:, :, hp:-hp, hp:-hp]
+                a = a.permute(0, 2, 3, 1)
+            g["pool%s_arg" % name[-1]] = a.cpu().numpy().astype(np.int8)
+    g["fc6"] = (eng.f6[:n] > 0).cpu().numpy().astype(np.float64)
+    if eng.f7 is not None:
+        g["fc7"] = (eng.f7[:n] > 0).cpu().numpy().astype(np.float64)
+    return g
+
+
+@pytest.mark.parametrize("name", ["cfg2_ws", "cfg2_ref", "t32_ws"])
+def test_benchmark_job_matches_oracle_fixture(name):
+    from vltf_amd.engine import LRCNEngine
+    gold = np.load(GOLD)
+    if name + "/logits" not in gold.files:
+        pytest.fail("fixture case %s missing from lrcn_full.npz (run tests/golden/make_golden_full.py)" % name)
+    cfg, p, frames, onehot = case_inputs(name)
+    clips = CASES[name][0]
+    eng = LRCNEngine(cfg, max_clips=clips, device=DEV)
+    eng.load_params(p)
+    fd, od = torch.from_numpy(frames).to(DEV), torch.from_numpy(onehot).to(DEV)
+    fwd = eng.forward_u8(fd, MEAN).cpu().numpy()
+    want = gold[name + "/logits"]
+    assert np.abs(fwd - want).max() <= 1e-3, "forward logits: max |d| %.3e" % np.abs(fwd - want).max()
+    out = eng.train_step_u8(fd, od, lr=LR, clip_norm=CLIP, mean_bgr=MEAN)
+    got_logits = eng.logits_host()
+    assert np.abs(got_logits - want).max() <= 1e-3
+    loss, gn, acc = gold[name + "/loss_gn_acc"]
+    assert abs(out["loss"] - loss) <= 1e-4 * max(1.0, abs(loss)), (out["loss"], loss)
+    assert abs(out["grad_norm"] - gn) <= 2e-3 * gn, (out["grad_norm"], gn)
+    assert abs(out["accuracy"] - acc) <= 1.0 / clips + 1e-9
+    g = eng.get_grads()
+    newp = eng.get_params()
+    clip_scale = CLIP / max(gn, CLIP)
+    for k in p:
+        gk = g[k].astype(np.float64).ravel()
+        wn = float(gold["%s/gradnorm/%s" % (name, k)][0])
+        assert abs(np.linalg.norm(gk) - wn) <= 2e-3 * wn + 1e-12, "grad norm of %s: %.6e vs %.6e" % (k, np.linalg.norm(gk), wn)
+        # a 64-element strided sample + the 16-element head: direction of the gradient, not only its length
+        idx = np.linspace(0, gk.size - 1, 64).astype(np.int64)
+        for tag, gv in (("gradsample", gk[idx]), ("gradhead", gk[:16])):
+            ws = gold["%s/%s/%s" % (name, tag, k)]
+            assert np.linalg.norm(gv - ws) <= 2e-2 * np.linalg.norm(ws) + 2e-3 * wn / np.sqrt(gk.size) * np.sqrt(ws.size), (tag, k)
+        # the update actually applied: w - lr * clip_scale * g
+        wh = gold["%s/newhead/%s" % (name, k)]
+        np.testing.assert_allclose(newp[k].ravel()[:16], wh, rtol=1e-5, atol=LR * clip_scale * 2e-2 * np.abs(gk[:16]).max() + 1e-7,
+                                   err_msg="updated " + k)
+
+
+@pytest.mark.parametrize("ws", [True, False])
+def test_full_geometry_gradients_with_device_gates(ws):
+    """2 clips x 4 frames, full geometry.  The oracle's backward is evaluated with the device's own ReLU masks and pool arg-max
+    maps (read back from the engine), so what is compared is rounding, not which side of a near-tie each arithmetic took:
+    every gradient tensor within 1e-4 relative L2 (the un-gated comparison needs 1.8e-2 on the conv stack, test_engine_gpu)."""
+    from vltf_amd.engine import LRCNEngine, NetConfig, init_params
+    fpc, b = 4, 2
+    cfg = NetConfig(image_shape=SHAPE, num_classes=NCLS, fpc=fpc, lstm_hidden=HID)
+    p = init_params(cfg, seed=7, well_scaled=ws)
+    rng = np.random.default_rng(70)
+    frames = rng.integers(0, 256, (b * fpc,) + SHAPE, dtype=np.uint8)
+    onehot = O.labels_to_one_hot([[l] for l in rng.integers(0, NCLS, b)], NCLS)
+    eng = LRCNEngine(cfg, max_clips=b, device=DEV)
+    eng.load_params(p)
+    out = eng.train_step_u8(torch.from_numpy(frames).to(DEV), torch.from_numpy(onehot).to(DEV), lr=0.0, clip_norm=0.0, mean_bgr=MEAN)
+    gates = device_gates(eng, b * fpc)
+    x = frames.astype(np.float32) - MEAN
+    logits, cache = O.lrcn_forward(p, x, fpc, keep=True, chunk=4)
+    loss, dlogits = O.softmax_xent_mean(logits, onehot)
+    np.testing.assert_allclose(eng.logits_host(), logits, rtol=0, atol=1e-3)
+    assert abs(out["loss"] - loss) < 1e-4 * max(1, abs(loss))
+    flips = {k: int((gates[k] != (cache_cat(cache, k) > 0)).sum()) for k in ("conv1", "conv2", "conv3", "conv4", "conv5", "fc6")}
+    flips.update({k: int((gates[k] != cache_cat(cache, k)).sum()) for k in ("pool1_arg", "pool2_arg", "pool5_arg")})
+    want = O.lrcn_backward(p, cache, dlogits, fpc, gates=gates)
+    plain = O.lrcn_backward(p, cache, dlogits, fpc)
+    g = eng.get_grads()
+    worst = {}
+    for k in p:
+        err = np.linalg.norm((g[k] - want[k]).ravel()) / (np.linalg.norm(want[k].ravel()) + 1e-30)
+        worst[k] = (err, np.linalg.norm((g[k] - plain[k]).ravel()) / (np.linalg.norm(plain[k].ravel()) + 1e-30))
+    print("gate disagreements device vs fp64 oracle:", flips)
+    print("relative L2 per tensor (gated, un-gated):", {k: "%.1e / %.1e" % v for k, v in worst.items()})
+    for k, (err, _) in worst.items():
+        assert err < 1e-4, "grad %s: relative L2 error %.3e with the device's gates (disagreements: %s)" % (k, err, flips)
+
+
+def cache_cat(cache, key):
+    return np.concatenate([c[key] for c in cache["cnn"]], axis=0)

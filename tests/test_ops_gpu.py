@@ -477,7 +477,11 @@ def test_lstm_steps_match_layer(ops):
     close(host(dx).reshape(b, T, d), dxo, rtol=1e-4, atol_rel=1e-5, msg="lstm dx")
 
 
-@pytest.mark.parametrize("b,T,d,H", [(5, 4, 24, 16), (3, 6, 40, 256), (9, 3, 12, 300), (2, 2, 8, 7)])
+@pytest.mark.parametrize("b,T,d,H", [(5, 4, 24, 16), (3, 6, 40, 256), (9, 3, 12, 300), (2, 2, 8, 7),
+                                     # the benchmark's LSTM (fc6 encode 4096 -> 256 hidden) at both clip lengths and at the
+                                     # 8-clip shard of the 8-GPU strong-scaling run as well as the 64-clip batch
+                                     (8, 16, 4096, 256), (64, 16, 4096, 256), (8, 32, 4096, 256), (64, 32, 4096, 256),
+                                     (1, 16, 64, 256), (130, 5, 32, 128)])
 def test_lstm_persistent_kernels(ops, b, T, d, H):
     """vl_lstm_seq_fwd / _bwd (one launch for all steps) against the oracle layer, incl. H > 256 (two waves per clip)."""
     rng = np.random.default_rng(b * H)

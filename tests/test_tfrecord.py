@@ -172,6 +172,35 @@ def test_corruption_is_detected(tmp_path):
     assert imgs.shape == (2, 4, 4, 3)
 
 
+def test_untrusted_record_lengths(tmp_path):
+    """Lengths come from the file: a length near 2^64 (wraps `len + 4`), one that merely runs past the end of the file, and a
+    malformed varint length inside the Example must all fail cleanly in the single-threaded, multi-threaded and skip paths."""
+    frames = np.arange(3 * 4 * 4 * 3, dtype=np.uint8).reshape(3, 4, 4, 3)
+    path = str(tmp_path / "l.tfrecord")
+    write_frames(path, frames, [[0], [1], [2]])
+    good = bytearray(open(path, "rb").read())
+    n, = struct.unpack("<Q", good[:8])
+    rec = 12 + n + 4
+    for bogus in (2 ** 64 - 3, 2 ** 63 + 5, len(good) * 2, rec * 3 - 16 - rec + 1):     # the last: one byte too long for record 1
+        raw = bytearray(good)
+        raw[rec:rec + 8] = struct.pack("<Q", bogus)                 # record 1's length (its CRC now mismatches too)
+        bad = str(tmp_path / "lbad.tfrecord")
+        open(bad, "wb").write(raw)
+        for threads in (1, 2):
+            with pytest.raises((EOFError, _hostio.HostIOError)):
+                _hostio.read_frames(bad, 0, 3, (4, 4, 3), verify_crc=False, threads=threads)
+        with pytest.raises(_hostio.HostIOError):
+            _hostio.skip_records(bad, 0, 3)
+        assert _hostio.skip_records(bad, 0, 1) == rec              # the record before it is still reachable
+    # a huge varint length inside the payload (field length > remaining bytes)
+    raw = bytearray(good)
+    raw[12 + 1:12 + 3] = b"\xff\xff"                                # the Features length varint of record 0 -> far past the record
+    bad = str(tmp_path / "lbad2.tfrecord")
+    open(bad, "wb").write(raw)
+    with pytest.raises(_hostio.HostIOError):
+        _hostio.read_frames(bad, 0, 1, (4, 4, 3), verify_crc=False, threads=1)
+
+
 def test_size_file(tmp_path):
     p = str(tmp_path / "x.size")
     T.write_size_file(p, 5, "video", [2, 2, 3, 3, 3], 16, 1)

@@ -4,6 +4,7 @@
 //   mode 2: + 1 ds_read_b32 per MFMA, waited (lgkmcnt(0)) before each group of 4 MFMAs (my GEMM loop)
 //   mode 3: ds_reads software-pipelined one group ahead
 // Grid = 256 CUs * blocks_per_cu, 256 threads (4 waves = 1 per SIMD per block).
+// Build + run on the GPU box:  hipcc --offload-arch=gfx950 -O3 -o mfma_issue mfma_issue.hip && ./mfma_issue
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>

@@ -24,6 +24,7 @@ static void set_err(const char* fmt, ...) {
 const char* vlh_last_error(void) { return g_err; }
 
 /* ---- CRC-32C: SSE4.2 crc32 instruction when the compiler targets it, else slicing table ---------------- */
+#if !defined(__SSE4_2__)
 static uint32_t table[8][256];
 static int table_ready;
 
@@ -37,6 +38,7 @@ static void init_table(void) {
         for (uint32_t i = 0; i < 256; ++i) table[t][i] = (table[t - 1][i] >> 8) ^ table[0][table[t - 1][i] & 0xFF];
     table_ready = 1;
 }
+#endif
 
 uint32_t vlh_crc32c(const void* data, size_t n) {
     const uint8_t* p = (const uint8_t*)data;
@@ -100,7 +102,7 @@ static int next_field(const uint8_t* b, size_t end, size_t* pos, uint32_t* field
     *wt = (uint32_t)(tag & 7);
     if (*wt == 2) {
         uint64_t l;
-        if (rd_varint(b, end, pos, &l) || *pos + l > end) return -1;
+        if (rd_varint(b, end, pos, &l) || l > (uint64_t)(end - *pos)) return -1;
         *val = b + *pos;
         *len = (size_t)l;
         *pos += (size_t)l;
@@ -184,19 +186,19 @@ static int parse_example(const uint8_t* buf, size_t n, uint8_t* image, int64_t i
                     memcpy(image, img, li);
                     got_img = 1;
                 } else if (f == 3) {
-                    int64_t tmp[1];
+                    int64_t tmp[1] = {0};
                     int cnt = 0;
                     if (klen == 5 && !memcmp(key, "label", 5)) {
                         if (int64_list(v, lv, labels, max_labels, &cnt)) return -4;
                         *label_count = cnt;
                     } else if (klen == 6 && !memcmp(key, "height", 6)) {
-                        if (int64_list(v, lv, tmp, 1, &cnt)) return -4;
+                        if (int64_list(v, lv, tmp, 1, &cnt) || cnt < 1) return -4;
                         dims[0] = (int32_t)tmp[0];
                     } else if (klen == 5 && !memcmp(key, "width", 5)) {
-                        if (int64_list(v, lv, tmp, 1, &cnt)) return -4;
+                        if (int64_list(v, lv, tmp, 1, &cnt) || cnt < 1) return -4;
                         dims[1] = (int32_t)tmp[0];
                     } else if (klen == 5 && !memcmp(key, "depth", 5)) {
-                        if (int64_list(v, lv, tmp, 1, &cnt)) return -4;
+                        if (int64_list(v, lv, tmp, 1, &cnt) || cnt < 1) return -4;
                         dims[2] = (int32_t)tmp[0];
                     }
                 }
@@ -228,6 +230,12 @@ static int read_full(int fd, void* dst, size_t n, int64_t off) {
     return 0;
 }
 
+/* A record (12-byte header at `offset`, `len` payload bytes, 4-byte CRC) must lie inside the file: lengths come from the file and are
+ * not trusted (a huge value would wrap `len + 4` and the offset arithmetic). */
+static int record_fits(uint64_t len, int64_t offset, int64_t file_size) {
+    return offset >= 0 && file_size - offset >= 16 && len <= (uint64_t)(file_size - offset - 16);
+}
+
 int64_t vlh_read_frames(const char* path, int64_t offset, int count, int verify_crc, uint8_t* images, int64_t image_bytes,
                         int32_t* dims, int64_t* labels, int max_labels, int32_t* label_counts, int32_t* records_read) {
     g_err[0] = 0;
@@ -235,6 +243,12 @@ int64_t vlh_read_frames(const char* path, int64_t offset, int count, int verify_
     const int fd = open(path, O_RDONLY);
     if (fd < 0) {
         set_err("cannot open %s: %s", path, strerror(errno));
+        return -2;
+    }
+    struct stat st0;
+    if (fstat(fd, &st0)) {
+        set_err("fstat %s: %s", path, strerror(errno));
+        close(fd);
         return -2;
     }
     size_t cap = (size_t)image_bytes + 4096;
@@ -249,6 +263,7 @@ int64_t vlh_read_frames(const char* path, int64_t offset, int count, int verify_
         memcpy(&len, hdr, 8);
         memcpy(&c, hdr + 8, 4);
         if (verify_crc && c != vlh_masked_crc32c(hdr, 8)) { set_err("record %d: corrupted length CRC", i); rc = -3; break; }
+        if (!record_fits(len, offset, (int64_t)st0.st_size)) { set_err("record %d: length %llu runs past the end of the file", i, (unsigned long long)len); rc = -1; break; }
         if (len + 4 > cap) {
             cap = (size_t)len + 4;
             uint8_t* nb = (uint8_t*)realloc(buf, cap);
@@ -357,7 +372,7 @@ int64_t vlh_read_frames_mt(const char* path, int64_t offset, int count, int veri
         memcpy(&len, hdr, 8);
         memcpy(&c, hdr + 8, 4);
         if (verify_crc && c != vlh_masked_crc32c(hdr, 8)) { set_err("record %d: corrupted length CRC", i); rc = -3; break; }
-        if (offset + 12 + (int64_t)len + 4 > (int64_t)st.st_size) { rc = -1; break; }
+        if (!record_fits(len, offset, (int64_t)st.st_size)) { rc = -1; break; }
         offs[i] = offset + 12;
         lens[i] = len;
         offset += 12 + (int64_t)len + 4;
@@ -409,6 +424,12 @@ int64_t vlh_skip_records(const char* path, int64_t offset, int64_t count, int ve
         return -2;
     }
     int64_t rc = 0;
+    struct stat st;
+    if (fstat(fd, &st)) {
+        set_err("fstat %s: %s", path, strerror(errno));
+        close(fd);
+        return -2;
+    }
     for (int64_t i = 0; i < count; ++i) {
         uint8_t hdr[12];
         const int r = read_full(fd, hdr, 12, offset);
@@ -418,6 +439,7 @@ int64_t vlh_skip_records(const char* path, int64_t offset, int64_t count, int ve
         memcpy(&len, hdr, 8);
         memcpy(&c, hdr + 8, 4);
         if (verify_crc && c != vlh_masked_crc32c(hdr, 8)) { set_err("record %lld: corrupted length CRC", (long long)i); rc = -3; break; }
+        if (!record_fits(len, offset, (int64_t)st.st_size)) { set_err("record %lld: length %llu runs past the end of the file", (long long)i, (unsigned long long)len); rc = -1; break; }
         offset += 12 + (int64_t)len + 4;
     }
     close(fd);

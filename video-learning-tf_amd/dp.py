@@ -7,8 +7,13 @@ rank scales its loss gradient by 1/(local_rows * world) (the loss is a batch mea
 so a SUM all-reduce of the flat gradient buffer yields the global-batch gradient on every rank;
 global-norm clipping and SGD then run identically everywhere (train.py:215-217).
 
-Two buckets, in the order backward produces them: [classifier + fc6/7/8] (85 % of the bytes) is
-reduced while conv5..conv1 backward (94 % of the FLOPs) still runs; [conv] follows at the end.
+Chunks in the order backward produces them (engine.grad_chunks): [classifier + LSTM], then the fc
+weight gradients in row blocks -- each block's all-reduce is issued right after the GEMM that
+produces it, so the ring starts while the next block is still being computed and 85 % of the bytes
+are in flight before conv5..conv1 backward (94 % of the FLOPs) begins --, and [conv] at the end.
+xGMI is point to point: a ring all-reduce of S bytes moves 2 (W-1)/W S through one link per rank
+(~153 GB/s), so chunks of 10-40 MB keep the per-launch latency (~20 us) negligible while the first
+one starts ~0.1 ms after the backward pass does.
 torch.distributed launches each all-reduce on RCCL's own stream behind the work already queued on
 the compute stream, and wait() makes the compute stream wait for it -- no host synchronisation."""
 import os
@@ -17,13 +22,15 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend=None):
+def init_from_env(backend=None, force=False):
     """Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torch.distributed.run contract).
-    Returns (rank, world, local_rank); world == 1 means no process group."""
+    Returns (rank, world, local_rank); world == 1 means no process group unless `force` (or VLTF_DIST_FORCE=1) asks for a
+    one-rank group -- the collective path (RCCL stream ordering against the launch stream) then runs on a single GPU."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    force = force or os.environ.get("VLTF_DIST_FORCE") == "1"
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:   # VLTF_DIST_BACKEND=gloo: rehearse the multi-rank path where RCCL cannot run (several ranks on one GPU)
@@ -42,16 +49,20 @@ def shard_range(total, rank, world):
 
 
 class GradAllReduce:
-    def __init__(self, group=None):
+    def __init__(self, group=None, always=False):
+        """always: issue the collectives even in a one-rank group (smoke test of the RCCL path on one GPU)."""
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.always = bool(always) and dist.is_initialized()
         self.pending = []
+        self.issued = 0                  # collectives launched (tests / logs)
 
     def reduce_async(self, flat, offset, count):
         """Start summing flat[offset:offset+count] over ranks; overlaps whatever is enqueued next."""
-        if self.world == 1 or count == 0:
+        if (self.world == 1 and not self.always) or count == 0:
             return
+        self.issued += 1
         self.pending.append(dist.all_reduce(flat[offset:offset + count], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def wait(self):

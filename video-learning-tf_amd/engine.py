@@ -121,6 +121,8 @@ def init_params(cfg: NetConfig, seed=0, stddev=0.05, well_scaled=False):
 
 
 class LRCNEngine:
+    FC6_CHUNKS = 4          # row blocks of the fc6 weight gradient = all-reduce chunks of the data-parallel exchange
+
     def __init__(self, cfg: NetConfig, max_clips: int, device="cuda:0", training=True, dp=None):
         if not torch.cuda.is_available():
             raise VltfError("LRCNEngine needs a HIP device; there is no CPU fallback")
@@ -150,8 +152,23 @@ class LRCNEngine:
                 self.G[name] = self.g[off:off + n].view(shp)
             self.offsets[name] = (off, n)
             off += n
+        # data-parallel exchange: chunks of the flat gradient in the order backward completes them (dp.py).  fc6W (85 % of the
+        # bytes) goes in FC6_CHUNKS row blocks, each reduced as soon as the GEMM that produces it is queued.
         first_conv = self.offsets["dcnn/conv5W"][0]
-        self.buckets = [(0, first_conv), (first_conv, total - first_conv)]   # [classifier+fc | convs]
+        f6o, f6n = self.offsets["dcnn/fc6W"]
+        rows6 = self.specs[[n for n, _ in self.specs].index("dcnn/fc6W")][1][0]
+        nch = max(1, min(self.FC6_CHUNKS, rows6 // 128))
+        edges = [(-(-rows6 * i // nch) + 127) // 128 * 128 if 0 < i < nch else (0 if i == 0 else rows6) for i in range(nch + 1)]
+        self.fc6_row_blocks = [(edges[i], edges[i + 1]) for i in range(nch) if edges[i + 1] > edges[i]]
+        self.grad_chunks = [(0, f6o)] if f6o > 0 else []
+        for bi, (r0, r1) in enumerate(self.fc6_row_blocks):
+            lo, hi = f6o + r0 * FC_DIM, f6o + r1 * FC_DIM
+            if bi == len(self.fc6_row_blocks) - 1:
+                hi = first_conv                                   # fc6b rides with the last block
+            self.grad_chunks.append((lo, hi - lo))
+        self.grad_chunks.append((first_conv, total - first_conv))   # conv5..conv1, at the end of backward
+        assert sum(c for _, c in self.grad_chunks) == total and all(
+            self.grad_chunks[i][0] + self.grad_chunks[i][1] == self.grad_chunks[i + 1][0] for i in range(len(self.grad_chunks) - 1))
         if cfg.optimizer == "adam" and training:
             self.adam_m, self.adam_v = torch.zeros(total, device=dev), torch.zeros(total, device=dev)
 
@@ -316,6 +333,40 @@ class LRCNEngine:
         torch.cuda.synchronize(self.dev)
         return {n: self.G[n].detach().cpu().numpy().copy() for n, _ in self.specs}
 
+    # ---- optimizer state (what tf.train.Saver() keeps besides the weights, feeder.py:201: Adam slots + beta powers) -------
+    OPT_PREFIX = "__optimizer__/"
+
+    def get_opt_state(self):
+        """{reserved name: array} to store beside the weights; step_count drives Adam's bias correction and the dropout seed."""
+        torch.cuda.synchronize(self.dev)
+        st = {self.OPT_PREFIX + "step_count": np.array([self.step_count], np.int64)}
+        if self.cfg.optimizer == "adam" and self.training:
+            st[self.OPT_PREFIX + "adam_m"] = self.adam_m.detach().cpu().numpy().copy()
+            st[self.OPT_PREFIX + "adam_v"] = self.adam_v.detach().cpu().numpy().copy()
+        return st
+
+    def load_opt_state(self, state, global_step=None):
+        """Restores get_opt_state(); returns the names that were expected but absent (fresh optimizer for those)."""
+        missing = []
+        key = self.OPT_PREFIX + "step_count"
+        if key in state:
+            self.step_count = int(np.asarray(state[key]).ravel()[0])
+        else:
+            missing.append(key)
+            if global_step is not None:
+                self.step_count = int(global_step)
+        if self.cfg.optimizer == "adam" and self.training:
+            for name, t in (("adam_m", self.adam_m), ("adam_v", self.adam_v)):
+                a = state.get(self.OPT_PREFIX + name)
+                if a is None:
+                    missing.append(self.OPT_PREFIX + name)
+                    continue
+                a = np.asarray(a, np.float32)
+                if a.shape != (t.numel(),):
+                    raise VltfError("optimizer state %s has shape %s, expected (%d,)" % (name, a.shape, t.numel()))
+                t.copy_(torch.from_numpy(np.ascontiguousarray(a)))
+        return missing
+
     def logits_host(self, rows=None):
         torch.cuda.synchronize(self.dev)
         return self.logits[:rows if rows is not None else self._rows].detach().cpu().numpy().copy()
@@ -422,6 +473,7 @@ class LRCNEngine:
     # ---- backward ------------------------------------------------------------------------------
     def _backward(self, n, b):
         P, G, cfg = self.P, self.G, self.cfg
+        ops.set_conv_math(cfg.conv_math)             # process-wide switch (see _forward): another engine may have run in between
         D, C, H, T = cfg.encode_dim(), cfg.num_classes, cfg.lstm_hidden, self.T
         sw = self.small_ws
         if cfg.classifier == "lstm":
@@ -491,11 +543,20 @@ class LRCNEngine:
             ops.gemm(d, P["dcnn/fc7W"], self.df6, n, FC_DIM, FC_DIM, transb=True, relu_mask=self.f6, ws=self.ws)
             d = self.df6
         L5 = self.layers[-1]
-        ops.gemm(L5["p"], d, G["dcnn/fc6W"], self.flat_dim, FC_DIM, n, transa=True, ws=self.ws)
         ops.colsum(d, G["dcnn/fc6b"], sw, n, FC_DIM)
+        if self.dp is None:
+            ops.gemm(L5["p"], d, G["dcnn/fc6W"], self.flat_dim, FC_DIM, n, transa=True, ws=self.ws)
+        else:
+            # the exchange starts here: everything produced so far, then fc6W block by block -- block i is on the wire
+            # (RCCL's stream) while block i+1 is computed, and the whole 85 % of the bytes before the conv backward begins
+            chunks = iter(self.grad_chunks)
+            if self.offsets["dcnn/fc6W"][0] > 0:
+                self.dp.reduce_async(self.g, *next(chunks))
+            flat_p = L5["p"].view(self.N, self.flat_dim)
+            for r0, r1 in self.fc6_row_blocks:
+                ops.gemm(flat_p[:, r0:], d, G["dcnn/fc6W"][r0:r1], r1 - r0, FC_DIM, n, transa=True, lda=self.flat_dim)
+                self.dp.reduce_async(self.g, *next(chunks))
         ops.gemm(d, P["dcnn/fc6W"], L5["dp"], n, self.flat_dim, FC_DIM, transb=True, ws=self.ws)
-        if self.dp is not None:
-            self.dp.reduce_async(self.g, *self.buckets[0])
         # ---- conv stack, last to first
         for li in reversed(range(len(self.layers))):
             L = self.layers[li]
@@ -522,7 +583,7 @@ class LRCNEngine:
                 else:
                     self._run(name + ".dgrad", conv.dgrad, dy, self.wt, prev["dy"][:n], relu_mask=prev["y"][:n])
         if self.dp is not None:
-            self.dp.reduce_async(self.g, *self.buckets[1])
+            self.dp.reduce_async(self.g, *self.grad_chunks[-1])
 
     def _pool_bwd(self, L, n, dx, relu_mask, dx_halo):
         ops.maxpool_bwd(L["dp"][:n], L["arg"][:n], dx, relu_mask=relu_mask, hwc=L["hwc"], dy_halo=L["p_halo"], dx_halo=dx_halo)
@@ -549,7 +610,7 @@ class LRCNEngine:
             raise VltfError("train_step_empty is a data-parallel call")
         ops.fill(self.g, 0.0)
         ops.fill(self.stats, 0.0)
-        for lo, cnt in self.buckets:
+        for lo, cnt in self.grad_chunks:
             self.dp.reduce_async(self.g, lo, cnt)
         return self._finish_step(0, lr, clip_norm, fetch)
 

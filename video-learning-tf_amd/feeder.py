@@ -233,6 +233,7 @@ class Feeder:
             error("Missing weights or snap part of savefile: %s" % base)
         with np.load(wfile, allow_pickle=False) as z:
             stored = {k: z[k] for k in z.files}
+        opt_state = {k: stored.pop(k) for k in list(stored) if k.startswith(engine.OPT_PREFIX)}
         ignor = set(ignorable_variable_names) | {defs.names.global_step}
         want = {n for n, _ in engine.specs}
         missing = sorted(want - set(stored) - ignor)
@@ -240,6 +241,19 @@ class Feeder:
         if missing or extra:
             error("Failed to load checkpoint: variables missing from it %s, unknown to the network %s" % (missing, extra))
         engine.load_params({k: v for k, v in stored.items() if k in want})
+        # tf.train.Saver() saves every global variable (feeder.py:201), i.e. also the Adam slots and beta powers: without them a
+        # resumed adam run restarts its moments and bias correction.  Their absence (a weights-only file) means a fresh optimizer.
+        if engine.training:
+            snap_gs = None
+            try:
+                with open(base + ".snap", "rb") as f:
+                    sp = pickle.load(f)          # a file this code wrote
+                snap_gs = sp[2] if len(sp) > 2 else None
+            except (OSError, pickle.UnpicklingError, IndexError):
+                pass
+            absent = engine.load_opt_state(opt_state, global_step=snap_gs)
+            if absent:
+                warning("Checkpoint holds no optimizer state %s: the optimizer starts fresh (step count from global_step)" % absent)
 
     def save(self, engine, progress, global_step):
         """feeder.py:263-288."""
@@ -247,7 +261,7 @@ class Feeder:
         os.makedirs(folder, exist_ok=True)
         base = os.path.join(folder, get_datetime_str() + "_" + progress) + ".graph-%d" % global_step
         info("Saving graph  to [%s]" % base)
-        np.savez(base + ".weights.npz", **engine.get_params())
+        np.savez(base + ".weights.npz", **engine.get_params(), **(engine.get_opt_state() if engine.training else {}))
         info("Saving params for epoch index %d, train index %d" % (self.train.epoch_index + 1, self.get_batch_index()))
         with open(base + ".snap", "wb") as f:
             pickle.dump([self.get_batch_index(), self.train.epoch_index, global_step], f)

@@ -63,7 +63,10 @@ class Train:
         eng, dpg = self.engine, self.engine.dp
         # data parallel: the loss is the mean over the GLOBAL batch, of which this rank holds a shard (possibly ragged or empty)
         per_clip = eng.cfg.classifier == "lstm" or eng.early or eng.late          # one logits row per clip
-        grows = fdict.get("global_clips") if (dpg is not None and per_clip) else None
+        grows = None
+        if dpg is not None and fdict.get("global_clips") is not None:
+            # per-frame head (classifier fc, no frame fusion): one logits row per frame -> global rows = global clips * fpc
+            grows = fdict["global_clips"] * (1 if per_clip else eng.cfg.fpc)
         if len(fdict["labels"]) == 0:
             out = eng.train_step_empty(lr, self.clip_norm)
         elif "device" in fdict:          # uploaded ahead of time by the feeder's BatchPrefetcher: wait for the copy on the stream
