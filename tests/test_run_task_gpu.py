@@ -16,18 +16,18 @@ pytestmark = pytest.mark.gpu
 RAW, WANT = (80, 90, 3), (67, 67, 3)
 
 
-def write_cfg(folder, name, data_path, phase, resume=None, epochs=2):
+def write_cfg(folder, name, data_path, phase, resume=None, epochs=2, optimizer="sgd", det=False, run="run"):
     cfg = {"run": {
-        "resume_file": resume, "run_folder": os.path.join(folder, "run"), "run_id": "e2e", "phase": "defs.phase.%s" % phase,
+        "resume_file": resume, "run_folder": os.path.join(folder, run), "run_id": "e2e", "phase": "defs.phase.%s" % phase,
         "data": {"d": {"data_path": data_path, "raw_image_shape": str(RAW), "image_shape": str(WANT), "mean_image": MEAN,
                        "data_format": "defs.data_format.tfrecord", "frame_format": "jpg",
-                       "imgproc": ["defs.imgproc.rand_crop", "defs.imgproc.rand_mirror", "defs.imgproc.sub_mean"] if phase == "train"
+                       "imgproc": ["defs.imgproc.rand_crop", "defs.imgproc.rand_mirror", "defs.imgproc.sub_mean"] if (phase == "train" and not det)
                        else ["defs.imgproc.center_crop", "defs.imgproc.sub_mean"],
                        "phase": "defs.phase.%s" % phase, "tag": "defs.dataset_tag.main"}},
         "network": {"num_classes": 4, "pipelines": [{"lrcn": {
             "input": "defs.dataset_tag.main", "representation": "defs.representation.dcnn", "frame_encoding_layer": "fc6",
             "classifier": "defs.classifier.lstm", "lstm_params": [8, 1, "defs.fusion_method.avg"]}}]},
-        "train": {"batch_size": 2, "epochs": epochs, "optimizer": "defs.optim.sgd", "base_lr": 1e-4, "lr_mult": "None",
+        "train": {"batch_size": 2, "epochs": epochs, "optimizer": "defs.optim.%s" % optimizer, "base_lr": 1e-4, "lr_mult": "None",
                   "lr_decay": ["defs.decay.exp", "defs.periodicity.interval", 2, 0.9], "clip_norm": 5, "dropout_keep_prob": 0.0},
         "val": {"batch_size": 2, "logits_save_interval": -1, "clip_fusion": ["defs.fusion_type.late", "defs.fusion_method.avg"]},
         "logging": {"save_freq_per_epoch": 1, "level": "logging.INFO", "print_tensors": False, "tensorboard_folder": "tb",
@@ -85,3 +85,37 @@ def test_train_resume_validate(tmp_path, monkeypatch, prefetch, math):
     want = O.clip_fusion_per_video(clip_logits, [2, 1, 2], "avg")
     np.testing.assert_allclose(got, want, rtol=1e-3, atol=1e-3)
     assert acc == float(np.mean(want.argmax(1) == np.array(vlabels)))
+
+
+def test_adam_resume_equals_uninterrupted(tmp_path, monkeypatch):
+    """tf.train.Saver() keeps every global variable (feeder.py:201), i.e. also Adam's m / v slots and beta powers: a run resumed from
+    the end-of-epoch-1 checkpoint must end with exactly the weights of the uninterrupted 2-epoch run (deterministic imgproc)."""
+    monkeypatch.setenv("VLTF_PREFETCH", "0")
+    monkeypatch.setenv("VLTF_CONV_MATH", "f32")
+    from vltf_amd import run_task
+    folder = str(tmp_path)
+    train_path, _, _ = make_dataset(folder, "train.txt", shape=RAW, seed=1)
+
+    def final_weights(run):
+        ck = sorted(glob.glob(os.path.join(folder, run, "checkpoints", "*.weights.npz")), key=os.path.getmtime)
+        with np.load(ck[-1], allow_pickle=False) as z:
+            return ck, {k: z[k] for k in z.files}
+
+    run_task.main(write_cfg(folder, "a.yml", train_path, "train", epochs=2, optimizer="adam", det=True, run="runA"), seed=3)
+    ck, full = final_weights("runA")
+    assert len(ck) == 2 and "__optimizer__/adam_m" in full and int(full["__optimizer__/step_count"][0]) == 6
+    assert np.abs(full["__optimizer__/adam_v"]).max() > 0
+    first = ck[0][:-len(".weights.npz")]
+    run_task.main(write_cfg(folder, "b.yml", train_path, "train", resume=first, epochs=2, optimizer="adam", det=True, run="runA"), seed=77)
+    _, resumed = final_weights("runA")
+    assert int(resumed["__optimizer__/step_count"][0]) == 6
+    for k in full:
+        np.testing.assert_array_equal(resumed[k], full[k], err_msg=k)
+    # a weights-only checkpoint (no optimizer state) still resumes, with a fresh optimizer and a warning
+    bare = os.path.join(folder, "runA", "checkpoints", "bare.graph-3")
+    np.savez(bare + ".weights.npz", **{k: v for k, v in np.load(first + ".weights.npz").items() if not k.startswith("__optimizer__/")})
+    import shutil
+    shutil.copy(first + ".snap", bare + ".snap")
+    run_task.main(write_cfg(folder, "c.yml", train_path, "train", resume=bare, epochs=2, optimizer="adam", det=True, run="runA"), seed=77)
+    log = "".join(open(f).read() for f in glob.glob(os.path.join(folder, "runA", "log_e2e_train_resume_*.log")))
+    assert "no optimizer state" in log

@@ -59,8 +59,9 @@ def counter_avgs(con, counter):
 
 def main():
     src, prefix = sys.argv[1], sys.argv[2]
+    prof = sys.argv[sys.argv.index("--prof") + 1] if "--prof" in sys.argv else "prof"      # kernel-trace pass directory name
     stats = {}
-    con = db(os.path.join(src, "prof"))
+    con = db(os.path.join(src, prof))
     if con:
         stats = kernel_stats(con, prefix + "_kernel_stats.csv")
     cf, cw = db(os.path.join(src, "pmc_fetch")), db(os.path.join(src, "pmc_write"))
