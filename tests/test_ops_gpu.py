@@ -495,9 +495,12 @@ def test_lstm_persistent_kernels(ops, b, T, d, H):
     act, cseq = torch.empty((b * T, 4 * H), device=DEV), torch.empty((b * T, H), device=DEV)
     hseq, hprev = torch.empty((b * T, H), device=DEV), torch.empty((b * T, H), device=DEV)
     ops.lstm_seq_fwd(gx, kd[d:], act, cseq, hseq, hprev, b, T, H)
-    close(host(hseq).reshape(b, T, H), out, rtol=1e-5, atol_rel=1e-6, msg="outputs")
-    close(host(cseq).reshape(b, T, H)[:, -1], c_last, rtol=1e-5, atol_rel=1e-6)
-    close(host(hprev).reshape(b, T, H), np.concatenate([np.zeros((b, 1, H)), out[:, :-1]], axis=1), rtol=1e-5, atol_rel=1e-6)
+    # a 4096-term fp32 pre-activation of size ~2 carries ~5e-6 of rounding (measured 5.5e-6 .. 8.1e-6 on |h| <= 1): the per-op
+    # bound of DESIGN section 2 (3e-5 of the largest element) applies there; the small cases stay at 1e-6
+    tol = dict(rtol=3e-5, atol_rel=3e-5) if d >= 1024 else dict(rtol=1e-5, atol_rel=1e-6)
+    close(host(hseq).reshape(b, T, H), out, msg="outputs", **tol)
+    close(host(cseq).reshape(b, T, H)[:, -1], c_last, **tol)
+    close(host(hprev).reshape(b, T, H), np.concatenate([np.zeros((b, 1, H)), out[:, :-1]], axis=1), **tol)
     dout = rng.standard_normal(out.shape).astype(np.float32)
     dxo, dko, dbo, _, _ = O.lstm_layer_backward(kern, cache, dout)
     kt = torch.empty((4 * H, H), device=DEV)
