@@ -175,14 +175,24 @@ int vl_lstm_step_fwd(const float* gx, const float* gh, float* act, float* cseq, 
 int vl_lstm_step_bwd(const float* dout, const float* dh_next, const float* act, const float* cseq, float* dc,
                      float* dz, int batch, int T, int t, int H, vl_stream_t stream);
 
-/* Persistent form of the recurrence: all T steps of every clip in ONE launch (clips are independent, a clip
- * lives in one workgroup slice; no inter-workgroup traffic).  kh = kernel[D:] ([H][4H], row stride 4H).
- * Same outputs as T x {vl_gemm + vl_lstm_step_fwd}.  H <= 1024. */
-int vl_lstm_seq_fwd(const float* gx, const float* kh, float* act, float* cseq, float* hseq, float* hprev,
-                    int batch, int T, int H, float forget_bias, vl_stream_t stream);
-/* BPTT over all steps: kh_t = transpose of kh ([4H][H], see vl_transpose); dout may be NULL; writes dz[r][4H]. */
-int vl_lstm_seq_bwd(const float* dout, const float* kh_t, const float* act, const float* cseq, float* dz,
-                    int batch, int T, int H, vl_stream_t stream);
+/* The whole recurrence in ONE launch per direction (csrc/lstm_cluster.hip).  kh = kernel[D:] ([H][4H], row stride 4H).
+ * Same outputs as T x {vl_gemm + vl_lstm_step_fwd}.  H <= 1024.
+ *   h0, c0 (nullable, [batch][H]): initial output and cell state -- the reference's get_state_tuple (lstm.py:34-42) passes ONE
+ *   vector as both (c = h = init), from input_state_fc (lstm.py:74-77); NULL = dynamic_rnn's zero state.  hprev[r] at t == 0 is h0.
+ * H <= 512: weight-stationary cluster form -- ceil(H/16) workgroups per group of <= 8 clips keep their 64 gate columns of kh in
+ * LDS for the whole sequence and exchange h_t (forward) / partial dh_{t-1} (backward) through tagged 8-byte words in `ws`
+ * (agent-scope atomics, bounded spins); larger H: one workgroup per clip streaming kh every step.
+ * ws: device scratch of vl_lstm_seq_ws_bytes(batch, T, H) bytes, contents irrelevant before and after the call. */
+size_t vl_lstm_seq_ws_bytes(int batch, int T, int H);
+int vl_lstm_seq_fwd(const float* gx, const float* kh, const float* h0, const float* c0, float* act, float* cseq, float* hseq,
+                    float* hprev, int batch, int T, int H, float forget_bias, void* ws, size_t ws_bytes, vl_stream_t stream);
+/* BPTT over all steps: dout may be NULL; writes dz[r][4H]; c0 as given to the forward call (NULL = zero state);
+ * dh0 / dc0 (nullable, [batch][H]) receive the gradients w.r.t. the initial output / cell state. */
+int vl_lstm_seq_bwd(const float* dout, const float* kh, const float* act, const float* cseq, const float* c0, float* dz,
+                    float* dh0, float* dc0, int batch, int T, int H, void* ws, size_t ws_bytes, vl_stream_t stream);
+/* Synchronous check of the last vl_lstm_seq_* call on `ws`: *timed_out = 1 if a workgroup of the cluster form gave up
+ * waiting for its peers (results are then invalid; it never hangs). */
+int vl_lstm_seq_status(const void* ws, int* timed_out);
 /* dst[cols][rows] = src[rows][cols]^T (src row stride ld). */
 int vl_transpose(const float* src, int64_t ld, float* dst, int rows, int cols, vl_stream_t stream);
 

@@ -481,33 +481,43 @@ def test_lstm_steps_match_layer(ops):
                                      # the benchmark's LSTM (fc6 encode 4096 -> 256 hidden) at both clip lengths and at the
                                      # 8-clip shard of the 8-GPU strong-scaling run as well as the 64-clip batch
                                      (8, 16, 4096, 256), (64, 16, 4096, 256), (8, 32, 4096, 256), (64, 32, 4096, 256),
-                                     (1, 16, 64, 256), (130, 5, 32, 128)])
-def test_lstm_persistent_kernels(ops, b, T, d, H):
-    """vl_lstm_seq_fwd / _bwd (one launch for all steps) against the oracle layer, incl. H > 256 (two waves per clip)."""
+                                     (1, 16, 64, 256), (130, 5, 32, 128), (20, 7, 24, 512), (3, 4, 16, 600), (11, 21, 50, 100)])
+@pytest.mark.parametrize("init", [False, True])
+def test_lstm_persistent_kernels(ops, b, T, d, H, init):
+    """vl_lstm_seq_fwd / _bwd (one launch per direction for all steps) against the oracle layer: the weight-stationary cluster
+    form (H <= 512; groups of 1..8 clips, several launches beyond 128 clips) and the per-clip form (H = 600).
+    init: a non-zero initial state c0 = h0 (lstm.py:34-42) and the gradients w.r.t. it."""
+    if init and d >= 1024 and b > 8:
+        pytest.skip("initial state is covered at the other sizes")
     rng = np.random.default_rng(b * H)
     x = rng.standard_normal((b, T, d)).astype(np.float32)
     kern = (rng.standard_normal((d + H, 4 * H)) * (0.5 / math.sqrt(H))).astype(np.float32)
     bias = (rng.standard_normal(4 * H) * 0.1).astype(np.float32)
-    out, (c_last, _), cache = O.lstm_layer_forward(x, kern, bias)
+    s0 = (rng.standard_normal((b, H)) * 0.5).astype(np.float32) if init else None
+    out, (c_last, _), cache = O.lstm_layer_forward(x, kern, bias, h0=s0, c0=s0)
     xd, kd = dev(x.reshape(b * T, d)), dev(kern)
+    s0d = dev(s0) if init else None
     gx = torch.empty((b * T, 4 * H), device=DEV)
     ops.gemm(xd, kd, gx, b * T, 4 * H, d, bias=dev(bias))
     act, cseq = torch.empty((b * T, 4 * H), device=DEV), torch.empty((b * T, H), device=DEV)
     hseq, hprev = torch.empty((b * T, H), device=DEV), torch.empty((b * T, H), device=DEV)
-    ops.lstm_seq_fwd(gx, kd[d:], act, cseq, hseq, hprev, b, T, H)
+    ws = ops.lstm_seq_ws(b, T, H, DEV)
+    ws.fill_(float("nan"))                                       # contents before the call are irrelevant
+    ops.lstm_seq_fwd(gx, kd[d:], act, cseq, hseq, hprev, b, T, H, ws=ws, h0=s0d, c0=s0d)
+    assert not ops.lstm_seq_timed_out(ws)
     # a 4096-term fp32 pre-activation of size ~2 carries ~5e-6 of rounding (measured 5.5e-6 .. 8.1e-6 on |h| <= 1): the per-op
     # bound of DESIGN section 2 (3e-5 of the largest element) applies there; the small cases stay at 1e-6
     tol = dict(rtol=3e-5, atol_rel=3e-5) if d >= 1024 else dict(rtol=1e-5, atol_rel=1e-6)
     close(host(hseq).reshape(b, T, H), out, msg="outputs", **tol)
     close(host(cseq).reshape(b, T, H)[:, -1], c_last, **tol)
-    close(host(hprev).reshape(b, T, H), np.concatenate([np.zeros((b, 1, H)), out[:, :-1]], axis=1), **tol)
+    first = np.zeros((b, 1, H)) if s0 is None else s0[:, None, :]
+    close(host(hprev).reshape(b, T, H), np.concatenate([first, out[:, :-1]], axis=1), **tol)
     dout = rng.standard_normal(out.shape).astype(np.float32)
-    dxo, dko, dbo, _, _ = O.lstm_layer_backward(kern, cache, dout)
-    kt = torch.empty((4 * H, H), device=DEV)
-    ops.transpose(kd[d:], kt, H, 4 * H)
-    np.testing.assert_array_equal(host(kt), kern[d:].T)
+    dxo, dko, dbo, dh0o, dc0o = O.lstm_layer_backward(kern, cache, dout)
     dz = torch.empty((b * T, 4 * H), device=DEV)
-    ops.lstm_seq_bwd(dev(dout.reshape(b * T, H)), kt, act, cseq, dz, b, T, H)
+    dh0, dc0 = (torch.empty((b, H), device=DEV), torch.empty((b, H), device=DEV)) if init else (None, None)
+    ops.lstm_seq_bwd(dev(dout.reshape(b * T, H)), kd[d:], act, cseq, dz, b, T, H, ws=ws, c0=s0d, dh0=dh0, dc0=dc0)
+    assert not ops.lstm_seq_timed_out(ws)
     dk = torch.empty_like(kd)
     ops.gemm(xd, dz, dk, d, 4 * H, b * T, transa=True)
     ops.gemm(hprev, dz, dk[d:], H, 4 * H, b * T, transa=True)
@@ -515,6 +525,30 @@ def test_lstm_persistent_kernels(ops, b, T, d, H):
     ops.gemm(dz, kd, dx, b * T, d, 4 * H, transb=True)
     close(host(dk), dko, rtol=1e-4, atol_rel=1e-5, msg="dkernel")
     close(host(dx).reshape(b, T, d), dxo, rtol=1e-4, atol_rel=1e-5, msg="dx")
+    if init:
+        close(host(dh0), dh0o, rtol=1e-4, atol_rel=1e-5, msg="dh0")
+        close(host(dc0), dc0o, rtol=1e-4, atol_rel=1e-5, msg="dc0")
+
+
+def test_lstm_cluster_is_deterministic_and_reentrant(ops):
+    """Two calls on the same workspace give bitwise identical results (the reduce-scatter of the backward sums partials in
+    workgroup order; stale exchange words of the first call must not satisfy the second)."""
+    rng = np.random.default_rng(3)
+    b, T, H = 24, 9, 256
+    gx = dev((rng.standard_normal((b * T, 4 * H)) * 1.5).astype(np.float32))
+    kh = dev((rng.standard_normal((H, 4 * H)) * 0.05).astype(np.float32))
+    dout = dev(rng.standard_normal((b * T, H)).astype(np.float32))
+    ws = ops.lstm_seq_ws(b, T, H, DEV)
+    res = []
+    for _ in range(2):
+        act, cseq = torch.zeros((b * T, 4 * H), device=DEV), torch.zeros((b * T, H), device=DEV)
+        hseq, hprev, dz = torch.zeros((b * T, H), device=DEV), torch.zeros((b * T, H), device=DEV), torch.zeros((b * T, 4 * H), device=DEV)
+        ops.lstm_seq_fwd(gx, kh, act, cseq, hseq, hprev, b, T, H, ws=ws)
+        ops.lstm_seq_bwd(dout, kh, act, cseq, dz, b, T, H, ws=ws)
+        assert not ops.lstm_seq_timed_out(ws)
+        res.append((host(hseq), host(dz)))
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    assert np.abs(res[0][1]).max() > 0
 
 
 @pytest.mark.parametrize("method", ["avg", "last"])

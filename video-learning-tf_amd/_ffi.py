@@ -43,8 +43,10 @@ SIGNATURES = {
     "vl_colsum": (i32, [p, i64, p, p, i32, i32, p]),
     "vl_lstm_step_fwd": (i32, [p, p, p, p, p, p, i32, i32, i32, i32, f32, p]),
     "vl_lstm_step_bwd": (i32, [p, p, p, p, p, p, i32, i32, i32, i32, p]),
-    "vl_lstm_seq_fwd": (i32, [p, p, p, p, p, p, i32, i32, i32, f32, p]),
-    "vl_lstm_seq_bwd": (i32, [p, p, p, p, p, i32, i32, i32, p]),
+    "vl_lstm_seq_ws_bytes": (sz, [i32, i32, i32]),
+    "vl_lstm_seq_fwd": (i32, [p, p, p, p, p, p, p, p, i32, i32, i32, f32, p, sz, p]),
+    "vl_lstm_seq_bwd": (i32, [p, p, p, p, p, p, p, p, i32, i32, i32, p, sz, p]),
+    "vl_lstm_seq_status": (i32, [p, C.POINTER(i32)]),
     "vl_transpose": (i32, [p, i64, p, i32, i32, p]),
     "vl_temporal_fusion_fwd": (i32, [p, p, i32, i32, i32, i32, p]),
     "vl_temporal_fusion_bwd": (i32, [p, p, i32, i32, i32, i32, p]),

@@ -58,3 +58,9 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
+
+// ---- LSTM recurrence: per-clip form (pointwise.hip), the fallback / A-B reference of the cluster form (lstm_cluster.hip) ------
+int vl_lstm_perclip_fwd(const float* gx, const float* kh, const float* h0, const float* c0, float* act, float* cseq, float* hseq,
+                        float* hprev, int batch, int T, int H, float forget_bias, hipStream_t stream);
+int vl_lstm_perclip_bwd(const float* dout, const float* kh_t, const float* act, const float* cseq, const float* c0, float* dz,
+                        float* dh0, float* dc0, int batch, int T, int H, hipStream_t stream);

@@ -1790,6 +1790,7 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ ws, float* __restr
 // template instead of the LDS-DMA kernels, VL_GEMM_NOSPLIT=1 disables the split-K of small dense GEMMs.
 static const bool kConvStaged = getenv("VL_CONV_STAGED") != nullptr;
 static const bool kGemmNoSplit = getenv("VL_GEMM_NOSPLIT") != nullptr;
+static const bool kConvNoLoadPick = getenv("VL_CONV_NO_LOAD_PICK") != nullptr;   // A/B: tile width by padded rows only (round-1 rule)
 static const bool kWgradDword = getenv("VL_WGRAD_DWORD") != nullptr;  // split-product wgrad: keep the dword fetches where 16-byte ones apply
 static const bool kRing8 = getenv("VL_CONV_RING8") != nullptr;      // bf16x3, 128-channel layers: the 8-wave conv_ring_kernel instead of conv_ring4_kernel
 
@@ -2310,6 +2311,8 @@ static int launch_conv_ring(const ConvGeom& g, const float* w, int64_t w_ld, int
     return 0;
 }
 
+static int device_cus();
+
 template <bool PADDED>
 static int dispatch_conv(const ConvGeom& g, const float* w, int64_t w_ld, int w_grp_stride, const int* row_tab, int Cog,
                          int Cout_total, const ConvOut& o, uint32_t* wsplit, hipStream_t s) {
@@ -2319,6 +2322,25 @@ static int dispatch_conv(const ConvGeom& g, const float* w, int64_t w_ld, int w_
     if (g_conv_math != 0 && PADDED && g.col_mul == 1) {
         if (Cog >= 96) return launch_conv_ring<128>(g, w, w_ld, w_grp_stride, row_tab, Cog, Cout_total, o, wsplit, s);
         if (Cog >= 40 && Cog <= 64) return launch_conv_ring<64>(g, w, w_ld, w_grp_stride, row_tab, Cog, Cout_total, o, wsplit, s);
+    }
+    // Few frames (one rank's shard of a multi-GPU job): the tile with the fewest padded rows can leave CUs idle or half of them
+    // with two workgroups and the rest with one.  Per-CU load of a tile width = ceil(workgroups / CUs) x its rows; take the
+    // LDS-DMA kernel (128 / 96 / 48 rows) with the smallest load, ties to the wider tile.  With many frames the widths agree
+    // with the padded-row rule below (loads differ by the padding only), which then decides alone.
+    const int64_t px = ceil_div(g.M, 128), cus = device_cus(), ngrp = Cout_total / Cog;
+    const bool few = px * ceil_div(Cog, 128) * ngrp < 8 * cus;        // under 8 workgroups per CU at the widest tile: quantisation matters
+    if (PADDED && few && (int64_t)g.K * w_ld * 4 < MAX_BUF_BYTES && !kConvStaged && !kConvNoLoadPick) {
+        const int widths[3] = {128, 96, 48};
+        int best = 0;
+        int64_t best_load = 0;
+        for (int i = 0; i < 3; ++i) {
+            const int64_t wgs = px * ceil_div(Cog, widths[i]) * ngrp;
+            const int64_t load = ceil_div(wgs, cus) * widths[i];
+            if (i == 0 || load < best_load) { best = i; best_load = load; }
+        }
+        if (best == 0) return launch_conv_dma<128>(g, w, w_ld, w_grp_stride, row_tab, Cog, Cout_total, o, s);
+        if (best == 1) return launch_conv_dma<96>(g, w, w_ld, w_grp_stride, row_tab, Cog, Cout_total, o, s);
+        return launch_conv_dma<48>(g, w, w_ld, w_grp_stride, row_tab, Cog, Cout_total, o, s);
     }
     if (w128 <= w96 && w128 <= w64) {
         // 128-wide tiles in the padded layout: the LDS-DMA kernel
@@ -2857,7 +2879,8 @@ extern "C" int vl_gemm(int transa, int transb, int m, int n, int k, const float*
     // barrier latency with co-resident workgroups: fc6 forward = 256 tiles = one per CU ran at 0.65 of peak) and a workspace
     // was provided
     int splits = 1;
-    const int want = 3 * device_cus();
+    static const int kWantPerCu = getenv("VL_GEMM_WANT") ? atoi(getenv("VL_GEMM_WANT")) : 3;   // experiments: workgroups per CU aimed at
+    const int want = kWantPerCu * device_cus();
     if (ws && tiles < want && !kGemmNoSplit) {
         splits = ceil_div(want, tiles);
         const int maxs = k / 256 > 0 ? k / 256 : 1;

@@ -999,7 +999,9 @@ extern "C" int vl_lstm_step_bwd(const float* dout, const float* dh_next, const f
 template <bool BWD>
 __global__ void lstm_seq_kernel(const float* __restrict__ gx, const float* __restrict__ kmat, float* __restrict__ act,
                                 float* __restrict__ cseq, float* __restrict__ hseq, float* __restrict__ hprev,
-                                const float* __restrict__ dout, float* __restrict__ dz, int T, int H, float forget_bias, int KQ) {
+                                const float* __restrict__ dout, float* __restrict__ dz, int T, int H, float forget_bias, int KQ,
+                                const float* __restrict__ h0, const float* __restrict__ c0, float* __restrict__ dh0,
+                                float* __restrict__ dc0) {
     // blockDim = KQ * HP threads (HP = H rounded up to the wave): thread (u, kq) accumulates the kq-th slice of the recurrent
     // reduction for hidden unit u; the KQ partial sums meet in LDS and the kq = 0 threads do the gate math.  The recurrence is a
     // chain of T dependent steps whose length is set by load latency, not bandwidth (1 MB of weights per step from L2): splitting
@@ -1014,15 +1016,16 @@ __global__ void lstm_seq_kernel(const float* __restrict__ gx, const float* __res
     if (!BWD) {
         float* hs = sm;                                // [H] h_{t-1}
         float* part = sm + H;                          // [KQ][4][H] partial gate pre-activations
-        float c = 0.f;
-        for (int i = threadIdx.x; i < H; i += blockDim.x) hs[i] = 0.f;
+        float c = (c0 && live) ? c0[(int64_t)b * H + u] : 0.f;
+        for (int i = threadIdx.x; i < H; i += blockDim.x) hs[i] = h0 ? h0[(int64_t)b * H + i] : 0.f;
         __syncthreads();
+        const bool rec0 = h0 != nullptr;               // an initial state makes step 0 a full recurrent step
         const int klen = (H + KQ - 1) / KQ, k0 = kq * klen, k1 = min(H, k0 + klen);
         const int nb = (k1 - k0) / KB, rot = (b * 5) % (nb > 0 ? nb : 1);
         for (int t = 0; t < T; ++t) {
             const int64_t r = (int64_t)b * T + t;
             float z[4] = {0.f, 0.f, 0.f, 0.f};
-            if (t > 0) {
+            if (t > 0 || rec0) {
                 for (int ib = 0; ib < nb; ++ib) {
                     const int kb = k0 + ((ib + rot) % nb) * KB;
                     float w[KB][4];
@@ -1053,7 +1056,7 @@ __global__ void lstm_seq_kernel(const float* __restrict__ gx, const float* __res
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     zz[q] = gx[r * H4 + q * H + u];
-                    if (t > 0)
+                    if (t > 0 || rec0)
                         for (int j = 0; j < KQ; ++j) zz[q] += part[(j * 4 + q) * H + u];    // fixed order: reproducible
                 }
                 const float gi = sigmoidf_(zz[0]), gj = tanhf(zz[1]), gf = sigmoidf_(zz[2] + forget_bias), go = sigmoidf_(zz[3]);
@@ -1082,7 +1085,7 @@ __global__ void lstm_seq_kernel(const float* __restrict__ gx, const float* __res
                 const float* a = act + r * H4 + u;
                 const float gi = a[0], gj = a[H], gf = a[2 * H], go = a[3 * H];
                 const float cc = cseq[r * H + u];
-                const float cp = t > 0 ? cseq[(r - 1) * H + u] : 0.f;
+                const float cp = t > 0 ? cseq[(r - 1) * H + u] : (c0 ? c0[(int64_t)b * H + u] : 0.f);
                 const float tc = tanhf(cc);
                 const float d_o = din * tc;
                 const float dcv = dc + din * go * (1.f - tc * tc);
@@ -1094,7 +1097,7 @@ __global__ void lstm_seq_kernel(const float* __restrict__ gx, const float* __res
                 zs[u] = zi; zs[H + u] = zj; zs[2 * H + u] = zf; zs[3 * H + u] = zo;
             }
             __syncthreads();                           // dz_t complete in LDS
-            if (t > 0) {
+            if (t > 0 || dh0) {
                 float acc = 0.f;
                 for (int ib = 0; ib < nb; ++ib) {
                     const int g = g0 + ((ib + rot) % nb) * KB;
@@ -1108,12 +1111,16 @@ __global__ void lstm_seq_kernel(const float* __restrict__ gx, const float* __res
                 if (live) part[kq * H + u] = acc;
             }
             __syncthreads();                           // partial dh complete; dz_t consumed before it is overwritten
-            if (t > 0 && live && kq == 0) {
+            if ((t > 0 || dh0) && live && kq == 0) {
                 float acc = 0.f;
                 for (int j = 0; j < KQ; ++j) acc += part[j * H + u];
                 dh = acc;
             }
             // (the next iteration's first barrier separates these reads of `part` from its next writes)
+        }
+        if (live && kq == 0) {
+            if (dh0) dh0[(int64_t)b * H + u] = dh;
+            if (dc0) dc0[(int64_t)b * H + u] = dc;
         }
     }
 }
@@ -1123,25 +1130,24 @@ static int lstm_seq_hp(int H) { return ((H + 63) / 64) * 64; }
 static int lstm_seq_kq(int H) { return lstm_seq_hp(H) * 4 <= 1024 ? 4 : (lstm_seq_hp(H) * 2 <= 1024 ? 2 : 1); }
 
 
-extern "C" int vl_lstm_seq_fwd(const float* gx, const float* kh, float* act, float* cseq, float* hseq, float* hprev, int batch,
-                               int T, int H, float forget_bias, vl_stream_t stream) {
-    VL_CHECK(gx && kh && act && cseq && hseq && hprev, "vl_lstm_seq_fwd: null argument");
-    VL_CHECK(batch > 0 && T > 0 && H > 0 && H <= 1024, "vl_lstm_seq_fwd: bad shape (hidden size must be <= 1024)");
+// Per-clip form: the fallback of vl_lstm_seq_fwd / _bwd (lstm_cluster.hip) for hidden sizes its LDS-resident weight slices do
+// not hold (H > 512), and the A/B reference of the cluster form (VL_LSTM_PERCLIP=1).
+int vl_lstm_perclip_fwd(const float* gx, const float* kh, const float* h0, const float* c0, float* act, float* cseq, float* hseq,
+                        float* hprev, int batch, int T, int H, float forget_bias, hipStream_t stream) {
     const int kq = lstm_seq_kq(H);
     hipLaunchKernelGGL((lstm_seq_kernel<false>), dim3(batch), dim3(lstm_seq_hp(H) * kq), (size_t)(1 + 4 * kq) * H * sizeof(float),
-                       (hipStream_t)stream, gx, kh, act, cseq, hseq, hprev, (const float*)nullptr, (float*)nullptr, T, H, forget_bias, kq);
+                       stream, gx, kh, act, cseq, hseq, hprev, (const float*)nullptr, (float*)nullptr, T, H, forget_bias, kq, h0, c0,
+                       (float*)nullptr, (float*)nullptr);
     VL_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int vl_lstm_seq_bwd(const float* dout, const float* kh_t, const float* act, const float* cseq, float* dz, int batch,
-                               int T, int H, vl_stream_t stream) {
-    VL_CHECK(kh_t && act && cseq && dz, "vl_lstm_seq_bwd: null argument");
-    VL_CHECK(batch > 0 && T > 0 && H > 0 && H <= 1024, "vl_lstm_seq_bwd: bad shape (hidden size must be <= 1024)");
+int vl_lstm_perclip_bwd(const float* dout, const float* kh_t, const float* act, const float* cseq, const float* c0, float* dz,
+                        float* dh0, float* dc0, int batch, int T, int H, hipStream_t stream) {
     const int kq = lstm_seq_kq(H);
     hipLaunchKernelGGL((lstm_seq_kernel<true>), dim3(batch), dim3(lstm_seq_hp(H) * kq), (size_t)(4 + kq) * H * sizeof(float),
-                       (hipStream_t)stream, (const float*)nullptr, kh_t, const_cast<float*>(act), const_cast<float*>(cseq),
-                       (float*)nullptr, (float*)nullptr, dout, dz, T, H, 0.f, kq);
+                       stream, (const float*)nullptr, kh_t, const_cast<float*>(act), const_cast<float*>(cseq),
+                       (float*)nullptr, (float*)nullptr, dout, dz, T, H, 0.f, kq, (const float*)nullptr, c0, dh0, dc0);
     VL_LAUNCH_CHECK();
     return 0;
 }

@@ -260,13 +260,13 @@ class LRCNEngine:
                     S.update(dz=buf(N, 4 * H), dout=buf(N, H))
                 self.lstm.append(S)
             self.gh = buf(B, 4 * H)
+            self.lstm_ws = ops.lstm_seq_ws(B, T, H, dev) if H <= 1024 else None
             self.fused = buf(B, H)
             self.dropped = buf(B, H)
             self.drop_mask = buf(B, H, dtype=torch.uint8)
             self.logits = buf(B, C) if H != C else self.dropped
             if training:
                 self.dh, self.dc = buf(B, H), buf(B, H)
-                self.kh_t = buf(4 * H, H)
                 self.dfused, self.ddropped = buf(B, H), buf(B, H)
         else:
             ff = cfg.frame_fusion
@@ -426,7 +426,7 @@ class LRCNEngine:
                 # hoisted input projection for all (clip, t) rows, then the serial recurrence
                 ops.gemm(xin, K, S["gx"], n, 4 * H, d, bias=P[pre + "bias"], ws=self.ws)
                 if H <= 1024:
-                    ops.lstm_seq_fwd(S["gx"], K[d:], S["act"], S["cseq"], S["hseq"], S["hprev"], b, T, H, FORGET_BIAS)
+                    ops.lstm_seq_fwd(S["gx"], K[d:], S["act"], S["cseq"], S["hseq"], S["hprev"], b, T, H, FORGET_BIAS, ws=self.lstm_ws)
                 else:
                     for t in range(T):
                         if t > 0:
@@ -496,8 +496,7 @@ class LRCNEngine:
                 din = D if l == 0 else H
                 xin = self.feat if l == 0 else self.lstm[l - 1]["hseq"]
                 if H <= 1024:
-                    ops.transpose(K[din:], self.kh_t, H, 4 * H)
-                    ops.lstm_seq_bwd(S["dout"], self.kh_t, S["act"], S["cseq"], S["dz"], b, T, H)
+                    ops.lstm_seq_bwd(S["dout"], K[din:], S["act"], S["cseq"], S["dz"], b, T, H, ws=self.lstm_ws)
                 else:
                     ops.fill(self.dc, 0.0)
                     for t in reversed(range(T)):

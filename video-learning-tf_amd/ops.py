@@ -272,15 +272,35 @@ def lstm_step_bwd(dout, dh_next, act, cseq, dc, dz, batch, T, t, H):
     _ffi.call("vl_lstm_step_bwd", _p(dout), _p(dh_next), _p(act), _p(cseq), _p(dc), _p(dz), batch, T, t, H, stream())
 
 
-def lstm_seq_fwd(gx, kh, act, cseq, hseq, hprev, batch, T, H, forget_bias=1.0):
-    """All T steps in one persistent launch; kh = kernel[D:] view ([H, 4H])."""
-    _f32(gx, kh, act, cseq, hseq, hprev)
-    _ffi.call("vl_lstm_seq_fwd", _p(gx), _p(kh), _p(act), _p(cseq), _p(hseq), _p(hprev), batch, T, H, forget_bias, stream())
+def lstm_seq_ws(batch, T, H, device):
+    """Scratch for lstm_seq_fwd / lstm_seq_bwd (vl_lstm_seq_ws_bytes): the exchange words of the cluster form."""
+    n = int(_ffi.lib().vl_lstm_seq_ws_bytes(int(batch), int(T), int(H)))
+    return torch.zeros((n + 3) // 4, dtype=torch.float32, device=device)
 
 
-def lstm_seq_bwd(dout, kh_t, act, cseq, dz, batch, T, H):
-    _f32(dout, kh_t, act, cseq, dz)
-    _ffi.call("vl_lstm_seq_bwd", _p(dout), _p(kh_t), _p(act), _p(cseq), _p(dz), batch, T, H, stream())
+def lstm_seq_fwd(gx, kh, act, cseq, hseq, hprev, batch, T, H, forget_bias=1.0, ws=None, h0=None, c0=None):
+    """All T steps in one launch; kh = kernel[D:] view ([H, 4H]); h0 / c0: initial state [batch, H] (None = zeros)."""
+    _f32(gx, kh, act, cseq, hseq, hprev, h0, c0, ws)
+    if ws is None:
+        raise _ffi.VltfError("lstm_seq_fwd: a workspace from lstm_seq_ws() is required")
+    _ffi.call("vl_lstm_seq_fwd", _p(gx), _p(kh), _p(h0), _p(c0), _p(act), _p(cseq), _p(hseq), _p(hprev), batch, T, H, forget_bias,
+              _p(ws), ws.numel() * 4, stream())
+
+
+def lstm_seq_bwd(dout, kh, act, cseq, dz, batch, T, H, ws=None, c0=None, dh0=None, dc0=None):
+    """BPTT in one launch; kh = kernel[D:] view (not transposed); dh0 / dc0: optional outputs [batch, H]."""
+    _f32(dout, kh, act, cseq, dz, c0, dh0, dc0, ws)
+    if ws is None:
+        raise _ffi.VltfError("lstm_seq_bwd: a workspace from lstm_seq_ws() is required")
+    _ffi.call("vl_lstm_seq_bwd", _p(dout), _p(kh), _p(act), _p(cseq), _p(c0), _p(dz), _p(dh0), _p(dc0), batch, T, H, _p(ws),
+              ws.numel() * 4, stream())
+
+
+def lstm_seq_timed_out(ws):
+    """True if a workgroup of the last cluster-form launch on `ws` gave up waiting for its peers (synchronises)."""
+    v = C.c_int(0)
+    _ffi.call("vl_lstm_seq_status", _p(ws), C.byref(v))
+    return bool(v.value)
 
 
 def transpose(src, dst, rows, cols, ld=None):
