@@ -201,6 +201,16 @@ int vl_transpose(const float* src, int64_t ld, float* dst, int rows, int cols, v
 int vl_temporal_fusion_fwd(const float* x, float* y, int batch, int T, int H, int method, vl_stream_t stream);
 int vl_temporal_fusion_bwd(const float* dy, float* dx, int batch, int T, int H, int method, vl_stream_t stream);
 
+/* ---- tensor-list plumbing of multi-input pipelines (tf_util.py:99-192) ------------------------------------------------
+ * vl_copy2d: dst[r][c] = src[r][c] for r < rows, c < cols with row strides src_ld / dst_ld (src_ld 0 repeats one row).
+ * tf.concat / vec_seq_concat (tf_util.py:99-124), the ibias insertion (tf_util.py:154-176) and replicate_auxilliary_tensor
+ * (tf_util.py:182-192) are such block copies, forward and backward. */
+int vl_copy2d(const float* src, int64_t src_ld, float* dst, int64_t dst_ld, int rows, int cols, vl_stream_t stream);
+/* op 0: a + b; 1: mean of the two (tf.reduce_mean, fusion avg, tf_util.py:142-143); 2: max (fusion maximum, :144-145). */
+int vl_eltwise2(const float* a, const float* b, float* out, int64_t count, int op, vl_stream_t stream);
+/* gradient of max(a, b) w.r.t. both (the larger input takes d; a on ties). */
+int vl_max2_grad(const float* a, const float* b, const float* d, float* da, float* db, int64_t count, vl_stream_t stream);
+
 /* ---- tf.nn.dropout (lstm.py:50-56): y = x * mask / keep, mask ~ Bernoulli(keep) ------------------
  * Counter-based RNG keyed by (seed, element index); mask (uint8) is written for the backward. */
 int vl_dropout_fwd(const float* x, float* y, uint8_t* mask, int64_t count, float keep, uint64_t seed, vl_stream_t stream);

@@ -660,3 +660,177 @@ def clip_fusion_per_video(clip_logits, cpv_list, method="avg"):
         pos += cpv
     assert pos == len(clip_logits)
     return np.stack(out).astype(np.float32)
+
+
+# ----------------------------------------------------------------------------------------------
+# Multi-input composition -- tf_util.py:99-124,136-192; models/model.py:61-79,128-141; lstm.py:34-42,59-99
+# (the pieces BASELINE config 4, the encoder-decoder description model, is assembled from)
+# ----------------------------------------------------------------------------------------------
+def replicate_auxilliary_tensor(aux, tile_num):
+    """tf_util.py:182-192, literally: reshape to [1, -1], tile [tile_num, 1], reshape to [-1, dim] -- i.e. the WHOLE batch of
+    aux vectors repeated tile_num times in sequence (a0..aB-1, a0..aB-1, ...), not each vector repeated in place."""
+    if tile_num <= 1:
+        return aux
+    return np.tile(aux.reshape(1, -1), (tile_num, 1)).reshape(-1, aux.shape[-1])
+
+
+def replicate_auxilliary_tensor_grad(d, tile_num, rows):
+    if tile_num <= 1:
+        return d
+    return d.reshape(tile_num, rows, d.shape[-1]).sum(axis=0)
+
+
+def vec_seq_concat(seq, vec, sequence_length, order="vecfirst"):
+    """tf_util.py:99-124: every vector of vec [B, dv] is repeated sequence_length times (tile on axis 1, reshape) and
+    concatenated column-wise with seq [B*T, ds]."""
+    rep = np.tile(vec, (1, sequence_length)).reshape(-1, vec.shape[-1])
+    return np.concatenate([rep, seq] if order == "vecfirst" else [seq, rep], axis=1)
+
+
+def tensor_list_fusion(inputs, method, dims, fpcs, cpvs):
+    """apply_tensor_list_fusion (tf_util.py:136-179) -> (tensor, dim, fpc, cpv, cache for the gradient)."""
+    cpv_ratio = int(cpvs[0] / cpvs[1]) if len(inputs) == 2 else None
+    if method == "avg":
+        return np.mean(np.stack(inputs), axis=0), dims[0], fpcs[0], cpvs[0], ("avg", len(inputs))
+    if method == "maximum":
+        st = np.stack(inputs)
+        return st.max(axis=0), dims[0], fpcs[0], cpvs[0], ("maximum", st.argmax(axis=0), len(inputs))
+    if method == "concat":
+        if cpv_ratio == 1:
+            return np.concatenate(inputs, axis=1), sum(dims), fpcs[0], cpvs[0], ("concat", list(dims))
+        aux = replicate_auxilliary_tensor(inputs[1], cpv_ratio)
+        return (vec_seq_concat(inputs[0], aux, fpcs[0]), sum(dims), fpcs[0], cpvs[0],
+                ("vecseq", list(dims), cpv_ratio, inputs[1].shape[0], fpcs[0]))
+    if method == "ibias":
+        main, aux = inputs
+        rows_aux = aux.shape[0]
+        if cpv_ratio != 1:
+            aux = replicate_auxilliary_tensor(aux, cpv_ratio)
+        mdim, adim = dims
+        combo = np.concatenate([aux.reshape(-1, 1, adim), main.reshape(-1, fpcs[0], mdim)], axis=1)   # needs adim == mdim, as in TF
+        return combo.reshape(-1, mdim), mdim, fpcs[0] + 1, cpvs[0], ("ibias", fpcs[0], mdim, cpv_ratio, rows_aux)
+    raise ValueError("Unknown fusion method: [%s]" % method)
+
+
+def tensor_list_fusion_grad(cache, d):
+    """-> list of gradients, one per fused input."""
+    kind = cache[0]
+    if kind == "avg":
+        return [d / cache[1]] * cache[1]
+    if kind == "maximum":
+        return [d * (cache[1] == i) for i in range(cache[2])]
+    if kind == "concat":
+        out, pos = [], 0
+        for dim in cache[1]:
+            out.append(d[:, pos:pos + dim])
+            pos += dim
+        return out
+    if kind == "vecseq":
+        (dmain, daux), ratio, rows_aux, T = cache[1], cache[2], cache[3], cache[4]
+        dvec = d[:, :daux].reshape(-1, T, daux).sum(axis=1)            # vecfirst: the tiled aux occupies the first columns
+        return [d[:, daux:], replicate_auxilliary_tensor_grad(dvec, ratio, rows_aux)]
+    if kind == "ibias":
+        T, mdim, ratio, rows_aux = cache[1], cache[2], cache[3], cache[4]
+        d3 = d.reshape(-1, T + 1, mdim)
+        return [d3[:, 1:, :].reshape(-1, mdim), replicate_auxilliary_tensor_grad(d3[:, 0, :], ratio, rows_aux)]
+    raise ValueError(kind)
+
+
+def lstm_classifier_forward(p, scope, x, T, layers, fusion, out_dim, state=None, dtype=F64):
+    """LSTM.build -> lstm.forward_pass_sequence (vectorizer.py:63-69, lstm.py:59-99) followed by the model-level handling of the
+    `state` fusion (model.py:136-141).  x [B*T, D]; state (optional) [B, S]: mapped by convert_dim_fc "input_state_fc" when
+    S != H (lstm.py:74-77) and used as BOTH c and h of EVERY layer (get_state_tuple, lstm.py:34-42).
+    fusion avg | last: pooled outputs -> [dropout] -> output_fc -> [B, out_dim];  reshape: every step's output -> output_fc ->
+    [B*T, out_dim];  state: final h of the last layer -> convert_dim_fc "fc_convert" -> [B, out_dim].
+    Parameter names are `scope` + the TF names.  Returns (logits, cache)."""
+    b = x.shape[0] // T
+    hdim = p[scope + "rnn/multi_rnn_cell/cell_0/basic_lstm_cell/kernel"].shape[1] // 4
+    cache = {"T": T, "fusion": fusion, "layers": layers, "scope": scope}
+    s = None
+    if state is not None:
+        s = state.astype(dtype)
+        cache["state_in"] = s
+        if scope + "input_state_fc_w" in p:
+            s = xw_plus_b(s, p[scope + "input_state_fc_w"], p[scope + "input_state_fc_b"], dtype)
+    seq = x.astype(dtype).reshape(b, T, -1)
+    lc = []
+    for l in range(layers):
+        pre = scope + "rnn/multi_rnn_cell/cell_%d/basic_lstm_cell/" % l
+        seq, _, c = lstm_layer_forward(seq, p[pre + "kernel"], p[pre + "bias"], h0=s, c0=s, dtype=dtype)
+        lc.append(c)
+    cache.update(lstm=lc, seq_shape=seq.shape, has_state=s is not None)
+    fused = temporal_fusion(seq, "last" if fusion == "state" else fusion)
+    cache["fused"] = fused
+    head = scope + ("fc_convert" if fusion == "state" else "output_fc")
+    cache["head"] = head
+    logits = xw_plus_b(fused, p[head + "_w"], p[head + "_b"], dtype) if head + "_w" in p else fused
+    return logits, cache
+
+
+def lstm_classifier_backward(p, cache, dlogits, dtype=F64):
+    """-> (gradients of the scope's parameters, d/dx [B*T, D], d/dstate [B, S] or None)."""
+    g, scope, head = {}, cache["scope"], cache["head"]
+    d = dlogits.astype(dtype)
+    if head + "_w" in p:
+        g[head + "_w"] = cache["fused"].T @ d
+        g[head + "_b"] = d.sum(0)
+        d = d @ p[head + "_w"].astype(dtype).T
+    d = temporal_fusion_grad(cache["seq_shape"], "last" if cache["fusion"] == "state" else cache["fusion"], d)
+    ds = None
+    for l in reversed(range(cache["layers"])):
+        pre = scope + "rnn/multi_rnn_cell/cell_%d/basic_lstm_cell/" % l
+        d, dk, db, dh0, dc0 = lstm_layer_backward(p[pre + "kernel"], cache["lstm"][l], d, dtype=dtype)
+        g[pre + "kernel"], g[pre + "bias"] = dk, db
+        if cache["has_state"]:
+            ds = dh0 + dc0 if ds is None else ds + dh0 + dc0          # c = h = state in every layer
+    dstate = None
+    if cache["has_state"]:
+        if scope + "input_state_fc_w" in p:
+            g[scope + "input_state_fc_w"] = cache["state_in"].T @ ds
+            g[scope + "input_state_fc_b"] = ds.sum(0)
+            ds = ds @ p[scope + "input_state_fc_w"].astype(dtype).T
+        dstate = ds
+    return g, d.reshape(-1, d.shape[-1]), dstate
+
+
+def init_lstm_classifier_params(rng, scope, in_dim, hidden, layers, fusion, out_dim, state_dim=None, stddev=0.05, well_scaled=False):
+    """Initialisers of the variables lstm_classifier_forward reads (BasicLSTMCell glorot-uniform kernels / zero biases;
+    convert_dim_fc truncated_normal(0.05) / 0.1, tf_util.py:44-45)."""
+    p, d = {}, in_dim
+    for l in range(layers):
+        lim = math.sqrt(6.0 / (d + hidden + 4 * hidden))
+        p[scope + "rnn/multi_rnn_cell/cell_%d/basic_lstm_cell/kernel" % l] = rng.uniform(-lim, lim, (d + hidden, 4 * hidden)).astype(np.float32)
+        p[scope + "rnn/multi_rnn_cell/cell_%d/basic_lstm_cell/bias" % l] = np.zeros(4 * hidden, np.float32)
+        d = hidden
+
+    def fc(name, i, o):
+        p[name + "_w"] = truncated_normal(rng, (i, o), math.sqrt(2.0 / i) if well_scaled else stddev)
+        p[name + "_b"] = np.full(o, 0.1, np.float32)
+    if state_dim is not None and state_dim != hidden:
+        fc(scope + "input_state_fc", state_dim, hidden)
+    if hidden != out_dim:
+        fc(scope + ("fc_convert" if fusion == "state" else "output_fc"), hidden, out_dim)
+    return p
+
+
+def encdec_forward(p, frames, words, fpc_frames, fpc_words, enc, dec, num_classes, dtype=F64, chunk=32):
+    """BASELINE config 4 as the reference's Model would assemble it from two pipelines (model.py:18-162):
+      enc: {input: frames dataset, representation dcnn @ enc["layer"], classifier lstm, lstm_params [H, L, state]}
+           -> final h of the last layer -> convert_dim_fc to num_classes when H != num_classes (model.py:136-141)
+      dec: {input: [word-vector dataset, enc], representation nop, classifier lstm, lstm_params [H, L, fusion]}
+           -> enc's output is the decoder's state vector (model.py:128-134): replicate (cpv ratio 1 here), input_state_fc,
+              c = h = state; the word vectors [B*Tw, E] are the sequence; fusion reshape gives per-step logits [B*Tw, classes].
+    Variables are scoped by pipeline name ("enc/", "dec/") -- in the reference both LSTMs would claim the same TF names.
+    Returns (logits, cache)."""
+    pe = {k[len("enc/"):]: v for k, v in p.items() if k.startswith("enc/")}
+    enc_out, ec = lrcn_forward(pe, frames, fpc_frames, enc["layer"], enc["layers"], "state", "lstm", None, dtype, True, chunk)
+    logits, dc = lstm_classifier_forward(p, "dec/", words, fpc_words, dec["layers"], dec["fusion"], num_classes, state=enc_out, dtype=dtype)
+    return logits, {"enc": ec, "dec": dc, "enc_out": enc_out}
+
+
+def encdec_backward(p, cache, dlogits, fpc_frames, enc, dtype=F64):
+    pe = {k[len("enc/"):]: v for k, v in p.items() if k.startswith("enc/")}
+    g, _, dstate = lstm_classifier_backward(p, cache["dec"], dlogits, dtype)
+    ge = lrcn_backward(pe, cache["enc"], dstate, fpc_frames, enc["layer"], enc["layers"], "state", dtype, "lstm", None)
+    g.update({"enc/" + k: v for k, v in ge.items()})
+    return g

@@ -57,6 +57,9 @@ SIGNATURES = {
     "vl_sgd_apply": (i32, [p, p, i64, f32, f32, p, f32, p]),
     "vl_adam_apply": (i32, [p, p, p, p, i64, f32, f32, p, f32, i32, p]),
     "vl_fill": (i32, [p, i64, f32, p]),
+    "vl_copy2d": (i32, [p, i64, p, i64, i32, i32, p]),
+    "vl_eltwise2": (i32, [p, p, p, i64, i32, p]),
+    "vl_max2_grad": (i32, [p, p, p, p, p, i64, p]),
     "vl_relu_grad": (i32, [p, p, i64, p]),
 }
 

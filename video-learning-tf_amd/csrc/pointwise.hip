@@ -1438,3 +1438,55 @@ extern "C" int vl_fill(float* p, int64_t count, float value, vl_stream_t stream)
     VL_LAUNCH_CHECK();
     return 0;
 }
+
+// ---- tensor-list plumbing of multi-input pipelines (tf_util.py:99-192) ----------------------------------------------------------
+// concat / vec_seq_concat / ibias / replicate_auxilliary_tensor are all strided block copies; avg / maximum are elementwise.
+__global__ void copy2d_kernel(const float* __restrict__ src, int64_t src_ld, float* __restrict__ dst, int64_t dst_ld, int rows,
+                              int cols) {
+    const int64_t total = (int64_t)rows * cols;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = e / cols, c = e - r * cols;
+        dst[r * dst_ld + c] = src[r * src_ld + c];
+    }
+}
+
+extern "C" int vl_copy2d(const float* src, int64_t src_ld, float* dst, int64_t dst_ld, int rows, int cols, vl_stream_t stream) {
+    VL_CHECK(src && dst && rows > 0 && cols > 0 && src_ld >= 0 && dst_ld >= cols, "vl_copy2d: bad argument");
+    hipLaunchKernelGGL(copy2d_kernel, dim3(grid_for((int64_t)rows * cols, 256, 4096)), dim3(256), 0, (hipStream_t)stream, src, src_ld, dst,
+                       dst_ld, rows, cols);
+    VL_LAUNCH_CHECK();
+    return 0;
+}
+
+// op 0: out = a + b;  1: out = (a + b) / 2 (tf.reduce_mean over two inputs);  2: out = max(a, b) (tf.reduce_max)
+__global__ void eltwise2_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int64_t count, int op) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (int64_t)gridDim.x * blockDim.x) {
+        const float x = a[e], y = b[e];
+        out[e] = op == 0 ? x + y : (op == 1 ? (x + y) * 0.5f : fmaxf(x, y));
+    }
+}
+
+extern "C" int vl_eltwise2(const float* a, const float* b, float* out, int64_t count, int op, vl_stream_t stream) {
+    VL_CHECK(a && b && out && count > 0 && op >= 0 && op <= 2, "vl_eltwise2: bad argument");
+    hipLaunchKernelGGL(eltwise2_kernel, dim3(grid_for(count, 256, 4096)), dim3(256), 0, (hipStream_t)stream, a, b, out, count, op);
+    VL_LAUNCH_CHECK();
+    return 0;
+}
+
+// gradient of max(a, b): the first maximum takes it (np.argmax / tf.reduce_max's gradient splits ties evenly in TF; ties have
+// measure zero for float activations and the oracle routes them to the first input, as here)
+__global__ void max2_grad_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ d,
+                                 float* __restrict__ da, float* __restrict__ db, int64_t count) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (int64_t)gridDim.x * blockDim.x) {
+        const bool first = a[e] >= b[e];
+        da[e] = first ? d[e] : 0.f;
+        db[e] = first ? 0.f : d[e];
+    }
+}
+
+extern "C" int vl_max2_grad(const float* a, const float* b, const float* d, float* da, float* db, int64_t count, vl_stream_t stream) {
+    VL_CHECK(a && b && d && da && db && count > 0, "vl_max2_grad: bad argument");
+    hipLaunchKernelGGL(max2_grad_kernel, dim3(grid_for(count, 256, 4096)), dim3(256), 0, (hipStream_t)stream, a, b, d, da, db, count);
+    VL_LAUNCH_CHECK();
+    return 0;
+}

@@ -123,7 +123,9 @@ def init_params(cfg: NetConfig, seed=0, stddev=0.05, well_scaled=False):
 class LRCNEngine:
     FC6_CHUNKS = 4          # row blocks of the fc6 weight gradient = all-reduce chunks of the data-parallel exchange
 
-    def __init__(self, cfg: NetConfig, max_clips: int, device="cuda:0", training=True, dp=None):
+    def __init__(self, cfg: NetConfig, max_clips: int, device="cuda:0", training=True, dp=None, flat=None):
+        """flat: optional (w, g) slices of a larger flat parameter / gradient buffer to live in (vltf_amd.composed: several
+        pipelines share one buffer so that the global-norm clip and the update run over all of them at once)."""
         if not torch.cuda.is_available():
             raise VltfError("LRCNEngine needs a HIP device; there is no CPU fallback")
         self.cfg, self.B, self.T = cfg, max_clips, cfg.fpc
@@ -141,8 +143,13 @@ class LRCNEngine:
         # ---- parameters: flat buffers + named views
         self.specs = param_specs(cfg)
         total = sum(int(np.prod(s)) for _, s in self.specs)
-        self.w = torch.zeros(total, device=dev)
-        self.g = torch.zeros(total, device=dev) if training else None
+        if flat is not None:
+            self.w, self.g = flat
+            if self.w.numel() != total or (training and self.g.numel() != total):
+                raise VltfError("flat parameter buffer has %d elements, the network needs %d" % (self.w.numel(), total))
+        else:
+            self.w = torch.zeros(total, device=dev)
+            self.g = torch.zeros(total, device=dev) if training else None
         self.P, self.G, self.offsets = {}, {}, {}
         off = 0
         for name, shp in self.specs:

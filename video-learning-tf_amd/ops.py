@@ -381,3 +381,24 @@ def relu_grad(d, y, count=None):
     """d = y > 0 ? d : 0 in place over the first `count` elements."""
     _f32(d, y); _dense(d, y)
     _ffi.call("vl_relu_grad", _p(d), _p(y), d.numel() if count is None else int(count), stream())
+
+
+# ---- tensor-list plumbing (tf_util.py:99-192) ----------------------------------------------------------------------------------
+def copy2d(src, dst, rows, cols, src_ld=None, dst_ld=None):
+    """dst[r, :cols] = src[r, :cols]; src / dst may be views (data_ptr + row strides are used); src_ld = 0 repeats one row."""
+    _f32(src, dst)
+    _ffi.call("vl_copy2d", _p(src), cols if src_ld is None else int(src_ld), _p(dst), cols if dst_ld is None else int(dst_ld),
+              int(rows), int(cols), stream())
+
+
+ELTWISE_OP = {"add": 0, "avg": 1, "maximum": 2}
+
+
+def eltwise2(a, b, out, op, count=None):
+    _f32(a, b, out)
+    _ffi.call("vl_eltwise2", _p(a), _p(b), _p(out), a.numel() if count is None else int(count), ELTWISE_OP[op], stream())
+
+
+def max2_grad(a, b, d, da, db, count=None):
+    _f32(a, b, d, da, db)
+    _ffi.call("vl_max2_grad", _p(a), _p(b), _p(d), _p(da), _p(db), a.numel() if count is None else int(count), stream())
