@@ -26,6 +26,7 @@ def oracle_params(rng, cfg, shape):
 
 @pytest.mark.parametrize("layer,layers,fusion,hid,math", [("fc6", 1, "avg", 8, "f32"), ("fc7", 2, "last", 12, "f32"),
                                                           ("fc8", 1, "avg", 7, "f32"), ("fc6", 2, "state", 9, "f32"),
+                                                          ("fc6", 1, "reshape", 8, "f32"), ("fc7", 2, "reshape", 7, "f32"),
                                                           ("fc6", 1, "avg", 8, "bf16x3"), ("fc6", 1, "avg", 8, "bf16x6")])
 def test_train_step_small(layer, layers, fusion, hid, math):
     """math="bf16x3": NetConfig.conv_math, the opt-in split-bf16 conv products -- same oracle, same tolerances."""
@@ -36,13 +37,14 @@ def test_train_step_small(layer, layers, fusion, hid, math):
     p = oracle_params(rng, cfg, shape)
     eng.load_params(p)
     frames = rng.integers(0, 256, (b * fpc,) + shape, dtype=np.uint8)
-    lab = rng.integers(0, ncls, b)
+    lab = rng.integers(0, ncls, b * fpc if fusion == "reshape" else b)     # reshape fusion (tf_util.py:26-27): a logits row per frame
     onehot = O.labels_to_one_hot([[l] for l in lab], ncls)
     x = frames.astype(np.float32) - MEAN
     newp, loss, gn, acc, logits, grads = O.lrcn_train_step(p, x, onehot, fpc, lr=0.01, clip_norm=0.5, final_layer=layer,
                                                           lstm_layers=layers, fusion=fusion)
     fd = torch.tensor(frames, device=DEV)
     got_fwd = eng.forward_u8(fd, MEAN).cpu().numpy()
+    assert got_fwd.shape == logits.shape
     np.testing.assert_allclose(got_fwd, logits, rtol=1e-3, atol=1e-3)
     out = eng.train_step_u8(fd, torch.tensor(onehot, device=DEV), lr=0.01, clip_norm=0.5, mean_bgr=MEAN)
     assert abs(out["loss"] - loss) < 1e-4 * max(1, abs(loss))

@@ -142,3 +142,61 @@ def test_validation_aggregation(tmp_path):
     with open(os.path.join(s.run_folder, files[0]), "rb") as f:
         stored = pickle.load(f)                                                       # written by this test
     assert stored.dtype == np.float32 and stored.shape == (5, 4)
+
+
+def test_vectors_dataset_and_two_pipeline_settings(tmp_path):
+    """`vectors` input mode (serialize.py:258-266, dataset_.py:137-168,709-714): float32 vector records with per-record labels,
+    read back batch by batch (per-clip labels = the first record's, per-record targets beside them), sharded, fast-forwarded;
+    and the YAML of a two-pipeline model (settings_.py:167-208: a pipeline name as the input of a later pipeline)."""
+    from vltf_amd import tfrecord
+    from vltf_amd.dataset_ import Dataset
+    folder = str(tmp_path)
+    rng = np.random.default_rng(0)
+    T, E, C = 4, 5, 7
+    seqs = [rng.standard_normal((T, E)).astype(np.float32) for _ in range(5)]
+    labels = [[[int(rng.integers(0, C))] for _ in range(T)] for _ in range(5)]
+    path = os.path.join(folder, "w.txt")
+    serialize.write_vector_dataset(path, seqs, labels, T, 1)
+    assert tfrecord.read_size_file(path + ".tfrecord.size") == {"items": 5, "type": "vectors", "cpv": [1] * 5, "fpc": T, "labelcount": 1}
+    d = Dataset()
+    d.initialize("w", path, None, None, None, [], None, defs.data_format.tfrecord, None, defs.batch_item.default, C, "main", 1)
+    d.calculate_batches(2, defs.input_mode.video)                       # the Feeder passes `video`; the size file decides
+    assert d.input_mode == defs.input_mode.vectors and d.vector_dim() == E and len(d.batches) == 3
+    vecs, cy, cx, mir, onehot = d.get_next_batch()
+    assert cy is None and vecs.shape == (2 * T, E) and np.array_equal(vecs, np.concatenate(seqs[:2]))
+    assert onehot.shape == (2, C) and onehot[0, labels[0][0][0]] == 1 and onehot[1, labels[1][0][0]] == 1
+    want = O.labels_to_one_hot([l for item in labels[:2] for l in item], C)
+    assert np.array_equal(d.record_onehot, want)
+    d.get_next_batch()
+    vecs, _, _, _, onehot = d.get_next_batch()                          # ragged last batch
+    assert vecs.shape == (T, E) and np.array_equal(vecs, seqs[4])
+    d.restore(1, 0)                                                     # resume at batch index 1
+    assert np.array_equal(d.get_next_batch()[0], np.concatenate(seqs[2:4]))
+    d.rewind()
+    d.set_shard(1, 2)                                                   # rank 1 of 2 reads the second item of each batch
+    assert np.array_equal(d.get_next_batch()[0], seqs[1]) and d.global_clips == 2
+    assert np.array_equal(d.get_next_batch()[0], seqs[3])
+
+    fpath, _, _ = make_dataset(folder, "f.txt")
+    cfg = yaml.safe_load(open(config(folder, fpath)))
+    cfg["run"]["data"]["d1"]["tag"] = "defs.dataset_tag.aux"
+    cfg["run"]["data"]["w"] = {"data_path": path, "data_format": "defs.data_format.tfrecord", "phase": "defs.phase.train",
+                               "tag": "defs.dataset_tag.main"}
+    cfg["run"]["network"]["num_classes"] = C
+    cfg["run"]["network"]["pipelines"] = [
+        {"enc": {"input": "defs.dataset_tag.aux", "representation": "defs.representation.dcnn", "frame_encoding_layer": "fc6",
+                 "classifier": "defs.classifier.lstm", "lstm_params": [8, 1, "defs.fusion_method.state"]}},
+        {"dec": {"input": ["defs.dataset_tag.main", "enc"], "representation": "defs.representation.fc", "fc_output_dim": 6,
+                 "classifier": "defs.classifier.lstm", "lstm_params": [10, 2, "defs.fusion_method.reshape"],
+                 "input_fusion": "defs.fusion_method.ibias"}}]
+    p2 = os.path.join(folder, "two.yml")
+    yaml.safe_dump(cfg, open(p2, "w"))
+    s = settings_.Settings()
+    s.initialize(p2)
+    assert s.pipeline_names == ["enc", "dec"] and s.pipelines["dec"].input == ["main", "enc"]
+    assert s.pipelines["dec"].input_fusion == "ibias" and s.pipelines["dec"].fc_output_dim == 6
+    assert s.pipelines["dec"].lstm_params == [10, 2, "reshape"]
+    cfg["run"]["network"]["pipelines"][1]["dec"]["input"] = ["defs.dataset_tag.main", "nosuch"]
+    yaml.safe_dump(cfg, open(p2, "w"))
+    with pytest.raises(Exception, match="not a dataset tag"):
+        settings_.Settings().initialize(p2)

@@ -202,6 +202,15 @@ class ComposedEngine:
         torch.cuda.synchronize(self.dev)
         return self.logits[:self._rows].detach().cpu().numpy().copy()
 
+    # checkpoints (feeder.py): same reserved keys as LRCNEngine
+    OPT_PREFIX = LRCNEngine.OPT_PREFIX
+    get_opt_state = LRCNEngine.get_opt_state
+    load_opt_state = LRCNEngine.load_opt_state
+
+    @property
+    def cfg(self):
+        return self.enc.cfg
+
     # ---- forward -------------------------------------------------------------------------------------------------------------------
     def _head_forward(self, words, b1, train):
         h, P, sc = self.h, self.P, self.scope2

@@ -28,6 +28,7 @@ class Dataset:
         self.batch_item, self.num_classes, self.read_tries = batch_item, num_classes, read_tries
         self.batch_index = self.epoch_index = 0
         self.batches, self.offset = None, 0
+        self._vec_iter = None
         self.frames, self.labels = [], []
         self.rng = random.Random()          # the reference uses the unseeded `random` module (dataset_.py:454,498)
         if data_format != defs.data_format.tfrecord:
@@ -61,7 +62,9 @@ class Dataset:
         if not os.path.exists(size_file):
             error("Could not file data size file: %s" % size_file)
         d = tfrecord.read_size_file(size_file)
-        if d["type"] != self.input_mode:
+        if d["type"] == defs.input_mode.vectors:
+            self.input_mode = defs.input_mode.vectors        # the size file decides (dataset_.py:709-714)
+        elif d["type"] != self.input_mode:
             error("Specified input mode is [%s] but the size file contains [%s]" % (self.input_mode, d["type"]))
         if d["cpv"] is None or d["fpc"] is None:
             error("Read cpi: %s / fpc: %s but input mode is %s" % (d["cpv"], d["fpc"], self.input_mode))
@@ -79,6 +82,11 @@ class Dataset:
 
     def initialize_imgproc(self):
         """dataset_.py:540-560 (+ build_mean_image 521-530: mean_image[0] is blue)."""
+        if self.input_mode == defs.input_mode.vectors:
+            if self.imgproc:
+                info("Ignoring imgproc due to input mode: [%s]" % self.input_mode)
+            self.imgproc, self.mean_bgr, self.crop_mode = [], None, None
+            return
         self.mean_bgr = np.asarray(self.mean_image, np.float32) if defs.imgproc.sub_mean in self.imgproc else None
         self.crop_mode = None
         if defs.imgproc.rand_crop in self.imgproc:
@@ -128,6 +136,39 @@ class Dataset:
     # ---- iteration ---------------------------------------------------------------------------------
     def reset_iterator(self):
         self.offset = 0
+        if getattr(self, "_vec_iter", None) is not None:
+            self._vec_iter.close()
+        self._vec_iter = None
+
+    def _read_vectors(self, count):
+        """deserialize_vector (dataset_.py:137-168): the next `count` vector records -> (float32 [count, dim], labels per record)."""
+        if self._vec_iter is None:
+            self._vec_iter = tfrecord.tf_record_iterator(self.record_path)
+        vecs, labels = [], []
+        for _ in range(count):
+            try:
+                payload = next(self._vec_iter)
+            except StopIteration:
+                break
+            try:
+                v, l = tfrecord.parse_vector_example(payload)
+            except Exception as ex:
+                warning(str(ex))
+                error("Error reading tfrecord vector.")
+            vecs.append(v)
+            labels.append(l)
+        if len(vecs) != count:
+            error("End of %s after %d of %d vector records" % (self.record_path, len(vecs), count))
+        return np.stack(vecs).astype(np.float32), labels
+
+    def vector_dim(self):
+        """Width of a vectors dataset (the `dimension` feature of its first record)."""
+        it = tfrecord.tf_record_iterator(self.record_path)
+        try:
+            v, _ = tfrecord.parse_vector_example(next(it))
+        finally:
+            it.close()
+        return int(v.size)
 
     def rewind(self):
         self.reset_iterator()
@@ -186,6 +227,22 @@ class Dataset:
         before, n = sum(fpc * c for c in cpv_all[:lo]), sum(fpc * c for c in cpv)
         after = n_all - before - n
         self.global_clips = sum(cpv_all)
+        if self.input_mode == defs.input_mode.vectors:
+            if self._vec_iter is None:
+                self._vec_iter = tfrecord.tf_record_iterator(self.record_path)
+            self._vec_iter.skip(before)
+            vecs, labels_per_frame = self._read_vectors(n) if n else (np.zeros((0, 1), np.float32), [])
+            self._vec_iter.skip(after)
+            labels, first = [], 0
+            for c in cpv:
+                labels.extend([labels_per_frame[first]] * c)            # one label set per clip: its first record's (dataset_.py:400-408)
+                first += c * fpc
+            # per-record targets as well (word-level cross-entropy of a per-step model: every record's own label)
+            self.record_onehot = labels_to_one_hot(labels_per_frame, self.num_classes) if labels_per_frame else \
+                np.zeros((0, self.num_classes), np.int32)
+            ground_truth = labels_to_one_hot(labels, self.num_classes) if labels else np.zeros((0, self.num_classes), np.int32)
+            self.batch_index += 1
+            return vecs, None, None, None, ground_truth
         if before:
             self.offset = _hostio.skip_records(self.record_path, self.offset, before)
         if n:
@@ -229,4 +286,9 @@ class Dataset:
         item_index = self.batch_index * self.batch_size
         num_forward = sum(self.clips_per_video[:item_index]) * self.num_frames_per_clip
         info("Fast forwarding to batch # %d/%d ( image # %d )" % (self.batch_index + 1, len(self.batches), num_forward + 1))
+        if self.input_mode == defs.input_mode.vectors:
+            self.reset_iterator()
+            self._vec_iter = tfrecord.tf_record_iterator(self.record_path)
+            self._vec_iter.skip(num_forward)
+            return
         self.offset = _hostio.skip_records(self.record_path, 0, num_forward)

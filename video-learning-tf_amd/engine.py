@@ -45,7 +45,7 @@ class NetConfig:
     classifier: str = "lstm"                    # defs.classifier.{lstm, fc}
     lstm_hidden: int = 256
     lstm_layers: int = 1
-    fusion: str = "avg"                         # lstm_params[2]: defs.fusion_method.{avg, last, state}
+    fusion: str = "avg"                         # lstm_params[2]: defs.fusion_method.{avg, last, reshape, state}
     frame_fusion: Optional[Tuple[str, str]] = None   # classifier fc: (early|late, avg|last) (model.py:103-106,149-151)
     dropout_keep_prob: float = 0.0              # <= 0 disables (lstm.py:52)
     optimizer: str = "sgd"                      # defs.optim.{sgd, adam}
@@ -255,10 +255,12 @@ class LRCNEngine:
             self.dfeat = self.df8 if self.df8 is not None else (self.df7 if self.df7 is not None else self.df6)
         # ---- classifier
         if cfg.classifier == "lstm":
-            if cfg.fusion not in ops.FUSION_CODE and cfg.fusion != "state":
-                raise VltfError("lstm fusion [%s] is not built (avg | last | state)" % cfg.fusion)
-            # `state` = final h of the last layer = its output at t = T-1 (full-length sequences, lstm.py:136), no dropout
+            if cfg.fusion not in ops.FUSION_CODE and cfg.fusion not in ("state", "reshape"):
+                raise VltfError("Undefined frame fusion type : %s" % cfg.fusion)          # tf_util.py:28-29
+            # `state` = final h of the last layer = its output at t = T-1 (full-length sequences, lstm.py:136), no dropout;
+            # `reshape` (tf_util.py:26-27) keeps every step: one logits row per frame, labels [clips * fpc, classes]
             self.lstm_fusion = "last" if cfg.fusion == "state" else cfg.fusion
+            self.per_step = cfg.fusion == "reshape"
             self.head = "fc_convert" if cfg.fusion == "state" else "output_fc"
             self.lstm = []
             for l in range(cfg.lstm_layers):
@@ -268,19 +270,23 @@ class LRCNEngine:
                 self.lstm.append(S)
             self.gh = buf(B, 4 * H)
             self.lstm_ws = ops.lstm_seq_ws(B, T, H, dev) if H <= 1024 else None
-            self.fused = buf(B, H)
-            self.dropped = buf(B, H)
-            self.drop_mask = buf(B, H, dtype=torch.uint8)
-            self.logits = buf(B, C) if H != C else self.dropped
+            R = N if self.per_step else B                             # logits rows
+            self.fused = buf(R, H)
+            self.dropped = buf(R, H)
+            self.drop_mask = buf(R, H, dtype=torch.uint8)
+            self.logits = buf(R, C) if H != C else self.dropped
             if training:
                 self.dh, self.dc = buf(B, H), buf(B, H)
-                self.dfused, self.ddropped = buf(B, H), buf(B, H)
+                self.dfused, self.ddropped = buf(R, H), buf(R, H)
         else:
             ff = cfg.frame_fusion
+            if ff and ff[0] in ("early", "late") and ff[1] not in ("avg", "last", "reshape"):
+                raise VltfError("Undefined frame fusion type : %s" % ff[1])              # apply_temporal_fusion, tf_util.py:28-29
+            if ff and ff[1] == "reshape":
+                ff = None        # aggregate_clip_vectors with `reshape` (tf_util.py:126-133,26-27): [N, d] -> [B, T, d] -> [N, d], the identity
             self.early = bool(ff and ff[0] == "early" and T > 1)
             self.late = bool(ff and ff[0] == "late" and T > 1)
-            if ff and ff[1] not in ops.FUSION_CODE:
-                raise VltfError("frame fusion method [%s] is not built (avg | last)" % ff[1])
+            self.ff_method = ff[1] if ff else None
             rows = B if self.early else N
             self.fc_in = buf(B, D) if self.early else self.feat
             self.fc_out = buf(rows, C) if D != C else self.fc_in
@@ -441,27 +447,32 @@ class LRCNEngine:
                         ops.lstm_step_fwd(S["gx"], self.gh if t > 0 else None, S["act"], S["cseq"], S["hseq"], S["hprev"], b, T,
                                           t, H, FORGET_BIAS)
                 xin, d = S["hseq"], H
-            ops.temporal_fusion_fwd(xin, self.fused, b, T, H, self.lstm_fusion)
-            v = self.fused
+            r = n if self.per_step else b
+            if self.per_step:
+                v = xin                                                  # every step's output of the last layer
+            else:
+                ops.temporal_fusion_fwd(xin, self.fused, b, T, H, self.lstm_fusion)
+                v = self.fused
             self._dropout = train and cfg.dropout_keep_prob > 0 and cfg.fusion != "state"
             if self._dropout:
-                ops.dropout_fwd(self.fused[:b], self.dropped[:b], self.drop_mask[:b], cfg.dropout_keep_prob,
+                ops.dropout_fwd(v[:r], self.dropped[:r], self.drop_mask[:r], cfg.dropout_keep_prob,
                                 (self.step_count << 20) ^ 0x5DEECE66D)
                 v = self.dropped
+            self._v = v
             if H != C:
-                ops.gemm(v, P[self.head + "_w"], self.logits, b, C, H, bias=P[self.head + "_b"])
+                ops.gemm(v, P[self.head + "_w"], self.logits, r, C, H, bias=P[self.head + "_b"])
             elif v is not self.logits:
-                self.logits[:b].copy_(v[:b])
-            self._rows = b
+                self.logits[:r].copy_(v[:r])
+            self._rows = r
         else:
             v, rows = self.feat, n
             if self.early:
-                ops.temporal_fusion_fwd(self.feat, self.fc_in, b, T, D, cfg.frame_fusion[1])
+                ops.temporal_fusion_fwd(self.feat, self.fc_in, b, T, D, self.ff_method)
                 v, rows = self.fc_in, b
             if D != C:
                 ops.gemm(v, P["fc_convert_w"], self.fc_out, rows, C, D, bias=P["fc_convert_b"])
             if self.late:
-                ops.temporal_fusion_fwd(self.fc_out, self.logits, b, T, C, cfg.frame_fusion[1])
+                ops.temporal_fusion_fwd(self.fc_out, self.logits, b, T, C, self.ff_method)
                 rows = b
             self._rows = rows
         return self._rows
@@ -484,18 +495,20 @@ class LRCNEngine:
         D, C, H, T = cfg.encode_dim(), cfg.num_classes, cfg.lstm_hidden, self.T
         sw = self.small_ws
         if cfg.classifier == "lstm":
-            d = self.dlogits
+            d, r = self.dlogits, self._rows
             if H != C:
-                v = self.dropped if self._dropout else self.fused
-                ops.gemm(v, self.dlogits, G[self.head + "_w"], H, C, b, transa=True)
-                ops.colsum(self.dlogits, G[self.head + "_b"], sw, b, C)
-                ops.gemm(self.dlogits, P[self.head + "_w"], self.ddropped, b, H, C, transb=True)
+                ops.gemm(self._v, self.dlogits, G[self.head + "_w"], H, C, r, transa=True)
+                ops.colsum(self.dlogits, G[self.head + "_b"], sw, r, C)
+                ops.gemm(self.dlogits, P[self.head + "_w"], self.ddropped, r, H, C, transb=True)
                 d = self.ddropped
             if self._dropout:
-                ops.dropout_bwd(d[:b], self.drop_mask[:b], self.dfused[:b], cfg.dropout_keep_prob)
+                ops.dropout_bwd(d[:r], self.drop_mask[:r], self.dfused[:r], cfg.dropout_keep_prob)
                 d = self.dfused
             top = self.lstm[-1]
-            ops.temporal_fusion_bwd(d, top["dout"], b, T, H, self.lstm_fusion)
+            if self.per_step:
+                top["dout"][:r].copy_(d[:r])
+            else:
+                ops.temporal_fusion_bwd(d, top["dout"], b, T, H, self.lstm_fusion)
             for l in reversed(range(cfg.lstm_layers)):
                 S = self.lstm[l]
                 pre = "rnn/multi_rnn_cell/cell_%d/basic_lstm_cell/" % l
@@ -521,7 +534,7 @@ class LRCNEngine:
         else:
             d, rows = self.dlogits, self._rows
             if self.late:
-                ops.temporal_fusion_bwd(self.dlogits, self.dfc_out, b, T, C, cfg.frame_fusion[1])
+                ops.temporal_fusion_bwd(self.dlogits, self.dfc_out, b, T, C, self.ff_method)
                 d, rows = self.dfc_out, b * T
             relu_mask = self.feat if (self.f8 is None and not self.early) else None
             target = self.dfc_in if self.early else self.dfeat
@@ -533,7 +546,7 @@ class LRCNEngine:
                 target[:rows].copy_(d[:rows])
             if self.early:
                 # ReluGrad of the encode layer applies per frame after un-fusing
-                ops.temporal_fusion_bwd(self.dfc_in, self.dfeat, b, T, D, cfg.frame_fusion[1])
+                ops.temporal_fusion_bwd(self.dfc_in, self.dfeat, b, T, D, self.ff_method)
                 if self.f8 is None:
                     ops.relu_grad(self.dfeat, self.feat, n * D)
         # ---- fc8 / fc7 / fc6 (dfeat already carries the ReluGrad of the encode layer)
@@ -638,7 +651,7 @@ class LRCNEngine:
 
     def _rows_for(self, b, n):
         if self.cfg.classifier == "lstm":
-            return b
+            return n if self.per_step else b
         return b if (self.early or self.late) else n
 
     def train_step_u8(self, frames_u8, onehot, lr, clip_norm=0.0, mean_bgr=None, crop_y=None, crop_x=None, mirror=None,

@@ -174,6 +174,10 @@ class Feeder:
             fdict = self.prefetch.next()
             return fdict, [len(fdict["frames_u8"])], len(fdict["labels"]), 0
         frames, cy, cx, mirror, onehot = d.get_next_batch()
+        if d.input_mode == defs.input_mode.vectors:            # float32 vectors instead of frames; per-record targets beside the per-clip ones
+            fdict = {"vectors": frames, "labels": onehot, "record_labels": d.record_onehot, "dataset": d, "batch_index": d.batch_index,
+                     "global_clips": d.global_clips}
+            return fdict, [len(frames)], len(onehot), 0
         fdict = {"frames_u8": frames, "crop_y": cy, "crop_x": cx, "mirror": mirror, "labels": onehot, "mean_bgr": d.mean_bgr,
                  "dataset": d, "batch_index": d.batch_index, "global_clips": d.global_clips}
         return fdict, [len(frames)], len(onehot), 0

@@ -45,3 +45,26 @@ def write_video_dataset(paths_file, videos, labels, fpc, clips_per_video):
                 w.write(tfrecord.frame_example(vid[k], lab))
     tfrecord.write_size_file(paths_file + ".tfrecord.size", len(videos), defs.input_mode.video, list(cpv), fpc, maxlab)
     info("Serialized %d videos to %s.tfrecord" % (len(videos), paths_file))
+
+
+def write_vector_dataset(paths_file, sequences, labels, fpc, clips_per_item=1):
+    """Vector-mode dataset (serialize.py:258-266,605-606; `.size` type `vectors`): sequences = list of float32 arrays
+    [clips * fpc, dim] (e.g. the word embeddings of a caption), labels = per item either ONE label list (stored with every record,
+    like a video's label) or a list of per-record label lists (word-level targets)."""
+    cpv = clips_per_item if isinstance(clips_per_item, (list, tuple)) else [clips_per_item] * len(sequences)
+    maxlab = 1
+    with open(paths_file, "w") as f:
+        for i in range(len(sequences)):
+            f.write("item_%04d\n" % i)
+    with tfrecord.TFRecordWriter(paths_file + ".tfrecord") as w:
+        for seq, lab, c in zip(sequences, labels, cpv):
+            seq = np.asarray(seq, np.float32)
+            if len(seq) != c * fpc:
+                error("vector item has %d records, needs %d" % (len(seq), c * fpc))
+            per_record = len(lab) == len(seq) and all(isinstance(x, (list, tuple, np.ndarray)) for x in lab)
+            for k in range(len(seq)):
+                l = list(lab[k]) if per_record else (list(lab) if isinstance(lab, (list, tuple, np.ndarray)) else [lab])
+                maxlab = max(maxlab, len(l))
+                w.write(tfrecord.vector_example(seq[k], l))
+    tfrecord.write_size_file(paths_file + ".tfrecord.size", len(sequences), defs.input_mode.vectors, list(cpv), fpc, maxlab)
+    info("Serialized %d vector items to %s.tfrecord" % (len(sequences), paths_file))

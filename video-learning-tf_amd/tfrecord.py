@@ -248,6 +248,24 @@ def parse_frame_example(payload):
     return img, list(ex["label"])
 
 
+def vector_example(vector, label):
+    """serialize_vectors_to_tfrecord (serialize.py:258-266): one float32 vector -> Example payload
+    {dimension, label, vector_raw}."""
+    v = np.ascontiguousarray(vector, np.float32).ravel()
+    label = list(label) if isinstance(label, (list, tuple, np.ndarray)) else [label]
+    return encode_example({"dimension": int(v.size), "label": [int(l) for l in label], "vector_raw": v.tobytes()})
+
+
+def parse_vector_example(payload):
+    """deserialize_vector (dataset_.py:137-168): -> (float32 [dim] view, label list); the stored dimension must match."""
+    ex = decode_example(payload)
+    vec = np.frombuffer(ex["vector_raw"][0], np.float32)
+    dim = int(ex["dimension"][0])
+    if dim != len(vec):
+        raise ValueError("Deserialized vector length %d but dimension stored is %d." % (len(vec), dim))
+    return vec, list(ex["label"])
+
+
 # ---- .size sidecar -----------------------------------------------------------------------------------------
 def write_size_file(path, num_items, mode, clips_per_item, fpc, max_num_labels):
     """serialize.py:138-151; cpi is run-length encoded [(count, cpv), ...]."""

@@ -43,6 +43,12 @@ class Validation:
             error("Logits and/or labels non empty at the end of video item mode aggregation!")
         info("Incremental accuracy up to current batch: %2.3f" % np.mean(self.get_chunk_accuracy(self.item_logits, self.item_labels)))
 
+    def add_items(self, logits, labels):
+        """Logit rows that are items of their own (per-step logits of a `reshape`-fusion model: no clip -> video fusion)."""
+        self.item_logits = np.vstack((self.item_logits, np.asarray(logits, np.float32)))
+        self.item_labels = np.vstack((self.item_labels, np.asarray(labels, np.float32)))
+        info("Incremental accuracy up to current batch: %2.3f" % np.mean(self.get_chunk_accuracy(self.item_logits, self.item_labels)))
+
     def save_validation_logits_chunk(self, save_all=False):
         """val.py:115-148: '<run_folder>/validation_logits_<run_id>_<ts>.total' or '.part_k'."""
         if self.save_interval is None or len(self.item_logits) == 0:
