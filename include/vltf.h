@@ -201,6 +201,17 @@ int vl_transpose(const float* src, int64_t ld, float* dst, int rows, int cols, v
 int vl_temporal_fusion_fwd(const float* x, float* y, int batch, int T, int H, int method, vl_stream_t stream);
 int vl_temporal_fusion_bwd(const float* dy, float* dx, int batch, int T, int H, int method, vl_stream_t stream);
 
+/* ---- imresize: scipy.misc.imresize(image, shape) of Dataset.process_image (dataset_.py:481-495: imgproc `raw_resize` to the raw
+ * shape, `resize` to the network input size; also serialize.py:424-425) = PIL Image.resize(BILINEAR) on uint8, bit-exact:
+ * Pillow's two-pass fixed-point resample (22-bit coefficients, uint8 intermediate, horizontal pass first; csrc/resize.hip).
+ * The descriptor holds the coefficient tables of one (h, w) -> (oh, ow) pair on the device.  Images are uint8 [n][h][w][3] (HWC). */
+typedef struct vl_resize_desc vl_resize_desc;
+int vl_resize_create(vl_resize_desc** out, int h, int w, int oh, int ow, int channels);
+void vl_resize_destroy(vl_resize_desc* d);
+/* bytes of the uint8 intermediate vl_resize_u8 needs for n images (0 when at most one axis changes size) */
+size_t vl_resize_tmp_bytes(const vl_resize_desc* d, int n);
+int vl_resize_u8(const vl_resize_desc* d, const uint8_t* src, uint8_t* tmp, uint8_t* dst, int n, vl_stream_t stream);
+
 /* ---- tensor-list plumbing of multi-input pipelines (tf_util.py:99-192) ------------------------------------------------
  * vl_copy2d: dst[r][c] = src[r][c] for r < rows, c < cols with row strides src_ld / dst_ld (src_ld 0 repeats one row).
  * tf.concat / vec_seq_concat (tf_util.py:99-124), the ibias insertion (tf_util.py:154-176) and replicate_auxilliary_tensor

@@ -834,3 +834,65 @@ def encdec_backward(p, cache, dlogits, fpc_frames, enc, dtype=F64):
     ge = lrcn_backward(pe, cache["enc"], dstate, fpc_frames, enc["layer"], enc["layers"], "state", dtype, "lstm", None)
     g.update({"enc/" + k: v for k, v in ge.items()})
     return g
+
+
+# ----------------------------------------------------------------------------------------------
+# imresize -- dataset_.py:481-495, serialize.py:424-425: scipy.misc.imresize(image, shape) = PIL's Image.resize((w, h), BILINEAR) on
+# the uint8 array (scipy < 1.2: toimage(arr).resize(size, resample=2)).  Restated from Pillow's published algorithm
+# (libImaging/Resample.c: precompute_coeffs, normalize_coeffs_8bpc, ImagingResampleHorizontal_8bpc / Vertical_8bpc) and pinned
+# bit for bit against the installed Pillow in tests/test_resize.py.
+# ----------------------------------------------------------------------------------------------
+RESIZE_PRECISION_BITS = 32 - 8 - 2
+
+
+def pil_bilinear_coeffs(in_size, out_size):
+    """precompute_coeffs + normalize_coeffs_8bpc for the triangle filter (support 1) over the full axis (box = 0 .. in_size).
+    -> (bounds int32 [out, 2] = (first input index, tap count), coefficients int32 [out, ksize] in 2^-22 units, ksize)."""
+    scale = float(np.float32(in_size) - np.float32(0.0)) / out_size          # in0, in1 are C floats
+    filterscale = max(scale, 1.0)
+    support = 1.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    bounds = np.zeros((out_size, 2), np.int32)
+    kk = np.zeros((out_size, ksize), np.int32)
+    ss = 1.0 / filterscale
+    for xx in range(out_size):
+        center = 0.0 + (xx + 0.5) * scale
+        xmin = max(int(center - support + 0.5), 0)
+        xmax = min(int(center + support + 0.5), in_size) - xmin
+        w = []
+        ww = 0.0
+        for x in range(xmax):
+            v = (x + xmin - center + 0.5) * ss
+            v = -v if v < 0.0 else v
+            wt = 1.0 - v if v < 1.0 else 0.0
+            w.append(wt)
+            ww += wt
+        for x in range(xmax):
+            k = w[x] / ww if ww != 0.0 else w[x]
+            kk[xx, x] = int(-0.5 + k * (1 << RESIZE_PRECISION_BITS)) if k < 0 else int(0.5 + k * (1 << RESIZE_PRECISION_BITS))
+        bounds[xx] = (xmin, xmax)
+    return bounds, kk, ksize
+
+
+def _resample_axis(img, out_size, axis):
+    """One 8-bit pass: out = clip8((2^21 + sum_k pixel * coeff) >> 22) along `axis` of a uint8 array."""
+    bounds, kk, ksize = pil_bilinear_coeffs(img.shape[axis], out_size)
+    src = np.moveaxis(img, axis, 0).astype(np.int64)
+    out = np.empty((out_size,) + src.shape[1:], np.uint8)
+    for xx in range(out_size):
+        x0, n = bounds[xx]
+        acc = np.tensordot(kk[xx, :n].astype(np.int64), src[x0:x0 + n], axes=(0, 0)) + (1 << (RESIZE_PRECISION_BITS - 1))
+        out[xx] = np.clip(acc >> RESIZE_PRECISION_BITS, 0, 255).astype(np.uint8)
+    return np.moveaxis(out, 0, axis)
+
+
+def imresize_bilinear_u8(img, out_hw):
+    """scipy.misc.imresize(img, (h, w, c)) for a uint8 [H, W, C] image: Pillow's two-pass resample, horizontal pass first (into a
+    uint8 intermediate), then vertical; an axis whose size does not change is skipped (ImagingResample: need_horizontal /
+    need_vertical), so an image already at the target size comes back unchanged."""
+    out = img
+    if out_hw[1] != img.shape[1]:
+        out = _resample_axis(out, out_hw[1], 1)
+    if out_hw[0] != img.shape[0]:
+        out = _resample_axis(out, out_hw[0], 0)
+    return out

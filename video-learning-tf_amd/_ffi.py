@@ -57,6 +57,10 @@ SIGNATURES = {
     "vl_sgd_apply": (i32, [p, p, i64, f32, f32, p, f32, p]),
     "vl_adam_apply": (i32, [p, p, p, p, i64, f32, f32, p, f32, i32, p]),
     "vl_fill": (i32, [p, i64, f32, p]),
+    "vl_resize_create": (i32, [C.POINTER(p), i32, i32, i32, i32, i32]),
+    "vl_resize_destroy": (None, [p]),
+    "vl_resize_tmp_bytes": (sz, [p, i32]),
+    "vl_resize_u8": (i32, [p, p, p, p, i32, p]),
     "vl_copy2d": (i32, [p, i64, p, i64, i32, i32, p]),
     "vl_eltwise2": (i32, [p, p, p, i64, i32, p]),
     "vl_max2_grad": (i32, [p, p, p, p, p, i64, p]),

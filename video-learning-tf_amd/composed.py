@@ -271,9 +271,9 @@ class ComposedEngine:
         self._rows = rows
         return rows
 
-    def forward(self, frames_u8, words, mean_bgr=None, crop_y=None, crop_x=None, mirror=None):
+    def forward(self, frames_u8, words, mean_bgr=None, crop_y=None, crop_x=None, mirror=None, resize=None):
         """sess.run(model.logits, fdict) for the two-pipeline model.  words: device float32 [clips * fpc, in_dim]."""
-        n, b1 = self.enc.feed_u8(frames_u8, mean_bgr, crop_y, crop_x, mirror)
+        n, b1 = self.enc.feed_u8(frames_u8, mean_bgr, crop_y, crop_x, mirror, resize)
         self.enc._forward(n, b1, train=False)
         rows = self._head_forward(words, b1, train=False)
         return self.logits[:rows]
@@ -355,12 +355,12 @@ class ComposedEngine:
 
     # ---- train step ------------------------------------------------------------------------------------------------------------------
     def train_step(self, frames_u8, words, onehot, lr, clip_norm=0.0, mean_bgr=None, crop_y=None, crop_x=None, mirror=None,
-                   fetch=True, global_rows=None):
+                   fetch=True, global_rows=None, resize=None):
         """sess.run([.., loss, .., optimizer], fdict): labels int32 one-hot [rows, classes], rows = clips (fusion avg | last |
         state) or clips * steps (fusion reshape: one row per time step, clip-major)."""
         if not self.training:
             raise VltfError("engine was built with training=False")
-        n, b1 = self.enc.feed_u8(frames_u8, mean_bgr, crop_y, crop_x, mirror)
+        n, b1 = self.enc.feed_u8(frames_u8, mean_bgr, crop_y, crop_x, mirror, resize)
         self.enc.step_count = self.step_count
         self.enc._forward(n, b1, train=True)
         self._words = words

@@ -85,7 +85,7 @@ class Dataset:
         if self.input_mode == defs.input_mode.vectors:
             if self.imgproc:
                 info("Ignoring imgproc due to input mode: [%s]" % self.input_mode)
-            self.imgproc, self.mean_bgr, self.crop_mode = [], None, None
+            self.imgproc, self.mean_bgr, self.crop_mode, self.resize_chain = [], None, None, []
             return
         self.mean_bgr = np.asarray(self.mean_image, np.float32) if defs.imgproc.sub_mean in self.imgproc else None
         self.crop_mode = None
@@ -93,11 +93,23 @@ class Dataset:
             self.crop_mode = defs.imgproc.rand_crop
         elif defs.imgproc.center_crop in self.imgproc:
             self.crop_mode = defs.imgproc.center_crop
-        elif defs.imgproc.resize in self.imgproc:
-            error("imgproc resize (scipy imresize) is not on the device path; serialize at the network size instead")
         if self.raw_image_shape is None:
             self.raw_image_shape = self.desired_image_shape
-        if self.crop_mode is None and tuple(self.raw_image_shape) != tuple(self.desired_image_shape):
+        # imresize steps of process_image (dataset_.py:481-495), run on the device (vl_resize_u8, PIL bilinear bit for bit):
+        # `raw_resize`: stored frame -> raw_image_shape, then crop; `resize`: -> the network input size instead of a crop
+        self.stored_image_shape = tuple(self.raw_image_shape)
+        self.resize_chain = []
+        if defs.imgproc.raw_resize in self.imgproc:
+            it = tfrecord.tf_record_iterator(self.record_path)
+            try:
+                img, _ = tfrecord.parse_frame_example(next(it))
+            finally:
+                it.close()
+            self.stored_image_shape = tuple(img.shape)
+            self.resize_chain.append((tuple(img.shape[:2]), tuple(self.raw_image_shape[:2])))
+        if defs.imgproc.resize in self.imgproc and self.crop_mode is None:
+            self.resize_chain.append((tuple(self.raw_image_shape[:2]), tuple(self.desired_image_shape[:2])))
+        elif self.crop_mode is None and tuple(self.raw_image_shape) != tuple(self.desired_image_shape):
             error("Encountered image shape %s but desired shape is %s" % (self.raw_image_shape, self.desired_image_shape))
         if self.crop_mode:
             self.crop_h, self.crop_w = self.compute_crop(self.raw_image_shape, self.desired_image_shape, self.crop_mode)
@@ -183,7 +195,7 @@ class Dataset:
         tries = 0
         while True:
             try:
-                imgs, labels, self.offset = _hostio.read_frames(self.record_path, self.offset, count, self.raw_image_shape,
+                imgs, labels, self.offset = _hostio.read_frames(self.record_path, self.offset, count, self.stored_image_shape,
                                                                 out=None if out is None else out[:count])
                 return imgs, labels
             except EOFError as ex:
@@ -248,7 +260,7 @@ class Dataset:
         if n:
             frames, labels_per_frame = self._read(n, out)      # out: caller's (pinned) uint8 buffer [>= n, H, W, C]
         else:                                                  # fewer videos than ranks in a short last batch
-            frames, labels_per_frame = np.empty((0,) + tuple(self.raw_image_shape), np.uint8), []
+            frames, labels_per_frame = np.empty((0,) + tuple(self.stored_image_shape), np.uint8), []
         if after:
             self.offset = _hostio.skip_records(self.record_path, self.offset, after)
         labels, first = [], 0

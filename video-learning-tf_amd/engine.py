@@ -300,6 +300,7 @@ class LRCNEngine:
         self.stats = torch.zeros(2, device=dev)
         self.ss = torch.zeros(1, device=dev)
         self.probe, self.probe_events = None, []
+        self._resizers = {}
         self.mean_dev = torch.zeros(3, device=dev)
 
     # ---- live kernel timing (bench.py roofline): HIP events around labelled launches -------------
@@ -390,10 +391,16 @@ class LRCNEngine:
             raise VltfError("got %d frames: need a positive multiple of fpc=%d, at most %d" % (n, self.T, self.N))
         return n // self.T
 
-    def feed_u8(self, frames_u8, mean_bgr=None, crop_y=None, crop_x=None, mirror=None):
-        """frames uint8 [n, raw_h, raw_w, 3] on device (TFRecord image_raw bytes) -> x0 (dataset_.py:481-501)."""
+    def feed_u8(self, frames_u8, mean_bgr=None, crop_y=None, crop_x=None, mirror=None, resize=None):
+        """frames uint8 [n, raw_h, raw_w, 3] on device (TFRecord image_raw bytes) -> x0 (dataset_.py:481-501).
+        resize: [((h, w), (oh, ow)), ...] imresize steps applied first (imgproc raw_resize / resize: PIL bilinear on uint8)."""
         n = frames_u8.shape[0]
         b = self._check_frames(n)
+        for src_hw, dst_hw in (resize or ()):
+            key = (tuple(src_hw), tuple(dst_hw))
+            if key not in self._resizers:
+                self._resizers[key] = ops.Resize(src_hw[0], src_hw[1], dst_hw[0], dst_hw[1])
+            frames_u8 = self._resizers[key](frames_u8)
         mean = None
         if mean_bgr is not None:
             self.mean_dev.copy_(torch.as_tensor(np.asarray(mean_bgr, np.float32)), non_blocking=True)
@@ -477,9 +484,9 @@ class LRCNEngine:
             self._rows = rows
         return self._rows
 
-    def forward_u8(self, frames_u8, mean_bgr=None, crop_y=None, crop_x=None, mirror=None):
+    def forward_u8(self, frames_u8, mean_bgr=None, crop_y=None, crop_x=None, mirror=None, resize=None):
         """sess.run(model.logits, fdict) (run_task.py:95).  Returns a device view [rows, classes]."""
-        n, b = self.feed_u8(frames_u8, mean_bgr, crop_y, crop_x, mirror)
+        n, b = self.feed_u8(frames_u8, mean_bgr, crop_y, crop_x, mirror, resize)
         rows = self._forward(n, b, train=False)
         return self.logits[:rows]
 
@@ -655,9 +662,9 @@ class LRCNEngine:
         return b if (self.early or self.late) else n
 
     def train_step_u8(self, frames_u8, onehot, lr, clip_norm=0.0, mean_bgr=None, crop_y=None, crop_x=None, mirror=None,
-                      fetch=True, global_rows=None):
+                      fetch=True, global_rows=None, resize=None):
         """sess.run([summaries, loss, lr, global_step, optimizer], fdict) (run_task.py:44)."""
-        n, b = self.feed_u8(frames_u8, mean_bgr, crop_y, crop_x, mirror)
+        n, b = self.feed_u8(frames_u8, mean_bgr, crop_y, crop_x, mirror, resize)
         return self._train(n, b, onehot, lr, clip_norm, fetch, global_rows)
 
     def train_step_f32(self, frames_nhwc, onehot, lr, clip_norm=0.0, fetch=True):

@@ -29,7 +29,7 @@ class BatchPrefetcher:
         self.torch, self.d, self.device, self.depth = torch, dataset, torch.device(device), max(1, int(depth))
         self.consumed = dataset.batch_index
         self.q, self.thread, self.stop_flag = None, None, None
-        h, w, c = dataset.raw_image_shape
+        h, w, c = dataset.stored_image_shape
         nmax = max(dataset.frames_in_batch(b) for b in range(len(dataset.batches))) if dataset.batches else 0
         self.slots = []
         # batch j trains while j+1 .. j+depth wait in the queue and the producer fills j+depth+1: depth + 2 live batches
@@ -54,7 +54,7 @@ class BatchPrefetcher:
                     ev = torch.cuda.Event()
                     ev.record(self.copy_stream)
                 item = {"frames_u8": frames, "crop_y": cy, "crop_x": cx, "mirror": mirror, "labels": onehot, "mean_bgr": d.mean_bgr,
-                        "dataset": d, "batch_index": d.batch_index, "global_clips": d.global_clips, "device": dict(dev, frames_u8=slot["dev"][:n]), "ready": ev}
+                        "resize": d.resize_chain, "dataset": d, "batch_index": d.batch_index, "global_clips": d.global_clips, "device": dict(dev, frames_u8=slot["dev"][:n]), "ready": ev}
                 k += 1
                 while not stop.is_set():
                     try:
@@ -179,7 +179,7 @@ class Feeder:
                      "global_clips": d.global_clips}
             return fdict, [len(frames)], len(onehot), 0
         fdict = {"frames_u8": frames, "crop_y": cy, "crop_x": cx, "mirror": mirror, "labels": onehot, "mean_bgr": d.mean_bgr,
-                 "dataset": d, "batch_index": d.batch_index, "global_clips": d.global_clips}
+                 "resize": d.resize_chain, "dataset": d, "batch_index": d.batch_index, "global_clips": d.global_clips}
         return fdict, [len(frames)], len(onehot), 0
 
     # ---- save cadence (feeder.py:111-129) ---------------------------------------------------------------

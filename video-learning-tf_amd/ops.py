@@ -402,3 +402,36 @@ def eltwise2(a, b, out, op, count=None):
 def max2_grad(a, b, d, da, db, count=None):
     _f32(a, b, d, da, db)
     _ffi.call("vl_max2_grad", _p(a), _p(b), _p(d), _p(da), _p(db), a.numel() if count is None else int(count), stream())
+
+
+# ---- imresize (dataset_.py:481-495) ---------------------------------------------------------------------------------------------
+class Resize:
+    """scipy.misc.imresize(image, (oh, ow, 3)) = PIL bilinear on uint8 [n, h, w, 3] device images (vl_resize_*), bit-exact."""
+
+    def __init__(self, h, w, oh, ow):
+        self.h, self.w, self.oh, self.ow = int(h), int(w), int(oh), int(ow)
+        self._d = C.c_void_p()
+        _ffi.check(_ffi.lib().vl_resize_create(C.byref(self._d), self.h, self.w, self.oh, self.ow, 3), "vl_resize_create")
+        self._tmp = None
+
+    def __del__(self):
+        try:
+            if self._d:
+                _ffi.lib().vl_resize_destroy(self._d)
+                self._d = None
+        except Exception:
+            pass
+
+    def __call__(self, src, dst=None):
+        if src.dtype != torch.uint8 or not src.is_cuda or not src.is_contiguous() or tuple(src.shape[1:]) != (self.h, self.w, 3):
+            raise _ffi.VltfError("resize: expected contiguous device uint8 [n, %d, %d, 3], got %s" % (self.h, self.w, tuple(src.shape)))
+        n = src.shape[0]
+        if dst is None:
+            dst = torch.empty((n, self.oh, self.ow, 3), dtype=torch.uint8, device=src.device)
+        elif dst.dtype != torch.uint8 or tuple(dst.shape) != (n, self.oh, self.ow, 3) or not dst.is_contiguous():
+            raise _ffi.VltfError("resize: destination must be contiguous uint8 %s" % ((n, self.oh, self.ow, 3),))
+        need = int(_ffi.lib().vl_resize_tmp_bytes(self._d, n))
+        if need and (self._tmp is None or self._tmp.numel() < need):
+            self._tmp = torch.empty(need, dtype=torch.uint8, device=src.device)
+        _ffi.call("vl_resize_u8", self._d, _p(src), _p(self._tmp) if need else None, _p(dst), n, stream())
+        return dst

@@ -156,11 +156,12 @@ def do_test(settings, val, feeder, engine, rank=0, world=1):
         elif "device" in fdict:          # read and uploaded ahead by the feeder's BatchPrefetcher
             torch.cuda.current_stream(dev).wait_event(fdict["ready"])
             t = fdict["device"]
-            logits = engine.forward_u8(t["frames_u8"], fdict["mean_bgr"], t["crop_y"], t["crop_x"], t["mirror"]).cpu().numpy()
+            logits = engine.forward_u8(t["frames_u8"], fdict["mean_bgr"], t["crop_y"], t["crop_x"], t["mirror"],
+                                       resize=fdict.get("resize")).cpu().numpy()
         else:
             logits = engine.forward_u8(torch.from_numpy(fdict["frames_u8"]).to(dev), fdict["mean_bgr"],
                                        torch.from_numpy(fdict["crop_y"]).to(dev), torch.from_numpy(fdict["crop_x"]).to(dev),
-                                       torch.from_numpy(fdict["mirror"]).to(dev)).cpu().numpy()
+                                       torch.from_numpy(fdict["mirror"]).to(dev), resize=fdict.get("resize")).cpu().numpy()
         labels = fdict["labels"].astype(np.float32)
         if world > 1:
             parts = [None] * world

@@ -77,13 +77,13 @@ class Train:
             torch.cuda.current_stream(dev).wait_event(fdict["ready"])
             t = fdict["device"]
             out = eng.train_step_u8(t["frames_u8"], t["labels"], lr, self.clip_norm, fdict["mean_bgr"], t["crop_y"], t["crop_x"],
-                                    t["mirror"], global_rows=grows)
+                                    t["mirror"], global_rows=grows, resize=fdict.get("resize"))
         else:
             out = eng.train_step_u8(torch.from_numpy(fdict["frames_u8"]).to(dev, non_blocking=True),
                                     torch.from_numpy(fdict["labels"]).to(dev),
                                     lr, self.clip_norm, fdict["mean_bgr"],
                                     torch.from_numpy(fdict["crop_y"]).to(dev), torch.from_numpy(fdict["crop_x"]).to(dev),
-                                    torch.from_numpy(fdict["mirror"]).to(dev), global_rows=grows)
+                                    torch.from_numpy(fdict["mirror"]).to(dev), global_rows=grows, resize=fdict.get("resize"))
         if dpg is not None:              # log the global-batch loss, not the shard's
             tot = dpg.sum_scalars(torch.tensor([out["loss_sum"], out["correct"], float(out["rows"])], device=dev, dtype=torch.float64))
             tot = tot.cpu().numpy()
