@@ -200,3 +200,42 @@ def test_vectors_dataset_and_two_pipeline_settings(tmp_path):
     yaml.safe_dump(cfg, open(p2, "w"))
     with pytest.raises(Exception, match="not a dataset tag"):
         settings_.Settings().initialize(p2)
+
+
+def test_weights_file_dict_npy_is_read_without_running_code(tmp_path):
+    """alexnet.py:50-52: the pickled {layer: [W, b]} dict of bvlc_alexnet.npy.  Read by an arrays-only unpickler: the arrays come
+    back bit for bit under their TF variable names, a pickle that names anything else is refused before it can run."""
+    import pickle
+    from vltf_amd.run_task import load_weights_file
+    rng = np.random.default_rng(0)
+    net = {"conv1": [rng.standard_normal((11, 11, 3, 96)).astype(np.float32), rng.standard_normal(96).astype(np.float32)],
+           "fc6": [rng.standard_normal((16, 8)).astype(np.float32), np.zeros(8, np.float32)]}
+    path = str(tmp_path / "net.npy")
+    np.save(path, np.array(net, dtype=object), allow_pickle=True)               # a file this test wrote, in the reference's layout
+    got = load_weights_file(path)
+    assert sorted(got) == ["dcnn/conv1W", "dcnn/conv1b", "dcnn/fc6W", "dcnn/fc6b"]
+    assert np.array_equal(got["dcnn/conv1W"], net["conv1"][0]) and np.array_equal(got["dcnn/fc6b"], net["fc6"][1])
+    # python-2 style pickle (protocol 2, the age of bvlc_alexnet.npy) loads too
+    path2 = str(tmp_path / "net2.npy")
+    with open(path2, "wb") as f:
+        np.lib.format.write_array_header_1_0(f, {"descr": "|O", "fortran_order": False, "shape": ()})
+        pickle.dump(net, f, protocol=2)
+    assert np.array_equal(load_weights_file(path2)["dcnn/conv1b"], net["conv1"][1])
+    # anything but array reconstruction is refused
+    evil = str(tmp_path / "evil.npy")
+    marker = str(tmp_path / "pwned")
+
+    class Evil:
+        def __reduce__(self):
+            import os as _os
+            return (_os.system, ("touch %s" % marker,))
+    with open(evil, "wb") as f:
+        np.lib.format.write_array_header_1_0(f, {"descr": "|O", "fortran_order": False, "shape": ()})
+        pickle.dump({"conv1": [Evil(), Evil()]}, f, protocol=2)
+    with pytest.raises(Exception, match="refused"):
+        load_weights_file(evil)
+    assert not os.path.exists(marker)
+    # npz keyed by TF names, no pickle at all
+    npz = str(tmp_path / "w.npz")
+    np.savez(npz, **{"dcnn/conv1W": net["conv1"][0]})
+    assert np.array_equal(load_weights_file(npz)["dcnn/conv1W"], net["conv1"][0])

@@ -3,6 +3,7 @@ MI355X engine.  Same YAML, same TFRecord/.size inputs, same log lines and result
 import argparse
 import math
 import os
+import pickle
 import time
 
 import numpy as np
@@ -82,13 +83,55 @@ def composed_config(settings, feeder):
     return pipeline_net_config(settings, p1, d1), head, d1, d2, (n1, n2)
 
 
+class _ArraysOnlyUnpickler(pickle.Unpickler):
+    """Unpickler for the reference's weights file: admits the reconstruction of numpy arrays / dtypes / scalars and nothing
+    else -- no other global can be looked up, so no code from the file can run."""
+    ALLOWED = {("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"), ("numpy", "ndarray"),
+               ("numpy", "dtype"), ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar")}
+
+    def find_class(self, module, name):
+        if (module, name) in self.ALLOWED:
+            import importlib
+            mod = importlib.import_module("numpy._core.multiarray" if module.endswith("multiarray") else module)
+            return getattr(mod, name)
+        raise pickle.UnpicklingError("weights file refers to %s.%s: only numpy arrays are admitted" % (module, name))
+
+
 def load_weights_file(path):
-    """alexnet.py:50-52: numpy dict {layer: [W, b]} (bvlc_alexnet.npy layout) -> tf variable names.  Loaded without
-    pickle execution only if it is an .npz; the pickled .npy dict of the reference needs allow_pickle and is refused."""
-    if not path.endswith(".npz"):
-        error("weights_file must be an .npz of arrays named like the TF variables (a pickled .npy is not loaded)")
-    with np.load(path, allow_pickle=False) as z:
-        return {k: z[k] for k in z.files}
+    """alexnet.py:50-52,69-71: `numpy.load(weights_file, encoding="latin1").item()` -- the bvlc_alexnet.npy layout, a pickled
+    dict {layer: [W, b]} (conv W in HWIO, fc W [in, out]) inside an object-dtype .npy -- -> {tf variable name: array}.
+    The pickle stream is read by an unpickler that can only rebuild numpy arrays (_ArraysOnlyUnpickler).  An .npz of arrays named
+    like the TF variables (dcnn/conv1W, ...) loads without any pickle."""
+    if path.endswith(".npz"):
+        with np.load(path, allow_pickle=False) as z:
+            return {k: z[k] for k in z.files}
+    with open(path, "rb") as f:
+        try:
+            version = np.lib.format.read_magic(f)
+            shape, _, dtype = np.lib.format.read_array_header_1_0(f) if version == (1, 0) else np.lib.format.read_array_header_2_0(f)
+        except ValueError as ex:
+            error("weights_file %s is not a .npy / .npz file: %s" % (path, ex))
+        if dtype.hasobject:
+            if shape != ():
+                error("weights_file %s: expected a 0-d object array holding the {layer: [W, b]} dict" % path)
+            try:
+                net_data = _ArraysOnlyUnpickler(f, encoding="latin1").load()
+            except pickle.UnpicklingError as ex:
+                error("weights_file %s refused: %s" % (path, ex))
+        else:
+            error("weights_file %s holds a plain array, not the {layer: [W, b]} dict" % path)
+    if isinstance(net_data, np.ndarray) and net_data.shape == () and net_data.dtype == object:
+        net_data = net_data.item()                               # numpy pickles the 0-d object array itself; `.item()` as alexnet.py:51
+    if not isinstance(net_data, dict):
+        error("weights_file %s: expected a dict {layer: [W, b]}, found %s" % (path, type(net_data).__name__))
+    out = {}
+    for layer, wb in net_data.items():
+        layer = layer.decode("latin1") if isinstance(layer, bytes) else str(layer)
+        if not isinstance(wb, (list, tuple)) or len(wb) != 2:
+            error("weights_file %s: entry [%s] is not a [W, b] pair" % (path, layer))
+        out["dcnn/%sW" % layer] = np.asarray(wb[0], np.float32)
+        out["dcnn/%sb" % layer] = np.asarray(wb[1], np.float32)
+    return out
 
 
 def do_train(settings, train, feeder, engine):
