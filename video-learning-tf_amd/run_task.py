@@ -89,7 +89,16 @@ class _ArraysOnlyUnpickler(pickle.Unpickler):
     ALLOWED = {("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"), ("numpy", "ndarray"),
                ("numpy", "dtype"), ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar")}
 
+    @staticmethod
+    def _latin1(text, encoding="latin1"):
+        """Stand-in for _codecs.encode, which protocol-2 pickles written by Python 3 use to carry array bytes as latin-1 text."""
+        if encoding not in ("latin1", "latin-1"):
+            raise pickle.UnpicklingError("weights file asks for the codec %r: only latin1 byte strings are admitted" % (encoding,))
+        return text.encode("latin1")
+
     def find_class(self, module, name):
+        if (module, name) == ("_codecs", "encode"):
+            return self._latin1
         if (module, name) in self.ALLOWED:
             import importlib
             mod = importlib.import_module("numpy._core.multiarray" if module.endswith("multiarray") else module)
