@@ -28,6 +28,8 @@ def main():
     xh = conv.same_pad() if padded else 0
     dyh = conv.same_pad() if (padded and s == 1) else 0
     conv.set_halo(xh, 0, dyh, 0)
+    if s > 1 and padded and os.environ.get("VL_PROBE_NO_PHASE") is None:
+        conv.set_x_phase_split(True)            # the engine's layout of a strided conv's input (vl_conv_set_x_phase_split)
 
     def haloed(c_, h_, w_, halo):
         t = torch.zeros(n, c_, h_ + 2 * halo, w_ + 2 * halo, device=dev)
@@ -35,6 +37,13 @@ def main():
         return t
 
     x = haloed(cin, h, w, xh)
+    if getattr(conv, "x_phase", 1) > 1:         # same values, column-phase-split storage: [n, c * phase, H + 2 halo, ceil((W + 2 halo) / phase)]
+        ph = conv.x_phase
+        xs = torch.zeros(conv.x_shape(n), device=dev)
+        for q in range(ph):
+            cols = x[:, :, :, q::ph]
+            xs[:, q::ph, :, :cols.shape[3]] = cols
+        x = xs
     wt = torch.randn(k, k, cin // g, cout, device=dev) * 0.05
     b = torch.zeros(cout, device=dev)
     y = torch.empty(n, cout, conv.oh, conv.ow, device=dev)

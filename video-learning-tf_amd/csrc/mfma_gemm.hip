@@ -1150,6 +1150,16 @@ __global__ __launch_bounds__(NT, 64 / SR) void conv_dma_kernel(const ConvDmaPara
     pin_table();
     finish_stage();
 
+    // this lane's 32 bias values, loaded ahead of the main loop (inside the epilogue every one was a dependent load in front of a store)
+    float bias_r[2][16];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int co = i0 + wm * 64 + 2 * ((q & 3) + 8 * (q >> 2) + 4 * (lane >> 5)) + a;
+            bias_r[a][q] = (pe.bias && co < pe.Cog) ? pe.bias[zg * pe.Cog + co] : 0.f;
+        }
+
     // lane half h = lane >> 5 consumes row 2 s + h at MFMA step s
     const float* fa = ldsc + (lane >> 5) * 128 + wm * 64 + 2 * (lane & 31);
     const float* fb = ldsc + ABUF + (lane >> 5) * 128 + wn * 64 + (lane & 31);
@@ -1231,15 +1241,22 @@ __global__ __launch_bounds__(NT, 64 / SR) void conv_dma_kernel(const ConvDmaPara
         const int64_t mbase = c0 * pe.m_plane + (int64_t)(oh + pe.m_halo) * pe.m_wp + ow + pe.m_halo;
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
+            float mk[16];                                          // mask loads of these 16 channels first, all in flight (conv_dma16_kernel)
+            if (pe.mask) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int co = i0 + wm * 64 + 2 * ((q & 3) + 8 * (q >> 2) + 4 * (lane >> 5)) + a;
+                    mk[q] = co < pe.Cog ? pe.mask[mbase + (int64_t)co * pe.m_plane] : 0.f;
+                }
+            }
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int i = (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
                 const int co = i0 + wm * 64 + 2 * i + a;
                 if (co < pe.Cog) {
-                    float v = acc[a][b][q];
-                    if (pe.bias) v += pe.bias[zg * pe.Cog + co];
+                    float v = acc[a][b][q] + bias_r[a][q];
                     if (pe.relu) v = fmaxf(v, 0.f);
-                    if (pe.mask) v = pe.mask[mbase + (int64_t)co * pe.m_plane] > 0.f ? v : 0.f;
+                    if (pe.mask) v = mk[q] > 0.f ? v : 0.f;
                     pe.y[ybase + (int64_t)co * pe.y_plane] = v;
                 }
             }
@@ -1790,6 +1807,7 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ ws, float* __restr
 // template instead of the LDS-DMA kernels, VL_GEMM_NOSPLIT=1 disables the split-K of small dense GEMMs.
 static const bool kConvStaged = getenv("VL_CONV_STAGED") != nullptr;
 static const bool kGemmNoSplit = getenv("VL_GEMM_NOSPLIT") != nullptr;
+static const bool kConvNoWideStore = getenv("VL_CONV_NO_WIDE_STORE") != nullptr;   // A/B: per-accumulator stores in conv_dma16_kernel's epilogue
 static const bool kConvNoLoadPick = getenv("VL_CONV_NO_LOAD_PICK") != nullptr;   // A/B: tile width by padded rows only (round-1 rule)
 static const bool kWgradDword = getenv("VL_WGRAD_DWORD") != nullptr;  // split-product wgrad: keep the dword fetches where 16-byte ones apply
 static const bool kRing8 = getenv("VL_CONV_RING8") != nullptr;      // bf16x3, 128-channel layers: the 8-wave conv_ring_kernel instead of conv_ring4_kernel
@@ -2051,10 +2069,11 @@ static int launch_conv(const ConvGeom& g, const float* w, int64_t w_ld, int w_gr
 // on disjoint banks.  Lane l holds A[co = l & 15][r = l >> 4], B[r = l >> 4][pixel = l & 15]; D register q is
 // y[co = 4 (l >> 4) + q][pixel = l & 15].
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte access at 4-byte alignment
 
 template <int TA>   // channel tiles of 16 per workgroup: 3 (48 channels: conv2 dgrad) or 6 (96: the 192-channel layers)
 __global__ __launch_bounds__(NT, 2) void conv_dma16_kernel(const ConvDmaParams pa, const ConvGeom g, const EpiConvNCHW::Params pe,
-                                                           int tiles_i) {
+                                                           int tiles_i, int wide) {
     constexpr int BM = 16 * TA, BN = 128, SR = 32;
     constexpr int NA = (BM + 63) / 64;                                // 64-lane fetches per weight row
     constexpr int SA = NA * 64 + 16, SB = 144;                        // LDS row strides (floats), both = 16 mod 32
@@ -2090,6 +2109,16 @@ __global__ __launch_bounds__(NT, 2) void conv_dma16_kernel(const ConvDmaParams p
         const int ih0 = (int)oh * g.stride - g.pt + g.halo, iw0 = (int)ow * g.col_mul + g.col_add;
         voff_b[hf] = vm ? (uint32_t)((int64_t)n * g.img_stride + (int64_t)ih0 * g.Wp + iw0) * 4u : OOB_OFF;
     }
+    // this lane's bias values, loaded before the main loop: fetched inside the epilogue (one dependent load in front of each of
+    // the 48 stores) they cost conv1's forward 0.5 of its 2.4 ms (a run with the stores removed: 1.9 ms)
+    float bias_r[TA][4];
+#pragma unroll
+    for (int a = 0; a < TA; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int co = i0 + 16 * a + 4 * (lane >> 4) + q;
+            bias_r[a][q] = (pe.bias && co < pe.Cog) ? pe.bias[zg * pe.Cog + co] : 0.f;
+        }
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)ldsc;
     const int ld_bytes = (int)(pa.w_ld * 4);
 
@@ -2161,7 +2190,8 @@ __global__ __launch_bounds__(NT, 2) void conv_dma16_kernel(const ConvDmaParams p
     const float* fa = ldsc + (lane >> 4) * SA + (lane & 15);
     const float* fb = ldsc + ABUF + (lane >> 4) * SB + wave * 32 + (lane & 15);
 
-    auto stage = [&](const int cur, const bool fast, int st_next) {
+    // nsteps: k4-steps of this stage that hold reduction rows below K (a tile's last stage: K = 363 needs 3 of 8)
+    auto stage = [&](const int cur, const bool fast, int st_next, const int nsteps) {
         float af[2][TA], bf[2][2];
         auto read = [&](int step, float (&a)[TA], float (&b)[2]) {
             const float* pa_ = fa + cur * BUF + step * 4 * SA;
@@ -2176,15 +2206,23 @@ __global__ __launch_bounds__(NT, 2) void conv_dma16_kernel(const ConvDmaParams p
         for (int t = 0; t < NSTEP; ++t) {
             const int c = t & 1;
             if (t + 1 < NSTEP) read(t + 1, af[c ^ 1], bf[c ^ 1]);
+            if (t < nsteps) {
 #pragma unroll
-            for (int m = 0; m < NM; ++m) {
-                const int a = m >> 1, b = m & 1;
-                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[c][a], bf[c][b], acc[a][b], 0, 0, 0);
-                const int f = t * NM + m;
-                if (f < NF) {
-                    if (fast) dma_fast(cur ^ 1, f, st_next);
-                    else dma(cur ^ 1, f, st_next);
-                    __builtin_amdgcn_sched_barrier(0);
+                for (int m = 0; m < NM; ++m) {
+                    const int a = m >> 1, b = m & 1;
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[c][a], bf[c][b], acc[a][b], 0, 0, 0);
+                    const int f = t * NM + m;
+                    if (f < NF) {
+                        if (fast) dma_fast(cur ^ 1, f, st_next);
+                        else dma(cur ^ 1, f, st_next);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            } else {                                               // rows past K: no products; the (zero) fetches of the stage after the last keep the counters in step
+#pragma unroll
+                for (int m = 0; m < NM; ++m) {
+                    const int f = t * NM + m;
+                    if (f < NF) dma(cur ^ 1, f, st_next);
                 }
             }
             static_assert(NF <= NM * (NSTEP - 3), "fetches must end before the table is replaced");
@@ -2200,16 +2238,66 @@ __global__ __launch_bounds__(NT, 2) void conv_dma16_kernel(const ConvDmaParams p
         finish_stage();
     };
     const int nfull = g.K / SR;                                        // stages entirely below K (see conv_dma_kernel)
+    const int last_steps = (g.K - (nstages - 1) * SR + 3) / 4;         // live k4-steps of the last stage
     int st = 0;
     for (; st + 2 < nfull; st += 2) {
-        stage(0, true, st + 1);
-        stage(1, true, st + 2);
+        stage(0, true, st + 1, NSTEP);
+        stage(1, true, st + 2, NSTEP);
     }
     for (; st < nstages; ++st) {
-        if (st & 1) stage(1, false, st + 1);
-        else stage(0, false, st + 1);
+        const int ns = st == nstages - 1 ? last_steps : NSTEP;
+        if (st & 1) stage(1, false, st + 1, ns);
+        else stage(0, false, st + 1, ns);
     }
 
+    // ---- epilogue.  Dense output planes (y_halo == 0: the layers followed by LRN / pool) without a ReluGrad mask go out through LDS
+    // as 16-byte stores of 4 consecutive pixels: a channel's 128 pixels of the tile are 512 contiguous bytes in NCHW, but the
+    // accumulator layout hands a store instruction 16 pixels x 4 channels = four 64-byte pieces at arbitrary 4-byte alignment, which
+    // the memory side splits again (measured on conv1 forward: 3.4e7 write requests for 1.28 GB, 1.7x the algorithmic bytes written,
+    // and 0.4 of the launch's 2.3 ms gone with the stores removed).
+    if (wide) {
+        constexpr int SP = BN + 4;                                     // row stride 132: the four 16-lane groups of a write hit disjoint bank quarters
+        float* T = ldsc;                                               // both stage buffers are free after the last barrier
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int a = 0; a < TA; ++a)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v = acc[a][b][q] + bias_r[a][q];
+                    if (pe.relu) v = fmaxf(v, 0.f);
+                    T[(16 * a + 4 * (lane >> 4) + q) * SP + wave * 32 + 16 * b + (lane & 15)] = v;
+                }
+        __syncthreads();
+        const int px = 4 * (lane & 31);
+        const int m = j0 + px;
+        const uint32_t n = fd_div((uint32_t)min(m, pe.M - 1), pe.dOHW);
+        const int p = m - (int)n * pe.OHW;
+        const bool run4 = m + 3 < pe.M && p + 3 < pe.OHW;              // four pixels of one image: contiguous
+        const int64_t cbase = ((int64_t)n * pe.Cout_total + (int64_t)zg * pe.Cog) * pe.y_plane + p;
+#pragma unroll
+        for (int i = 0; i < BM / 8; ++i) {                             // 2 channel rows per wave instruction, BM / 4 rows per wave
+            const int cl = wave * (BM / 4) + 2 * i + (lane >> 5);
+            const int co = i0 + cl;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(T + cl * SP + px);
+            if (co >= pe.Cog) continue;
+            float* dst = pe.y + cbase + (int64_t)co * pe.y_plane;
+            if (run4) {
+                *reinterpret_cast<f32x4u*>(dst) = v;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int me = m + e;
+                    if (me < pe.M) {
+                        const uint32_t ne = fd_div((uint32_t)me, pe.dOHW);
+                        const int pe_ = me - (int)ne * pe.OHW;
+                        pe.y[((int64_t)ne * pe.Cout_total + (int64_t)zg * pe.Cog + co) * pe.y_plane + pe_] = v[e];
+                    }
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         const int m = j0 + wave * 32 + 16 * b + (lane & 15);
@@ -2221,16 +2309,25 @@ __global__ __launch_bounds__(NT, 2) void conv_dma16_kernel(const ConvDmaParams p
         const int64_t c0 = (int64_t)n * pe.Cout_total + (int64_t)zg * pe.Cog;
         const int64_t ybase = c0 * pe.y_plane + (int64_t)(oh + pe.y_halo) * pe.y_wp + ow + pe.y_halo;
         const int64_t mbase = c0 * pe.m_plane + (int64_t)(oh + pe.m_halo) * pe.m_wp + ow + pe.m_halo;
+        float mk[TA][4];                                          // mask loads first, all in flight (see conv_dma16p_kernel)
+        if (pe.mask) {
+#pragma unroll
+            for (int a = 0; a < TA; ++a)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int co = i0 + 16 * a + 4 * (lane >> 4) + q;
+                    mk[a][q] = co < pe.Cog ? pe.mask[mbase + (int64_t)co * pe.m_plane] : 0.f;
+                }
+        }
 #pragma unroll
         for (int a = 0; a < TA; ++a) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int co = i0 + 16 * a + 4 * (lane >> 4) + q;
                 if (co < pe.Cog) {
-                    float v = acc[a][b][q];
-                    if (pe.bias) v += pe.bias[zg * pe.Cog + co];
+                    float v = acc[a][b][q] + bias_r[a][q];
                     if (pe.relu) v = fmaxf(v, 0.f);
-                    if (pe.mask) v = pe.mask[mbase + (int64_t)co * pe.m_plane] > 0.f ? v : 0.f;
+                    if (pe.mask) v = mk[a][q] > 0.f ? v : 0.f;
                     pe.y[ybase + (int64_t)co * pe.y_plane] = v;
                 }
             }
@@ -2238,6 +2335,8 @@ __global__ __launch_bounds__(NT, 2) void conv_dma16_kernel(const ConvDmaParams p
     }
 }
 
+
+static int device_cus();
 
 template <int BM>   // 128: conv_dma_kernel (32x32 MFMA tiles); 48 / 96: conv_dma16_kernel (16x16 tiles)
 static int launch_conv_dma(const ConvGeom& g, const float* w, int64_t w_ld, int w_grp_stride, const int* row_tab, int Cog,
@@ -2252,15 +2351,24 @@ static int launch_conv_dma(const ConvGeom& g, const float* w, int64_t w_ld, int 
     pe.dOHW = g.dOHW; pe.dOW = g.dOW;
     pe.y_halo = o.y_halo; pe.y_wp = o.OW + 2 * o.y_halo; pe.y_plane = (int64_t)(o.OH + 2 * o.y_halo) * pe.y_wp;
     pe.m_halo = o.m_halo; pe.m_wp = o.OW + 2 * o.m_halo; pe.m_plane = (int64_t)(o.OH + 2 * o.m_halo) * pe.m_wp;
+    if (getenv("VL_CONV_DEBUG_NOSTORE")) pe.M = 0;       // timing experiment only: the epilogue stores nothing (results are wrong)
     static bool attr_set = false;
-    auto kern = BM == 128 ? conv_dma_kernel<SR> : conv_dma16_kernel<BM == 128 ? 3 : BM / 16>;
     if (!attr_set) {
-        VL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const void* kern;
+        if constexpr (BM == 128) kern = reinterpret_cast<const void*>(conv_dma_kernel<SR>);
+        else kern = reinterpret_cast<const void*>(conv_dma16_kernel<BM / 16>);
+        VL_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     const int tiles_i = ceil_div(Cog, BM), tiles_j = ceil_div(g.M, BN);
     dim3 grid(tiles_i * tiles_j, (unsigned)(Cout_total / Cog), 1);
-    hipLaunchKernelGGL(kern, grid, dim3(NT), lds, s, pa, g, pe, tiles_i);
+    if constexpr (BM == 128) {
+        hipLaunchKernelGGL(conv_dma_kernel<SR>, grid, dim3(NT), lds, s, pa, g, pe, tiles_i);
+    } else {
+        // wide-store epilogue: dense output planes, no mask, and the [BM][132] staging tile must fit the stage buffers
+        const int wide = (o.y_halo == 0 && !o.mask && !kConvNoWideStore && (size_t)BM * (BN + 4) * sizeof(float) <= lds) ? 1 : 0;
+        hipLaunchKernelGGL((conv_dma16_kernel<BM / 16>), grid, dim3(NT), lds, s, pa, g, pe, tiles_i, wide);
+    }
     VL_LAUNCH_CHECK();
     return 0;
 }
@@ -2310,8 +2418,6 @@ static int launch_conv_ring(const ConvGeom& g, const float* w, int64_t w_ld, int
     VL_LAUNCH_CHECK();
     return 0;
 }
-
-static int device_cus();
 
 template <bool PADDED>
 static int dispatch_conv(const ConvGeom& g, const float* w, int64_t w_ld, int w_grp_stride, const int* row_tab, int Cog,
