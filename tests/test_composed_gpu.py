@@ -149,3 +149,64 @@ def test_tensor_list_ops(ops=None):
     rep = torch.empty((3 * 6, 5), device=DEV)
     ops.copy2d(ad, rep, 3, 30, src_ld=0, dst_ld=30)
     np.testing.assert_array_equal(rep.cpu().numpy(), O.replicate_auxilliary_tensor(a, 3))
+
+
+def _dp_worker(rank, world, port, q):
+    import os
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from vltf_amd import dp
+    from vltf_amd.composed import ComposedEngine, HeadConfig
+    from vltf_amd.engine import NetConfig
+    dp.init_from_env(backend="gloo")
+    shape, V, E, Tf, Tw, clips = (67, 67, 3), 7, 5, 2, 3, 4
+    rng = np.random.default_rng(17)                                      # identical on every rank
+    enc_cfg = NetConfig(image_shape=shape, num_classes=V, fpc=Tf, classifier="lstm", lstm_hidden=6, fusion="state")
+    head = HeadConfig(in_dim=E, fpc=Tw, num_classes=V, lstm_hidden=8, lstm_layers=1, fusion="reshape")
+    pe = O.init_params(rng, V, "fc6", 6, 1, shape, well_scaled=True, fusion="state")
+    p = {"enc/" + k: v for k, v in pe.items()}
+    p.update(O.init_lstm_classifier_params(rng, "dec/", E, 8, 1, "reshape", V, state_dim=V, well_scaled=True))
+    frames = rng.integers(0, 256, (clips * Tf,) + shape, dtype=np.uint8)
+    words = rng.standard_normal((clips * Tw, E)).astype(np.float32)
+    onehot = O.labels_to_one_hot([[l] for l in rng.integers(0, V, clips * Tw)], V)
+    lo, hi = dp.shard_range(clips, rank, world)
+    gar = dp.GradAllReduce()
+    eng = ComposedEngine(enc_cfg, head, max_clips=hi - lo, device=DEV, dp=gar)
+    eng.load_params(p)
+    gar.broadcast_params(eng.w)
+    out = eng.train_step(torch.tensor(frames[lo * Tf:hi * Tf], device=DEV), torch.tensor(words[lo * Tw:hi * Tw], device=DEV),
+                         torch.tensor(onehot[lo * Tw:hi * Tw], device=DEV), lr=0.05, clip_norm=0.5, mean_bgr=MEAN,
+                         global_rows=clips * Tw)
+    got = eng.get_params()
+    if rank == 0:
+        ref = ComposedEngine(enc_cfg, head, max_clips=clips, device=DEV)
+        ref.load_params(p)
+        want_out = ref.train_step(torch.tensor(frames, device=DEV), torch.tensor(words, device=DEV), torch.tensor(onehot, device=DEV),
+                                  lr=0.05, clip_norm=0.5, mean_bgr=MEAN)
+        want = ref.get_params()
+        err = {k: float(np.abs(got[k] - want[k]).max() / (np.abs(want[k] - p[k]).max() + 1e-12)) for k in want}
+        q.put(("ok", max(err.values()), abs(out["grad_norm"] - want_out["grad_norm"]) / want_out["grad_norm"], gar.issued, len(eng.grad_chunks)))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_composed_step_equals_one_rank():
+    """Data parallel over clips for the two-pipeline model: the shared flat gradient buffer goes out in chunks -- pipeline 2's
+    first, then pipeline 1's through the offset view of its own chunk list -- and two ranks (gloo, one GPU) end with the
+    parameters of one rank stepping on all the clips."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    for pr in procs:
+        pr.join(300)
+        assert pr.exitcode == 0, "rank exited with %s" % pr.exitcode
+    tag, worst, gn_err, issued, nchunks = q.get(timeout=10)
+    assert tag == "ok" and issued == nchunks and nchunks >= 4, (issued, nchunks)
+    assert worst < 1e-3 and gn_err < 1e-5, (worst, gn_err)

@@ -12,8 +12,12 @@ from vltf_amd import ops
 
 GEOM = {  # cin, h, w, cout, k, stride, groups
     "conv1": (3, 227, 227, 96, 11, 4, 1), "conv2": (96, 28, 28, 256, 5, 1, 2), "conv3": (256, 13, 13, 384, 3, 1, 1),
-    "conv4": (384, 13, 13, 384, 3, 1, 2), "conv5": (384, 13, 13, 256, 3, 1, 2)}
-MACS = {"conv1": 113221152, "conv2": 240844800, "conv3": 149520384, "conv4": 112140288, "conv5": 74760192}
+    "conv4": (384, 13, 13, 384, 3, 1, 2), "conv5": (384, 13, 13, 256, 3, 1, 2),
+    # dense layers as 1x1 convolutions over ONE image whose pixels are the frames (activations stored [features][frames]):
+    # run with frames = 1; the image width is the frame count
+    "fc6x1024": (9216, 1, 1024, 4096, 1, 1, 1), "fc6x128": (9216, 1, 128, 4096, 1, 1, 1), "gxx1024": (4096, 1, 1024, 1024, 1, 1, 1)}
+MACS = {"conv1": 113221152, "conv2": 240844800, "conv3": 149520384, "conv4": 112140288, "conv5": 74760192,
+        "fc6x1024": 9216 * 4096 * 1024, "fc6x128": 9216 * 4096 * 128, "gxx1024": 4096 * 1024 * 1024}
 
 
 def main():
