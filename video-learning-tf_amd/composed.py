@@ -376,6 +376,20 @@ class ComposedEngine:
         self.enc.dp = _OffsetReduce(self.dp, self.g, self.enc.g) if self.dp is not None else None
         self.enc._backward(n, b1)
         self.enc.dp = None
+        return self._finish_step(rows, lr, clip_norm, fetch)
+
+    def train_step_empty(self, lr, clip_norm=0.0, fetch=True):
+        """This rank's shard of the global batch is empty (fewer items than ranks in a short last batch): contribute zero gradients
+        to the exchange and apply the same update as every other rank (LRCNEngine.train_step_empty)."""
+        if self.dp is None:
+            raise VltfError("train_step_empty is a data-parallel call")
+        ops.fill(self.g, 0.0)
+        ops.fill(self.stats, 0.0)
+        for lo, cnt in self.grad_chunks:
+            self.dp.reduce_async(self.g, lo, cnt)
+        return self._finish_step(0, lr, clip_norm, fetch)
+
+    def _finish_step(self, rows, lr, clip_norm, fetch):
         if self.dp is not None:
             self.dp.wait()
         ops.sumsq(self.g, self.ss, self.small_ws)

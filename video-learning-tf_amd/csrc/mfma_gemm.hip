@@ -1037,6 +1037,9 @@ __global__ __launch_bounds__(NT, 1) void wgrad_dma_kernel(const ConvGeom g, cons
 // pixel axis the tiles are the two contiguous 32-pixel halves (two b32 reads): an even/odd split there made every output
 // store a stride-2 half-filled line and doubled the kernel's HBM write traffic (measured 747 vs 360 MB algorithmic).
 // Accumulator (a, b, q) of lane l is y[co = 64 wm + 2 i + a][pixel = 64 wn + 32 b + j], i = (q&3) + 8 (q>>2) + 4 (l>>5), j = l & 31.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte access at 4-byte alignment
+
 struct ConvDmaParams {
     const float* w;          // [K][w_ld] weights (HWIO forward, flipped/transposed for dgrad)
     int64_t w_ld;
@@ -1048,7 +1051,7 @@ struct ConvDmaParams {
 
 template <int SR>   // reduction rows per stage: 64 (one workgroup per CU) or 32 (two: one's epilogue under the other's MFMAs)
 __global__ __launch_bounds__(NT, 64 / SR) void conv_dma_kernel(const ConvDmaParams pa, const ConvGeom g, const EpiConvNCHW::Params pe,
-                                                               int tiles_i) {
+                                                               int tiles_i, int wide) {
     constexpr int BM = 128, BN = 128;
     constexpr int ABUF = SR * BM, BUF = SR * (BM + BN);               // floats: A tile, whole buffer
     constexpr int RW = SR / 4;                                        // rows of a stage each wave fetches (within ONE 16-row block)
@@ -1228,6 +1231,52 @@ __global__ __launch_bounds__(NT, 64 / SR) void conv_dma_kernel(const ConvDmaPara
     }
 
     // ---- epilogue: NCHW (+ halo), bias, ReLU, ReluGrad mask
+    // dense output planes without a mask (conv2 / conv5 forward): through LDS as 16-byte stores of 4 consecutive pixels, see
+    // conv_dma16_kernel (a run with the stores removed was 4-6 % faster; the launcher sizes the LDS for the [128][132] staging tile)
+    if (wide) {
+        constexpr int SP = BN + 4;                                     // lanes 32..63 write channel + 8: 8 * 132 = 32 mod 64 banks
+        float* T = ldsc;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int i = (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+                    float v = acc[a][b][q] + bias_r[a][q];
+                    if (pe.relu) v = fmaxf(v, 0.f);
+                    T[(wm * 64 + 2 * i + a) * SP + wn * 64 + 32 * b + (lane & 31)] = v;
+                }
+        __syncthreads();
+        const int px = 4 * (lane & 31);
+        const int m = j0 + px;
+        const uint32_t n = fd_div((uint32_t)min(m, pe.M - 1), pe.dOHW);
+        const int p = m - (int)n * pe.OHW;
+        const bool run4 = m + 3 < pe.M && p + 3 < pe.OHW;
+        const int64_t cbase = ((int64_t)n * pe.Cout_total + (int64_t)zg * pe.Cog) * pe.y_plane + p;
+#pragma unroll
+        for (int i = 0; i < BM / 8; ++i) {                             // 2 channel rows per wave instruction, 32 rows per wave
+            const int cl = wave * (BM / 4) + 2 * i + (lane >> 5);
+            const int co = i0 + cl;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(T + cl * SP + px);
+            if (co >= pe.Cog) continue;
+            float* dst = pe.y + cbase + (int64_t)co * pe.y_plane;
+            if (run4) {
+                *reinterpret_cast<f32x4u*>(dst) = v;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int me = m + e;
+                    if (me < pe.M) {
+                        const uint32_t ne = fd_div((uint32_t)me, pe.dOHW);
+                        const int pe_ = me - (int)ne * pe.OHW;
+                        pe.y[((int64_t)ne * pe.Cout_total + (int64_t)zg * pe.Cog + co) * pe.y_plane + pe_] = v[e];
+                    }
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         const int m = j0 + wn * 64 + 32 * b + (lane & 31);
@@ -2068,8 +2117,6 @@ static int launch_conv(const ConvGeom& g, const float* w, int64_t w_ld, int w_gr
 // strides 80 / 144 floats (= 16 mod 32) keep the four 16-lane groups of a fragment read -- lane group g reads row 4 s + g --
 // on disjoint banks.  Lane l holds A[co = l & 15][r = l >> 4], B[r = l >> 4][pixel = l & 15]; D register q is
 // y[co = 4 (l >> 4) + q][pixel = l & 15].
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte access at 4-byte alignment
 
 template <int TA>   // channel tiles of 16 per workgroup: 3 (48 channels: conv2 dgrad) or 6 (96: the 192-channel layers)
 __global__ __launch_bounds__(NT, 2) void conv_dma16_kernel(const ConvDmaParams pa, const ConvGeom g, const EpiConvNCHW::Params pe,
@@ -2342,8 +2389,10 @@ template <int BM>   // 128: conv_dma_kernel (32x32 MFMA tiles); 48 / 96: conv_dm
 static int launch_conv_dma(const ConvGeom& g, const float* w, int64_t w_ld, int w_grp_stride, const int* row_tab, int Cog,
                            int Cout_total, const ConvOut& o, hipStream_t s) {
     constexpr int BN = 128, SR = 32;
-    constexpr size_t lds = BM == 128 ? (size_t)2 * SR * (BM + BN) * sizeof(float)    // 64 KB: two workgroups per CU
+    // 128-wide: 64 KB of stage buffers, 66 KB with the wide-store staging tile [128][132] (two workgroups per CU either way)
+    constexpr size_t lds = BM == 128 ? (size_t)BM * (BN + 4) * sizeof(float)
                                      : (size_t)2 * SR * ((BM + 63) / 64 * 64 + 16 + 144) * sizeof(float);   // 56 / 72 KB
+    static_assert(BM != 128 || (size_t)2 * SR * (BM + BN) * sizeof(float) <= (size_t)BM * (BN + 4) * sizeof(float), "stage buffers fit");
     ConvDmaParams pa{w, w_ld, (int64_t)w_grp_stride, (int64_t)g.K * w_ld * 4, row_tab, ceil_div(g.K, KBLK)};
     EpiConvNCHW::Params pe;
     pe.y = o.y; pe.bias = o.bias; pe.mask = o.mask; pe.relu = o.relu;
@@ -2362,11 +2411,11 @@ static int launch_conv_dma(const ConvGeom& g, const float* w, int64_t w_ld, int 
     }
     const int tiles_i = ceil_div(Cog, BM), tiles_j = ceil_div(g.M, BN);
     dim3 grid(tiles_i * tiles_j, (unsigned)(Cout_total / Cog), 1);
+    // wide-store epilogue: dense output planes, no mask, and the [BM][132] staging tile must fit the LDS allocation
+    const int wide = (o.y_halo == 0 && !o.mask && !kConvNoWideStore && (size_t)BM * (BN + 4) * sizeof(float) <= lds) ? 1 : 0;
     if constexpr (BM == 128) {
-        hipLaunchKernelGGL(conv_dma_kernel<SR>, grid, dim3(NT), lds, s, pa, g, pe, tiles_i);
+        hipLaunchKernelGGL(conv_dma_kernel<SR>, grid, dim3(NT), lds, s, pa, g, pe, tiles_i, wide);
     } else {
-        // wide-store epilogue: dense output planes, no mask, and the [BM][132] staging tile must fit the stage buffers
-        const int wide = (o.y_halo == 0 && !o.mask && !kConvNoWideStore && (size_t)BM * (BN + 4) * sizeof(float) <= lds) ? 1 : 0;
         hipLaunchKernelGGL((conv_dma16_kernel<BM / 16>), grid, dim3(NT), lds, s, pa, g, pe, tiles_i, wide);
     }
     VL_LAUNCH_CHECK();

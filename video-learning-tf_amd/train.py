@@ -104,10 +104,13 @@ class Train:
         grows = None
         if eng.dp is not None and fdict.get("global_clips") is not None:
             grows = fdict["global_clips"] * (eng.Ts if eng.per_step else 1) * (eng.h.cpv_ratio if "frames_u8" in fdict else 1)
-        out = eng.train_step(torch.from_numpy(fr["frames_u8"]).to(dev, non_blocking=True), torch.from_numpy(vec["vectors"]).to(dev),
-                             torch.from_numpy(np.ascontiguousarray(labels)).to(dev), lr, self.clip_norm, fr["mean_bgr"],
-                             torch.from_numpy(fr["crop_y"]).to(dev), torch.from_numpy(fr["crop_x"]).to(dev),
-                             torch.from_numpy(fr["mirror"]).to(dev), global_rows=grows)
+        if len(labels) == 0:                 # this rank's shard of a short last batch is empty
+            out = eng.train_step_empty(lr, self.clip_norm)
+        else:
+            out = eng.train_step(torch.from_numpy(fr["frames_u8"]).to(dev, non_blocking=True), torch.from_numpy(vec["vectors"]).to(dev),
+                                 torch.from_numpy(np.ascontiguousarray(labels)).to(dev), lr, self.clip_norm, fr["mean_bgr"],
+                                 torch.from_numpy(fr["crop_y"]).to(dev), torch.from_numpy(fr["crop_x"]).to(dev),
+                                 torch.from_numpy(fr["mirror"]).to(dev), global_rows=grows, resize=fr.get("resize"))
         if eng.dp is not None:
             tot = eng.dp.sum_scalars(torch.tensor([out["loss_sum"], out["correct"], float(out["rows"])], device=dev, dtype=torch.float64))
             tot = tot.cpu().numpy()
