@@ -59,6 +59,25 @@ def device_gates(eng, n):
     return g
 
 
+@pytest.mark.parametrize("math,logit_tol,loss_tol", [("bf16x3", 1e-3, 1e-4), ("bf16", 5e-2, 1e-2)])
+def test_config5_clip_length_in_the_bf16_conv_arithmetics(math, logit_tol, loss_tol):
+    """BASELINE config 5 = the bf16-MFMA conv path on 32-frame clips: the 4-clip x 32-frame fixture job in the opt-in conv arithmetics.
+    bf16x3 (split products) is held to the fp32 bounds; plain bf16 products are reduced precision by design (2e-3 per
+    contraction) and get the bounds of test_plain_bf16_conv_mode_runs_close."""
+    import dataclasses
+    from vltf_amd.engine import LRCNEngine
+    gold = np.load(GOLD)
+    cfg, p, frames, onehot = case_inputs("t32_ws")
+    eng = LRCNEngine(dataclasses.replace(cfg, conv_math=math), max_clips=CASES["t32_ws"][0], device=DEV)
+    eng.load_params(p)
+    out = eng.train_step_u8(torch.from_numpy(frames).to(DEV), torch.from_numpy(onehot).to(DEV), lr=LR, clip_norm=CLIP, mean_bgr=MEAN)
+    want = gold["t32_ws/logits"]
+    loss, gn, _ = gold["t32_ws/loss_gn_acc"]
+    assert np.abs(eng.logits_host() - want).max() <= logit_tol
+    assert abs(out["loss"] - loss) <= loss_tol * max(1.0, abs(loss))
+    assert abs(out["grad_norm"] - gn) <= (5e-3 if math == "bf16x3" else 0.3) * gn
+
+
 @pytest.mark.parametrize("name", ["cfg2_ws", "cfg2_ref", "t32_ws"])
 def test_benchmark_job_matches_oracle_fixture(name):
     from vltf_amd.engine import LRCNEngine
