@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Runs one HBM-bound kernel of the path in isolation at a layer's real size (for rocprofv3 / timing).
-usage: pw_probe.py <pool_lrn_bwd|lrn_fwd|maxpool_fwd|maxpool_bwd|lrn_bwd|bias_grad> <1|2> [frames] [iters]"""
+usage: pw_probe.py <pool_lrn_bwd|lrn_pool_fwd|lrn_fwd|maxpool_fwd|maxpool_bwd|lrn_bwd|bias_grad> <1|2> [frames] [iters]"""
 import os
 import sys
 import time
@@ -30,6 +30,7 @@ def main():
     db = torch.empty(c, device=dev)
     fns = {
         "pool_lrn_bwd": lambda: ops.pool_lrn_bwd(x, dp, arg, y, p_halo=ph),
+        "lrn_pool_fwd": lambda: ops.lrn_pool_fwd(x, p, arg, p_halo=ph),
         "lrn_fwd": lambda: ops.lrn_fwd(x, y),
         "lrn_bwd": lambda: ops.lrn_bwd(x, dy, y, relu_fused=True),
         "maxpool_fwd": lambda: ops.maxpool_fwd(x, p, arg, y_halo=ph),

@@ -3,6 +3,9 @@
 // All activations NCHW fp32; lanes always walk the contiguous (w / hw / column) dimension.
 #include <stdlib.h>
 
+#include <stdio.h>
+#include <stdlib.h>
+
 #include "common.h"
 
 // A/B switches for measurements, read once: VL_POOL_LRN_CHUNKED=1 runs the fused pool+LRN backward on the older chunked
@@ -481,6 +484,11 @@ extern "C" int vl_pool_lrn_bwd(const float* x, const float* dp, const uint8_t* a
         VL_LAUNCH_CHECK();                                                                                                          \
         return 0;                                                                                                                   \
     } while (0)
+        // chunk = 5 channels (110 registers, 12.5 KB of LDS: four workgroups per CU instead of two) when C + 4 is a multiple of it (96
+        // and 256 are: no idle tail iterations): layer 1 0.79 -> 0.71 ms, layer 2 0.57 -> 0.51 ms against the 20-channel chunks of
+        // round 1 (VL_POOL_LRN_BWD_R1=1)
+        static const bool r1 = getenv("VL_POOL_LRN_BWD_R1") != nullptr;
+        if (ok && !r1 && (c + 4) % 5 == 0 && (int64_t)5 * max_prow * ow <= 3 * 256) VL_PLB_LAUNCH(5, 3);
         // chunk = 20 channels when C + 4 is a multiple of it (96 and 256 are): no idle tail iterations
         if (ok && (c + 4) % 20 == 0 && (int64_t)20 * max_prow * ow <= 11 * 256 && !kPoolLrnChk16) VL_PLB_LAUNCH(20, 11);
         if (ok && (int64_t)16 * max_prow * ow <= 9 * 256) VL_PLB_LAUNCH(16, 9);
@@ -633,17 +641,12 @@ __global__ __launch_bounds__(512) void lrn_pool_fwd_kernel(const float* __restri
     }
 }
 
-extern "C" int vl_lrn_pool_fwd(const float* x, float* p, uint8_t* argmax, int n, int c, int h, int w, int p_halo, int radius,
-                               float alpha, float beta, float bias, vl_stream_t stream) {
-    VL_CHECK(x && p && argmax && n > 0 && c > 0 && h >= 3 && w >= 3 && p_halo >= 0, "vl_lrn_pool_fwd: bad argument");
-    VL_CHECK(radius == 2 && beta == 0.75f, "vl_lrn_pool_fwd: only depth_radius 2, beta 0.75 are built (alexnet.py:81-84)");
-    VL_CHECK(n <= 65535, "vl_lrn_pool_fwd: batch %d exceeds the grid limit", n);
+template <int CHK, int PPT, int NSL>
+static int launch_lrn_pool_fwd(const float* x, float* p, uint8_t* argmax, int n, int c, int h, int w, int p_halo, float alpha, float bias,
+                               hipStream_t stream) {
     const int oh = (h - 3) / 2 + 1, ow = (w - 3) / 2 + 1;
     const int owp = ow + 2 * p_halo;
     const int64_t pplane = (int64_t)(oh + 2 * p_halo) * owp;
-    VL_CHECK((int64_t)(c + 16) * h * w * 4 < (1ll << 31) && (int64_t)c * pplane * 4 < (1ll << 31) && pplane < (1 << 24),
-             "vl_lrn_pool_fwd: image too large for 32-bit buffer offsets");
-    constexpr int CHK = 8, PPT = 3, NSL = 6;
     // band = prb pooled rows: the largest that fits PPT pixels per thread of a <= 512-thread workgroup, NSL outputs per thread
     // and 64 KB of LDS; then the smallest thread count (multiple of 64) that still covers it
     int prb = 0, threads = 0;
@@ -665,10 +668,31 @@ extern "C" int vl_lrn_pool_fwd(const float* x, float* p, uint8_t* argmax, int n,
         threads = ceil_div(need_px > need_out ? need_px : need_out, 64) * 64;
     }
     const size_t lds = (size_t)2 * CHK * (2 * prb + 1) * w * sizeof(float);
-    hipLaunchKernelGGL((lrn_pool_fwd_kernel<CHK, PPT, NSL>), dim3(bands, n), dim3(threads), lds, (hipStream_t)stream, x, p, argmax, c, h,
+    if (getenv("VL_LRN_POOL_VERBOSE")) fprintf(stderr, "lrn_pool_fwd<%d,%d,%d>: bands %d prb %d threads %d lds %zu\n", CHK, PPT, NSL, bands, prb, threads, lds);
+    hipLaunchKernelGGL((lrn_pool_fwd_kernel<CHK, PPT, NSL>), dim3(bands, n), dim3(threads), lds, stream, x, p, argmax, c, h,
                        w, oh, ow, prb, (int)pplane, owp, p_halo, alpha, bias);
     VL_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int vl_lrn_pool_fwd(const float* x, float* p, uint8_t* argmax, int n, int c, int h, int w, int p_halo, int radius,
+                               float alpha, float beta, float bias, vl_stream_t stream) {
+    VL_CHECK(x && p && argmax && n > 0 && c > 0 && h >= 3 && w >= 3 && p_halo >= 0, "vl_lrn_pool_fwd: bad argument");
+    VL_CHECK(radius == 2 && beta == 0.75f, "vl_lrn_pool_fwd: only depth_radius 2, beta 0.75 are built (alexnet.py:81-84)");
+    VL_CHECK(n <= 65535, "vl_lrn_pool_fwd: batch %d exceeds the grid limit", n);
+    const int oh = (h - 3) / 2 + 1, ow = (w - 3) / 2 + 1;
+    const int owp = ow + 2 * p_halo;
+    const int64_t pplane = (int64_t)(oh + 2 * p_halo) * owp;
+    VL_CHECK((int64_t)(c + 16) * h * w * 4 < (1ll << 31) && (int64_t)c * pplane * 4 < (1ll << 31) && pplane < (1 << 24),
+             "vl_lrn_pool_fwd: image too large for 32-bit buffer offsets");
+    // Chunk of 2 channels, 2 pixels and 1 pooled output per thread: 46 registers, 13 KB of LDS -> the CU holds 4-5 workgroups of 448
+    // threads.  The round-1 shape <8, 3, 6> (8-channel chunks, 214 registers, 55 KB) left ONE 320-thread workgroup = 5 waves on a CU and
+    // ran LRN's ~13 VALU per element at that occupancy: layer 1 0.63 -> 0.45 ms, layer 2 0.33 -> 0.28 ms (sweep of 14 shapes on MI355X,
+    // tools/pw_probe.py lrn_pool_fwd; VL_LRN_POOL_R1=1 runs the old shape for comparison).
+    static const bool r1 = getenv("VL_LRN_POOL_R1") != nullptr;
+    hipStream_t s = (hipStream_t)stream;
+    if (r1) return launch_lrn_pool_fwd<8, 3, 6>(x, p, argmax, n, c, h, w, p_halo, alpha, bias, s);
+    return launch_lrn_pool_fwd<2, 2, 1>(x, p, argmax, n, c, h, w, p_halo, alpha, bias, s);
 }
 
 // ---- max-pool VALID (alexnet.py:91-98) --------------------------------------------------------
