@@ -2400,7 +2400,6 @@ static int launch_conv_dma(const ConvGeom& g, const float* w, int64_t w_ld, int 
     pe.dOHW = g.dOHW; pe.dOW = g.dOW;
     pe.y_halo = o.y_halo; pe.y_wp = o.OW + 2 * o.y_halo; pe.y_plane = (int64_t)(o.OH + 2 * o.y_halo) * pe.y_wp;
     pe.m_halo = o.m_halo; pe.m_wp = o.OW + 2 * o.m_halo; pe.m_plane = (int64_t)(o.OH + 2 * o.m_halo) * pe.m_wp;
-    if (getenv("VL_CONV_DEBUG_NOSTORE")) pe.M = 0;       // timing experiment only: the epilogue stores nothing (results are wrong)
     static bool attr_set = false;
     if (!attr_set) {
         const void* kern;
