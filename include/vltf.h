@@ -231,9 +231,10 @@ int vl_dropout_bwd(const float* dy, const uint8_t* mask, float* dx, int64_t coun
  * labels: int32 one/multi-hot [batch][classes] (the reference's labels placeholder, train.py:117).
  * dlogits = (softmax - labels) * grad_scale   (grad_scale = 1/global_batch); may be NULL.
  * stats[0] += sum_b loss_b, stats[1] += number of rows with argmax(logits) == argmax(labels);
- * zero `stats` first (vl_fill). */
-int vl_softmax_xent(const float* logits, const int32_t* labels, float* dlogits, float* stats, int batch,
-                    int classes, float grad_scale, vl_stream_t stream);
+ * zero `stats` first (vl_fill).  rows: float[2*batch] workspace receiving the per-row losses and hits (one wave per row over
+ * the whole chip, summed in a fixed order); NULL walks every row in one workgroup (same result, for small batches only). */
+int vl_softmax_xent(const float* logits, const int32_t* labels, float* dlogits, float* stats, float* rows,
+                    int batch, int classes, float grad_scale, vl_stream_t stream);
 
 /* ---- optimizer: clip_by_global_norm + GradientDescentOptimizer (train.py:199-222) ---------------
  * vl_sumsq: out[0] (+)= sum g^2 over count elements (ws: float[1024]); accumulate != 0 adds to out. */

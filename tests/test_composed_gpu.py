@@ -72,6 +72,30 @@ def test_encoder_decoder_train_step(fusion, enc_layers, dec_layers, enc_h, dec_h
     assert not any(("enc/" in k) and np.abs(want[k]).max() == 0 for k in p if k.endswith("W")), "no gradient reached the encoder"
 
 
+def test_config4_full_geometry():
+    """BASELINE config 4 at its real layer shapes: 2 clips x 4 frames of 227x227x3 through AlexNet(fc6) + LSTM(256, state), the state
+    vector of a 256-unit decoder over 21 word vectors of 300 dimensions, per-step logits over 1000 classes; one train step against the
+    oracle (logits 1e-3; gradients by relative L2 per tensor: 1e-3 above pool5, where no ReLU / arg-max flip can reach, and the
+    un-gated conv-stack bound of tests/test_engine_gpu.py below it)."""
+    shape, V, E, Tf, Tw, b, H = (227, 227, 3), 1000, 300, 4, 21, 2, 256
+    eng, p, frames, words, rng = build(shape, V, H, 1, H, 1, "reshape", E, Tf, Tw, b, seed=41)
+    onehot = O.labels_to_one_hot([[l] for l in rng.integers(0, V, b * Tw)], V)
+    x = frames.astype(np.float32) - MEAN
+    enc, dec = dict(layer="fc6", layers=1), dict(layers=1, fusion="reshape")
+    logits, cache = O.encdec_forward(p, x, words, Tf, Tw, enc, dec, V, chunk=4)
+    loss, dlogits = O.softmax_xent_mean(logits, onehot)
+    want = O.encdec_backward(p, cache, dlogits, Tf, enc)
+    fd, wd, od = torch.tensor(frames, device=DEV), torch.tensor(words, device=DEV), torch.tensor(onehot, device=DEV)
+    out = eng.train_step(fd, wd, od, lr=0.0, clip_norm=0.0, mean_bgr=MEAN)
+    np.testing.assert_allclose(eng.logits_host(), logits, rtol=1e-3, atol=1e-3)
+    assert abs(out["loss"] - loss) < 1e-4 * max(1, abs(loss))
+    g = eng.get_grads()
+    for k in p:
+        err = np.linalg.norm((g[k] - want[k]).ravel()) / (np.linalg.norm(want[k].ravel()) + 1e-30)
+        bound = 2.5e-2 if k.startswith("enc/dcnn/conv") else 1e-3
+        assert err < bound, "grad %s: relative L2 error %.3e" % (k, err)
+
+
 @pytest.mark.parametrize("input_fusion,representation,ratio", [("concat", "nop", 2), ("ibias", "fc", 1), (None, "fc", 2), ("ibias", "fc", 3)])
 def test_input_fusion_replication_and_fc_representation(input_fusion, representation, ratio):
     """apply_tensor_list_fusion concat (the vec_seq_concat branch: clips-per-video ratio > 1) / ibias of a word sequence with the

@@ -585,8 +585,10 @@ def test_dropout(ops):
 
 
 # ---- loss / optimizer --------------------------------------------------------------------------------
-@pytest.mark.parametrize("b,c", [(6, 9), (64, 101), (9, 200)])
-def test_softmax_xent(ops, b, c):
+@pytest.mark.parametrize("rows_ws", [False, True])
+@pytest.mark.parametrize("b,c", [(6, 9), (64, 101), (9, 200), (1344, 1000)])
+def test_softmax_xent(ops, b, c, rows_ws):
+    """rows_ws: one wave per row over the chip + fixed-order sum (the engines' path) vs one workgroup walking the batch."""
     rng = np.random.default_rng(b)
     z = (rng.standard_normal((b, c)) * 5).astype(np.float32)
     lab = rng.integers(0, c, b)
@@ -595,9 +597,16 @@ def test_softmax_xent(ops, b, c):
     loss, dz = O.softmax_xent_mean(z, onehot)
     stats = torch.zeros(2, device=DEV)
     dl = torch.empty((b, c), device=DEV)
-    ops.softmax_xent(dev(z), dev(onehot, torch.int32), dl, stats, 1.0 / b)
+    rows = torch.full((2 * b,), float("nan"), device=DEV) if rows_ws else None
+    ops.softmax_xent(dev(z), dev(onehot, torch.int32), dl, stats, 1.0 / b, rows)
     s = host(stats)
     assert abs(s[0] / b - loss) < 1e-5 * max(1.0, abs(loss))
+    if rows_ws:                                                 # the workspace holds the per-row terms; twice gives the same bits
+        r = host(rows)
+        assert abs(r[:b].astype(np.float64).sum() / b - loss) < 1e-5 * max(1.0, abs(loss))
+        stats2 = torch.zeros(2, device=DEV)
+        ops.softmax_xent(dev(z), dev(onehot, torch.int32), dl, stats2, 1.0 / b, rows)
+        assert host(stats2).tobytes() == s.tobytes()
     assert s[1] == round(O.accuracy(z, onehot) * b)
     close(host(dl), dz, rtol=1e-4, atol_rel=1e-6)
 

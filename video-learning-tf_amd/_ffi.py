@@ -52,7 +52,7 @@ SIGNATURES = {
     "vl_temporal_fusion_bwd": (i32, [p, p, i32, i32, i32, i32, p]),
     "vl_dropout_fwd": (i32, [p, p, p, i64, f32, u64, p]),
     "vl_dropout_bwd": (i32, [p, p, p, i64, f32, p]),
-    "vl_softmax_xent": (i32, [p, p, p, p, i32, i32, f32, p]),
+    "vl_softmax_xent": (i32, [p, p, p, p, p, i32, i32, f32, p]),
     "vl_sumsq": (i32, [p, i64, p, p, i32, p]),
     "vl_sgd_apply": (i32, [p, p, i64, f32, f32, p, f32, p]),
     "vl_adam_apply": (i32, [p, p, p, p, i64, f32, f32, p, f32, i32, p]),

@@ -176,6 +176,7 @@ class ComposedEngine:
             self.dxfc = buf(B * T, self.E) if self.xfc is not None else None
             self.tmp_enc = buf(B, enc_dim) if head.input_fusion == "concat" else None
         self.stats = torch.zeros(2, device=dev)
+        self.loss_rows = torch.zeros(2 * rows, device=dev)              # per-row losses | hits (vl_softmax_xent workspace)
         self.ss = torch.zeros(1, device=dev)
 
     # ---- parameters --------------------------------------------------------------------------------------------------------------
@@ -369,7 +370,7 @@ class ComposedEngine:
             raise VltfError("labels must be int32 one-hot of shape (%d, %d)" % (rows, self.h.num_classes))
         world = self.dp.world if self.dp is not None else 1
         ops.fill(self.stats, 0.0)
-        ops.softmax_xent(self.logits[:rows], onehot, self.dlogits, self.stats, 1.0 / (global_rows or rows * world))
+        ops.softmax_xent(self.logits[:rows], onehot, self.dlogits, self.stats, 1.0 / (global_rows or rows * world), self.loss_rows)
         self._head_backward(b1)
         if self.dp is not None and self.grad_chunks:
             self.dp.reduce_async(self.g, *self.grad_chunks[0])

@@ -1285,53 +1285,61 @@ extern "C" int vl_dropout_bwd(const float* dy, const uint8_t* mask, float* dx, i
 }
 
 // ---- softmax cross-entropy, mean over the batch (train.py:120-123) + accuracy (142-149) --------
-// One workgroup; wave w takes rows w, w+4, ...; fixed summation order -> bitwise reproducible.
+// One wave per row.  Row losses / hits go to a per-row workspace and are summed in a fixed order by a second one-workgroup
+// kernel -> bitwise reproducible at any batch; without a workspace one workgroup walks all rows (small batches only).
+__device__ __forceinline__ void softmax_xent_row(const float* __restrict__ z, const int32_t* __restrict__ y, float* __restrict__ dz,
+                                                 int C, float gscale, int lane, float& loss, float& hit) {
+    float mx = -INFINITY;
+    int am = 0x7fffffff;
+    for (int c = lane; c < C; c += 64) {
+        const float v = z[c];
+        if (v > mx) {
+            mx = v;
+            am = c;
+        }
+    }
+    const float gmx = wave_max(mx);
+    // first index attaining the maximum
+    int cand = (mx == gmx) ? am : 0x7fffffff;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o, 64));
+    float se = 0.f;
+    for (int c = lane; c < C; c += 64) se += expf(z[c] - gmx);
+    se = wave_sum(se);
+    const float lse = logf(se) + gmx;
+    float l = 0.f;
+    int ymax = -2147483647 - 1, yarg = 0x7fffffff;
+    for (int c = lane; c < C; c += 64) {
+        const int yv = y[c];
+        l += (float)yv * (lse - z[c]);
+        if (yv > ymax) {
+            ymax = yv;
+            yarg = c;
+        }
+        if (dz) dz[c] = (expf(z[c] - lse) - (float)yv) * gscale;
+    }
+    l = wave_sum(l);
+    int gy = ymax;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) gy = max(gy, __shfl_xor(gy, o, 64));
+    int ycand = (ymax == gy) ? yarg : 0x7fffffff;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ycand = min(ycand, __shfl_xor(ycand, o, 64));
+    loss = l;
+    hit = (cand == ycand) ? 1.f : 0.f;
+}
+
 __global__ void softmax_xent_kernel(const float* __restrict__ logits, const int32_t* __restrict__ labels,
                                     float* __restrict__ dlogits, float* __restrict__ stats, int batch, int C, float gscale) {
     __shared__ float sl[4], sc[4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float loss_acc = 0.f, corr_acc = 0.f;
     for (int b = wv; b < batch; b += 4) {
-        const float* z = logits + (int64_t)b * C;
-        const int32_t* y = labels + (int64_t)b * C;
-        float mx = -INFINITY;
-        int am = 0x7fffffff;
-        for (int c = lane; c < C; c += 64) {
-            const float v = z[c];
-            if (v > mx) {
-                mx = v;
-                am = c;
-            }
-        }
-        const float gmx = wave_max(mx);
-        // first index attaining the maximum
-        int cand = (mx == gmx) ? am : 0x7fffffff;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o, 64));
-        float se = 0.f;
-        for (int c = lane; c < C; c += 64) se += expf(z[c] - gmx);
-        se = wave_sum(se);
-        const float lse = logf(se) + gmx;
-        float l = 0.f;
-        int ymax = -2147483647 - 1, yarg = 0x7fffffff;
-        for (int c = lane; c < C; c += 64) {
-            const int yv = y[c];
-            l += (float)yv * (lse - z[c]);
-            if (yv > ymax) {
-                ymax = yv;
-                yarg = c;
-            }
-            if (dlogits) dlogits[(int64_t)b * C + c] = (expf(z[c] - lse) - (float)yv) * gscale;
-        }
-        l = wave_sum(l);
-        int gy = ymax;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) gy = max(gy, __shfl_xor(gy, o, 64));
-        int ycand = (ymax == gy) ? yarg : 0x7fffffff;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) ycand = min(ycand, __shfl_xor(ycand, o, 64));
+        float l, h;
+        softmax_xent_row(logits + (int64_t)b * C, labels + (int64_t)b * C, dlogits ? dlogits + (int64_t)b * C : nullptr, C, gscale,
+                         lane, l, h);
         loss_acc += l;
-        corr_acc += (cand == ycand) ? 1.f : 0.f;
+        corr_acc += h;
     }
     if (lane == 0) {
         sl[wv] = loss_acc;
@@ -1344,11 +1352,56 @@ __global__ void softmax_xent_kernel(const float* __restrict__ logits, const int3
     }
 }
 
-extern "C" int vl_softmax_xent(const float* logits, const int32_t* labels, float* dlogits, float* stats, int batch, int classes,
-                               float grad_scale, vl_stream_t stream) {
+__global__ void softmax_xent_rows_kernel(const float* __restrict__ logits, const int32_t* __restrict__ labels,
+                                         float* __restrict__ dlogits, float* __restrict__ rows, int batch, int C, float gscale) {
+    const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= batch) return;
+    float l, h;
+    softmax_xent_row(logits + (int64_t)b * C, labels + (int64_t)b * C, dlogits ? dlogits + (int64_t)b * C : nullptr, C, gscale, lane,
+                     l, h);
+    if (lane == 0) {
+        rows[b] = l;
+        rows[batch + b] = h;
+    }
+}
+
+// rows[0..batch) losses, rows[batch..2 batch) hits -> stats += their sums; thread t adds rows t, t+256, ... then a fixed tree.
+__global__ void softmax_xent_sum_kernel(const float* __restrict__ rows, float* __restrict__ stats, int batch) {
+    __shared__ float sl[256], sc[256];
+    float l = 0.f, h = 0.f;
+    for (int b = threadIdx.x; b < batch; b += 256) {
+        l += rows[b];
+        h += rows[batch + b];
+    }
+    sl[threadIdx.x] = l;
+    sc[threadIdx.x] = h;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            sl[threadIdx.x] += sl[threadIdx.x + s];
+            sc[threadIdx.x] += sc[threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        stats[0] += sl[0];
+        stats[1] += sc[0];
+    }
+}
+
+extern "C" int vl_softmax_xent(const float* logits, const int32_t* labels, float* dlogits, float* stats, float* rows, int batch,
+                               int classes, float grad_scale, vl_stream_t stream) {
     VL_CHECK(logits && labels && stats && batch > 0 && classes > 0, "vl_softmax_xent: bad argument");
-    hipLaunchKernelGGL(softmax_xent_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, labels, dlogits, stats, batch,
-                       classes, grad_scale);
+    if (!rows) {
+        hipLaunchKernelGGL(softmax_xent_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, labels, dlogits, stats, batch,
+                           classes, grad_scale);
+        VL_LAUNCH_CHECK();
+        return 0;
+    }
+    hipLaunchKernelGGL(softmax_xent_rows_kernel, dim3((batch + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, labels, dlogits,
+                       rows, batch, classes, grad_scale);
+    VL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(softmax_xent_sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, rows, stats, batch);
     VL_LAUNCH_CHECK();
     return 0;
 }

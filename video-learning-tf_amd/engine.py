@@ -298,6 +298,7 @@ class LRCNEngine:
         if training:
             self.dlogits = buf(*self.logits.shape)
         self.stats = torch.zeros(2, device=dev)
+        self.loss_rows = torch.zeros(2 * self.rows_out, device=dev)     # per-row losses | hits (vl_softmax_xent workspace)
         self.ss = torch.zeros(1, device=dev)
         self.probe, self.probe_events = None, []
         self._resizers = {}
@@ -625,7 +626,7 @@ class LRCNEngine:
         ops.fill(self.stats, 0.0)
         # mean over the GLOBAL batch (train.py:123): each rank scales its rows by 1/global_rows and the all-reduce sums.
         # global_rows defaults to rows*world (equal shards); a workflow with ragged shards passes the true count.
-        ops.softmax_xent(self.logits[:rows], onehot, self.dlogits, self.stats, 1.0 / (global_rows or rows * world))
+        ops.softmax_xent(self.logits[:rows], onehot, self.dlogits, self.stats, 1.0 / (global_rows or rows * world), self.loss_rows)
         self._backward(n, b)
         return self._finish_step(rows, lr, clip_norm, fetch)
 

@@ -332,12 +332,17 @@ def dropout_bwd(dy, mask, dx, keep):
 
 
 # ---- loss / optimizer ----------------------------------------------------------------------------
-def softmax_xent(logits, labels, dlogits, stats, grad_scale):
+def softmax_xent(logits, labels, dlogits, stats, grad_scale, rows=None):
+    """rows: float32 workspace of >= 2*batch elements (per-row losses and hits); without it one workgroup walks the batch."""
     _f32(logits, dlogits, stats); _dense(logits, labels, dlogits)
     if labels.dtype != torch.int32:
         raise _ffi.VltfError("softmax_xent: labels must be int32 one-hot")
     b, c = logits.shape
-    _ffi.call("vl_softmax_xent", _p(logits), _p(labels), _p(dlogits), _p(stats), b, c, grad_scale, stream())
+    if rows is not None:
+        _f32(rows)
+        if rows.numel() < 2 * b:
+            raise _ffi.VltfError("softmax_xent: rows workspace needs 2*batch floats")
+    _ffi.call("vl_softmax_xent", _p(logits), _p(labels), _p(dlogits), _p(stats), _p(rows), b, c, grad_scale, stream())
 
 
 def sumsq(g, out, ws, accumulate=False):
