@@ -107,6 +107,31 @@ size_t vl_conv_wgrad_ws_bytes(const vl_conv_desc* d, int n);
 int vl_conv_wgrad_fuses_bias(const vl_conv_desc* d);
 int vl_conv_wgrad(const vl_conv_desc* d, const float* x, const float* dy, float* dw, float* db, void* ws,
                   size_t ws_bytes, int n, vl_stream_t stream);
+/* ---- the bf16 conv PATH (BASELINE config 5; csrc/conv_c8.hip) --------------------------------------
+ * Same arithmetic as vl_set_conv_math(1) -- operands rounded to bf16 (nearest even), fp32 accumulation, fp32 bias / ReLU -- but the
+ * operands ARE bf16 in memory, in the "c8" layout: a tensor [n][c][h][w] with halo p is stored
+ * [n][ceil(c/8)][h + 2p][w + 2p][8] bf16 (8 consecutive channels of a pixel = one 16-byte chunk = one MFMA operand; zero halo, zero
+ * beyond c).  Kernels fetch 16 bytes per lane straight into LDS and run v_mfma_f32_32x32x16_bf16 with no conversion in the loop.
+ * Layers: channels per group a multiple of 8, padded layout (vl_conv_set_halo), not phase split; dgrad / wgrad: stride 1, wgrad
+ * additionally x_halo == dy_halo (every SAME layer with an odd kernel).  Halos are those of the descriptor, as for the fp32 calls.
+ *   vl_c8_bytes            bytes of a c8 tensor (allocate zeroed once: only interiors are ever written)
+ *   vl_pack_c8             fp32 NCHW (x_halo) -> c8 (xb_halo): the stand-alone producer
+ *   vl_conv_c8_pack_w      HWIO fp32 weights -> the packed operand of vl_conv_c8_fwd (bwd = 0) / vl_conv_c8_dgrad (bwd = 1);
+ *                          wb: vl_conv_c8_w_bytes(d, bwd) bytes
+ *   vl_conv_c8_fwd         y (fp32 NCHW, y_halo; may be NULL) and / or yb (c8, y_halo; may be NULL) = conv(xb) + bias (ReLU)
+ *   vl_conv_c8_dgrad       dx (fp32 NCHW, dx_halo) and / or dxb (c8, dx_halo) from dyb (c8, dy_halo); relu_mask as vl_conv_dgrad
+ *   vl_conv_c8_wgrad       dw (HWIO fp32) from xb and dyb; deterministic slab reduction through ws (vl_conv_c8_wgrad_ws_bytes) */
+size_t vl_c8_bytes(int n, int c, int h, int w, int halo);
+int vl_pack_c8(const float* x, void* xb, int n, int c, int h, int w, int x_halo, int xb_halo, vl_stream_t stream);
+size_t vl_conv_c8_w_bytes(const vl_conv_desc* d, int bwd);
+int vl_conv_c8_pack_w(const vl_conv_desc* d, const float* w_hwio, void* wb, int bwd, vl_stream_t stream);
+int vl_conv_c8_fwd(vl_conv_desc* d, const void* xb, const void* wb, const float* bias, float* y, void* yb, int n, int relu,
+                   vl_stream_t stream);
+int vl_conv_c8_dgrad(vl_conv_desc* d, const void* dyb, const void* wbt, float* dx, void* dxb, const float* relu_mask, int n,
+                     vl_stream_t stream);
+size_t vl_conv_c8_wgrad_ws_bytes(const vl_conv_desc* d, int n);
+int vl_conv_c8_wgrad(vl_conv_desc* d, const void* xb, const void* dyb, float* dw, void* ws, size_t ws_bytes, int n,
+                     vl_stream_t stream);
 /* db[c] = sum_{n,h,w} dy[n][c][h][w]  (gradient of tf.nn.bias_add, alexnet.py:31).
  * ws: float[64*c] scratch. */
 int vl_bias_grad_nchw(const float* dy, float* db, float* ws, int n, int c, int hw, vl_stream_t stream);

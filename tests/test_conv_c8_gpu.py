@@ -1,0 +1,164 @@
+"""The bf16 conv PATH (csrc/conv_c8.hip; include/vltf.h "c8"): operands packed bf16 in memory, v_mfma_f32_32x32x16_bf16, fp32
+accumulation.  The arithmetic is exactly "round both operands to bf16 (nearest even), multiply-accumulate in fp32", so the oracle
+evaluated on bf16-ROUNDED inputs must agree to fp32 summation-order error -- the tolerances below are the fp32 ones, not bf16 ones.
+Parity unpinned: the reference has no bf16 path; this is BASELINE config 5's reduced-precision conv arithmetic."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import lrcn_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import vltf_amd.ops as ops_
+    return ops_
+
+
+def bf16_round(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).bfloat16().float().numpy()
+
+
+def nchw(a):
+    return np.ascontiguousarray(np.transpose(a, (0, 3, 1, 2)))
+
+
+def nhwc(a):
+    return np.ascontiguousarray(np.transpose(a, (0, 2, 3, 1)))
+
+
+def to_c8(a_nhwc, halo):
+    """NHWC fp32 (values already bf16-representable) -> device bf16 [n][cb][h + 2 halo][w + 2 halo][8]."""
+    n, h, w, c = a_nhwc.shape
+    cb = (c + 7) // 8
+    full = np.zeros((n, h + 2 * halo, w + 2 * halo, cb * 8), np.float32)
+    full[:, halo:halo + h, halo:halo + w, :c] = a_nhwc
+    t = torch.from_numpy(np.ascontiguousarray(full.reshape(n, h + 2 * halo, w + 2 * halo, cb, 8).transpose(0, 3, 1, 2, 4)))
+    return t.to(DEV).bfloat16().contiguous()
+
+
+def from_c8(t, c, halo):
+    """device c8 -> host NHWC fp32 interior, + the halo / channel-padding values (must be zero)."""
+    torch.cuda.synchronize()
+    a = t.float().cpu().numpy()                                   # [n][cb][hp][wp][8]
+    n, cb, hp, wp, _ = a.shape
+    full = a.transpose(0, 2, 3, 1, 4).reshape(n, hp, wp, cb * 8)
+    inner = full[:, halo:hp - halo, halo:wp - halo, :c]
+    outside = full.copy()
+    outside[:, halo:hp - halo, halo:wp - halo, :c] = 0
+    return np.ascontiguousarray(inner), outside
+
+
+def close(got, want, rtol=3e-5, atol_rel=3e-5, msg=""):
+    want = np.asarray(want, np.float64)
+    scale = float(np.abs(want).max()) or 1.0
+    np.testing.assert_allclose(np.asarray(got, np.float64), want, rtol=rtol, atol=atol_rel * scale, err_msg=msg)
+
+
+def pad_nchw(a_nchw, halo):
+    return np.pad(a_nchw, ((0, 0), (0, 0), (halo, halo), (halo, halo)))
+
+
+def test_pack_c8(ops):
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((3, 7, 9, 20)).astype(np.float32)                      # 20 channels: the third block is half empty
+    xd = torch.from_numpy(pad_nchw(nchw(x), 2)).to(DEV)
+    xb = torch.zeros(ops.c8_shape(3, 20, 7, 9, 1), dtype=torch.bfloat16, device=DEV)
+    ops.pack_c8(xd, xb, 2, 1)
+    inner, outside = from_c8(xb, 20, 1)
+    assert np.array_equal(inner, bf16_round(x))
+    assert not outside.any()
+
+
+# n, h, w, cin, cout, k, groups: AlexNet's stride-1 layers (conv2 .. conv5; conv4's 192-channel groups take the 192-wide tile), a
+# narrow layer (24 output channels per group: the 64-wide tile; 18 taps -> a padded last stage) and a batch that ends inside a pixel tile
+C8_CASES = [(3, 13, 13, 256, 384, 3, 1), (2, 27, 27, 96, 256, 5, 2), (2, 13, 13, 384, 384, 3, 2), (2, 13, 13, 384, 256, 3, 2),
+            (5, 9, 11, 32, 48, 3, 2), (21, 13, 13, 64, 128, 3, 1)]
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout,k,g", C8_CASES)
+def test_conv_c8_fwd_dgrad_wgrad(ops, n, h, w, cin, cout, k, g):
+    rng = np.random.default_rng(h * 100 + cin)
+    x = bf16_round(np.maximum(rng.standard_normal((n, h, w, cin)), 0))             # post-ReLU-like input (zeros included)
+    wt = (rng.standard_normal((k, k, cin // g, cout)) / math.sqrt(k * k * cin / g)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    dy = bf16_round(rng.standard_normal((n, h, w, cout)))
+    wr = bf16_round(wt)
+    conv = ops.Conv(cin, h, w, cout, k, k, 1, g)
+    pad = conv.same_pad()
+    conv.set_halo(pad, 1, pad, 2)                                                  # x / dy: the SAME padding; y: 1; dx: 2
+    xb, dyb = to_c8(x, pad), to_c8(dy, pad)
+    wd = torch.from_numpy(wt).to(DEV)
+    wb = torch.zeros(conv.c8_w_bytes(False), dtype=torch.uint8, device=DEV)
+    wbt = torch.zeros(conv.c8_w_bytes(True), dtype=torch.uint8, device=DEV)
+    conv.c8_pack_w(wd, wb, False)
+    conv.c8_pack_w(wd, wbt, True)
+
+    # forward: fp32 NCHW and c8 outputs of the same launch
+    z = O.grouped_conv(x, wr, b, 1, g)
+    y = torch.zeros((n, cout, h + 2, w + 2), device=DEV)
+    yb = torch.zeros(ops.c8_shape(n, cout, h, w, 1), dtype=torch.bfloat16, device=DEV)
+    conv.c8_fwd(xb, wb, torch.from_numpy(b).to(DEV), y=y, yb=yb, relu=False)
+    torch.cuda.synchronize()
+    yh = y.cpu().numpy()
+    close(nhwc(yh[:, :, 1:-1, 1:-1]), z, msg="c8 fwd (fp32 out)")
+    assert not yh[:, :, 0].any() and not yh[:, :, :, -1].any()
+    inner, outside = from_c8(yb, cout, 1)
+    assert np.array_equal(inner, bf16_round(nhwc(yh[:, :, 1:-1, 1:-1]))), "c8 output = bf16 rounding of the fp32 output"
+    assert not outside.any()
+    conv.c8_fwd(xb, wb, torch.from_numpy(b).to(DEV), y=y, relu=True)
+    close(nhwc(y.cpu().numpy()[:, :, 1:-1, 1:-1]), np.maximum(z, 0), msg="c8 fwd + relu")
+
+    dxo, dwo, _ = O.grouped_conv_grad(x, wr, dy, 1, g, need_dx=True)
+    # dgrad
+    dx = torch.zeros((n, cin, h + 4, w + 4), device=DEV)
+    dxb = torch.zeros(ops.c8_shape(n, cin, h, w, 2), dtype=torch.bfloat16, device=DEV)
+    conv.c8_dgrad(dyb, wbt, dx=dx, dxb=dxb)
+    torch.cuda.synchronize()
+    dxh = dx.cpu().numpy()
+    close(nhwc(dxh[:, :, 2:-2, 2:-2]), dxo, msg="c8 dgrad")
+    inner, outside = from_c8(dxb, cin, 2)
+    assert np.array_equal(inner, bf16_round(nhwc(dxh[:, :, 2:-2, 2:-2]))) and not outside.any()
+    mask = rng.standard_normal(x.shape).astype(np.float32)
+    conv.c8_dgrad(dyb, wbt, dx=dx, relu_mask=torch.from_numpy(pad_nchw(nchw(mask), 2)).to(DEV))
+    close(nhwc(dx.cpu().numpy()[:, :, 2:-2, 2:-2]), dxo * (mask > 0), msg="c8 dgrad + mask")
+    # wgrad (twice: bitwise reproducible)
+    dw = torch.empty_like(wd)
+    ws = torch.empty(max(conv.c8_wgrad_ws_bytes(n) // 4, 1), device=DEV)
+    conv.c8_wgrad(xb, dyb, dw, ws)
+    close(dw.cpu().numpy(), dwo, msg="c8 wgrad")
+    dw2 = torch.empty_like(wd)
+    conv.c8_wgrad(xb, dyb, dw2, ws)
+    assert torch.equal(dw, dw2)
+
+
+def test_c8_matches_the_in_loop_bf16_mode(ops):
+    """The c8 path and vl_set_conv_math(1) (fp32 operands rounded inside the loop) are the same arithmetic."""
+    rng = np.random.default_rng(3)
+    n, h, w, cin, cout, k, g = 4, 13, 13, 256, 384, 3, 1
+    x = np.maximum(rng.standard_normal((n, h, w, cin)), 0).astype(np.float32)
+    wt = (rng.standard_normal((k, k, cin, cout)) / math.sqrt(k * k * cin)).astype(np.float32)
+    conv = ops.Conv(cin, h, w, cout, k, k, 1, g)
+    conv.set_halo(1, 0, 1, 0)
+    xd = torch.from_numpy(pad_nchw(nchw(x), 1)).to(DEV)
+    wd, bd = torch.from_numpy(wt).to(DEV), torch.zeros(cout, device=DEV)
+    y1 = torch.empty((n, cout, h, w), device=DEV)
+    ops.set_conv_math("bf16")
+    try:
+        conv.fwd(xd, wd, bd, y1, relu=False)
+    finally:
+        ops.set_conv_math("f32")
+    xb = torch.zeros(ops.c8_shape(n, cin, h, w, 1), dtype=torch.bfloat16, device=DEV)
+    ops.pack_c8(xd, xb, 1, 1)
+    wb = torch.zeros(conv.c8_w_bytes(False), dtype=torch.uint8, device=DEV)
+    conv.c8_pack_w(wd, wb, False)
+    y2 = torch.empty_like(y1)
+    conv.c8_fwd(xb, wb, bd, y=y2, relu=False)
+    torch.cuda.synchronize()
+    close(y2.cpu().numpy(), y1.cpu().numpy(), rtol=1e-5, atol_rel=1e-5)

@@ -32,6 +32,14 @@ SIGNATURES = {
     "vl_conv_wgrad_ws_bytes": (sz, [p, i32]),
     "vl_conv_wgrad_fuses_bias": (i32, [p]),
     "vl_conv_wgrad": (i32, [p, p, p, p, p, p, sz, i32, p]),
+    "vl_c8_bytes": (sz, [i32, i32, i32, i32, i32]),
+    "vl_pack_c8": (i32, [p, p, i32, i32, i32, i32, i32, i32, p]),
+    "vl_conv_c8_w_bytes": (sz, [p, i32]),
+    "vl_conv_c8_pack_w": (i32, [p, p, p, i32, p]),
+    "vl_conv_c8_fwd": (i32, [p, p, p, p, p, p, i32, i32, p]),
+    "vl_conv_c8_dgrad": (i32, [p, p, p, p, p, p, i32, p]),
+    "vl_conv_c8_wgrad_ws_bytes": (sz, [p, i32]),
+    "vl_conv_c8_wgrad": (i32, [p, p, p, p, p, sz, i32, p]),
     "vl_bias_grad_nchw": (i32, [p, p, p, i32, i32, i32, p]),
     "vl_lrn_fwd": (i32, [p, p, i32, i32, i32, i32, f32, f32, f32, p]),
     "vl_lrn_bwd": (i32, [p, p, p, i32, i32, i32, i32, f32, f32, f32, i32, i32, i32, p]),

@@ -1,0 +1,753 @@
+// Packed-bf16 convolutions for gfx950: the "bf16" conv arithmetic (vl_set_conv_math mode 1: operands rounded to bf16, fp32
+// accumulation) as a bf16 PATH -- operands are bf16 in HBM and in LDS, fetched 16 bytes per lane, and reach the matrix pipe
+// (v_mfma_f32_32x32x16_bf16, 16x the fp32 MFMA rate) without a single vector-ALU instruction in the loop.
+//
+// Layout "c8": an activation tensor [n][c][h][w] is stored [n][cb = ceil(c / 8)][h + 2 halo][w + 2 halo][8] bf16 -- 8 consecutive
+// channels of one pixel are one 16-byte chunk, zero halo as in the fp32 padded layout (vltf.h, vl_conv_set_halo), zero beyond c.
+// A chunk IS the MFMA operand of its pixel for 8 reduction positions, so:
+//   * forward / dgrad: reduction order (channel block, kh, kw, channel in block) = "taps" of 8 positions.  One
+//     `buffer_load_dwordx4 ... lds` moves one tap of 64 pixels (per-lane pixel offset decoded once per tile, the tap's offset is a
+//     scalar) to 1 KB of LDS, lane l at M0 + 16 l = the [tap][pixel][16 B] image one ds_read_b128 per lane reads back as an operand
+//     (conflict free: each 16-lane service group of ds_read_b128 covers 16 different chunks of a 512-byte run).  Weights are packed
+//     once per step into [group][tap][cout][8] and fetched the same way.
+//   * wgrad reduces over PIXELS, the strided index of both operands; the LDS image [pixel][chunk] is read column-wise with
+//     ds_read_b64_tr_b16 (the hardware transpose read of gfx950), see wgrad_c8_kernel.
+// Producers write the c8 copies (vl_pack_c8 as a stand-alone producer; the fused forms live with the producers).
+#include <stdlib.h>
+#include <string.h>
+
+#include "common.h"
+#include "conv_desc.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(4))) int* const_int_ptr;
+__device__ __forceinline__ const_int_ptr as_const(const int* p) { return (const_int_ptr)(uintptr_t)p; }
+
+static constexpr int64_t MAX_BUF_BYTES = 0xE0000000ll;
+
+__device__ __forceinline__ i32x4 rsrc_words(const void* base, int64_t bytes) {
+    const uint64_t a = (uint64_t)base;
+    return i32x4{(int)(uint32_t)a, (int)((uint32_t)(a >> 32) & 0xffffu), (int)(uint32_t)bytes, 0x00020000};
+}
+// LDS-DMA, 16 bytes per lane: lane l lands at M0 + 16 l (inline asm on purpose, see mfma_gemm.hip lds_dma_row)
+__device__ __forceinline__ void lds_dma16(i32x4 rs, uint32_t lds_byte_addr, uint32_t voff, int soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_byte_addr), "v"(voff), "s"(rs), "s"(soff)
+                 : "m0");
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N));
+}
+__device__ __forceinline__ f32x16 mfma_bf16(const i32x4& a, const i32x4& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {   // round to nearest even (v_cvt_pk_bf16_f32)
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
+}
+__device__ __forceinline__ int xcd_swizzle(int id, int n) {
+    const int q = n >> 3, r = n & 7, xcd = id & 7, k = id >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
+// ---- stand-alone producers -----------------------------------------------------------------------------------------------
+// fp32 NCHW (halo hin) -> bf16 c8 (halo hout), interiors only; one thread per (n, cb, h, w)
+__global__ void pack_c8_kernel(const float* __restrict__ x, uint4* __restrict__ xb, int C, int H, int W, int hin, int hout, int CB,
+                               int64_t total, FastDiv dW, FastDiv dH, FastDiv dCB) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const uint32_t i = (uint32_t)idx;
+    const uint32_t r1 = fd_div(i, dW), w = i - r1 * dW.d;
+    const uint32_t r2 = fd_div(r1, dH), h = r1 - r2 * dH.d;
+    const uint32_t n = fd_div(r2, dCB), cb = r2 - n * dCB.d;
+    const int Wi = W + 2 * hin, Hi = H + 2 * hin, Wo = W + 2 * hout, Ho = H + 2 * hout;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = cb * 8 + j;
+        v[j] = c < C ? x[(((int64_t)n * C + c) * Hi + h + hin) * Wi + w + hin] : 0.f;
+    }
+    uint4 o;
+    o.x = pack_bf16(v[0], v[1]);
+    o.y = pack_bf16(v[2], v[3]);
+    o.z = pack_bf16(v[4], v[5]);
+    o.w = pack_bf16(v[6], v[7]);
+    xb[(((int64_t)n * CB + cb) * Ho + h + hout) * Wo + w + hout] = o;
+}
+
+extern "C" size_t vl_c8_bytes(int n, int c, int h, int w, int halo) {
+    return (size_t)n * ((c + 7) / 8) * (h + 2 * halo) * (w + 2 * halo) * 16;
+}
+
+extern "C" int vl_pack_c8(const float* x, void* xb, int n, int c, int h, int w, int x_halo, int xb_halo, vl_stream_t stream) {
+    VL_CHECK(x && xb && n > 0 && c > 0 && h > 0 && w > 0 && x_halo >= 0 && xb_halo >= 0, "vl_pack_c8: bad argument");
+    const int CB = (c + 7) / 8;
+    const int64_t total = (int64_t)n * CB * h * w;
+    VL_CHECK(total < (1ll << 31), "vl_pack_c8: tensor too large");
+    hipLaunchKernelGGL(pack_c8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, (uint4*)xb, c, h, w, x_halo,
+                       xb_halo, CB, total, make_fastdiv(w), make_fastdiv(h), make_fastdiv(CB));
+    VL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- reduction taps and packed weights -------------------------------------------------------------------------------------
+static constexpr int KT = 4;   // taps (32 reduction positions = two MFMA steps) per pipeline stage of conv_c8_kernel
+
+// taps of one group: t = (cb * kh + ky) * kw + kx over the group's cbg channel blocks, padded to a multiple of KT
+static int c8_taps(int cg, int kh, int kw) { return ((cg + 7) / 8) * kh * kw; }
+static int c8_taps_padded(int cg, int kh, int kw) { return (c8_taps(cg, kh, kw) + KT - 1) / KT * KT; }
+static int c8_cop(int cog) { return (cog + 63) / 64 * 64; }   // channel pitch of the packed weights: whole 64-channel fetches
+
+// out[g][t][co < CoP][8]: forward  (bwd = 0): W[ky][kx][cb * 8 + j][g * cog + co]              (reduce over input channels)
+//                         dgrad    (bwd = 1): W[kh-1-ky][kw-1-kx][co][g * cog + cb * 8 + j]     (reduce over output channels; "co" = ci)
+__global__ void pack_w_c8_kernel(const float* __restrict__ w, uint4* __restrict__ out, int kh, int kw, int cig, int cog, int cout,
+                                 int bwd, int ntaps, int ntaps_p, int CoP) {
+    const int g = blockIdx.y;
+    const int rows = bwd ? cig : cog, red = bwd ? cog : cig;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < ntaps_p * CoP; idx += gridDim.x * blockDim.x) {
+        const int co = idx % CoP, t = idx / CoP;
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (t < ntaps && co < rows) {
+            const int kx = t % kw, ky = (t / kw) % kh, cb = t / (kw * kh);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = cb * 8 + j;
+                if (c < red)
+                    v[j] = bwd ? w[((int64_t)((kh - 1 - ky) * kw + (kw - 1 - kx)) * cig + co) * cout + g * cog + c]
+                               : w[((int64_t)(ky * kw + kx) * cig + c) * cout + g * cog + co];
+            }
+        }
+        uint4 o;
+        o.x = pack_bf16(v[0], v[1]);
+        o.y = pack_bf16(v[2], v[3]);
+        o.z = pack_bf16(v[4], v[5]);
+        o.w = pack_bf16(v[6], v[7]);
+        out[((int64_t)g * ntaps_p + t) * CoP + co] = o;
+    }
+}
+
+extern "C" size_t vl_conv_c8_w_bytes(const vl_conv_desc* d, int bwd) {
+    if (!d) return 0;
+    const int red = bwd ? d->cog : d->cig, rows = bwd ? d->cig : d->cog;
+    return (size_t)d->groups * c8_taps_padded(red, d->kh, d->kw) * c8_cop(rows) * 16;
+}
+
+extern "C" int vl_conv_c8_pack_w(const vl_conv_desc* d, const float* w_hwio, void* wb, int bwd, vl_stream_t stream) {
+    VL_CHECK(d && w_hwio && wb, "vl_conv_c8_pack_w: bad argument");
+    const int red = bwd ? d->cog : d->cig, rows = bwd ? d->cig : d->cog;
+    const int nt = c8_taps(red, d->kh, d->kw), ntp = c8_taps_padded(red, d->kh, d->kw), CoP = c8_cop(rows);
+    hipLaunchKernelGGL(pack_w_c8_kernel, dim3((ntp * CoP + 255) / 256, d->groups), dim3(256), 0, (hipStream_t)stream, w_hwio, (uint4*)wb,
+                       d->kh, d->kw, d->cig, d->cog, d->cout, bwd, nt, ntp, CoP);
+    VL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- forward / dgrad ---------------------------------------------------------------------------------------------------------
+// out[co][pixel] = sum over taps W[tap][co][8] . X[tap][pixel][8]; MFMA A = weights (rows = co), B = pixels (columns = lanes), so an
+// accumulator register q of lane l is (co = 8 (q >> 2) + 4 (l >> 5) + (q & 3), pixel = l & 31).
+// Workgroup = WP x WQ waves, each TP x TQ blocks of 32 pixels x 32 channels: P = 32 WP TP pixels x Q = 32 WQ TQ channels.
+// Pipeline: ring of NBUF stages of KT taps; per stage every wave issues the same F fetches (ids wrap: surplus fetches repeat a
+// piece, same bytes to the same place), one barrier per stage, `s_waitcnt vmcnt` counted so that NBUF - 2 stages stay in flight.
+struct C8ConvArgs {
+    const char* x;          // gathered operand, c8
+    int64_t x_img;          // bytes per image
+    int64_t x_total;        // bytes in the tensor
+    int64_t x_grp;          // bytes between the first blocks of consecutive groups
+    int x_row;              // bytes per row of a plane (Wp * 16)
+    int stride;
+    int OW, OHW, M;         // output pixels per row / image / in all
+    FastDiv dOHW, dOW;
+    const int* toff;        // byte offset of tap t within an image's group (padded taps: 0)
+    int nstages;
+    const char* w;          // packed weights [g][nstages * KT][CoP][8]
+    int CoP, Cog, Ctot;     // channel pitch of w; output channels per group / in all
+    const float* bias;      // [Ctot] or null
+    int relu;
+    float* y;               // fp32 NCHW output with halo (null: not written)
+    const float* mask;      // fp32, y's layout: out = mask > 0 ? out : 0 (fused ReluGrad), or null
+    int y_halo, y_w;        // y: plane width (OW + 2 halo)
+    int64_t y_plane;        // floats per plane
+    char* yb;               // bf16 c8 output with halo (null: not written)
+    int yb_halo, yb_row;    // bytes per row
+    int64_t yb_plane;       // bytes per plane
+    int yb_cb;              // channel blocks per image
+};
+
+template <int WP, int WQ, int TP, int TQ>
+struct C8Cfg {
+    static constexpr int NW = WP * WQ, NT = 64 * NW, P = 32 * WP * TP, Q = 32 * WQ * TQ, NBUF = 4;
+    static constexpr int PIX_BYTES = KT * P * 16, W_BYTES = KT * Q * 16, SLOT = PIX_BYTES + W_BYTES;
+    static constexpr int NPI = KT * P / 64, NWI = KT * Q / 64;             // 1 KB fetches per stage: pixels, weights
+    static constexpr int FP = (NPI + NW - 1) / NW, FW = (NWI + NW - 1) / NW, F = FP + FW;
+    static constexpr size_t LDS_BYTES = (size_t)NBUF * SLOT;
+    static_assert(Q % 64 == 0 && P % 64 == 0, "whole 64-lane fetches");
+};
+
+template <int WP, int WQ, int TP, int TQ>
+__global__ __launch_bounds__(64 * WP * WQ) void conv_c8_kernel(const C8ConvArgs a, int tiles_q) {
+    using C = C8Cfg<WP, WQ, TP, TQ>;
+    constexpr int NW = C::NW, P = C::P, Q = C::Q, NBUF = C::NBUF, SLOT = C::SLOT, FP = C::FP, FW = C::FW, F = C::F;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int bid = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int tq = bid % tiles_q, tp = bid / tiles_q, g = blockIdx.y;
+    const int p0 = tp * P, q0 = tq * Q;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wp = wave % WP, wq = wave / WP;
+    const int nstages = a.nstages;
+
+    // ---- fetch plan ----
+    const int n0 = (int)fd_div((uint32_t)p0, a.dOHW);
+    const int64_t xoff = (int64_t)n0 * a.x_img + (int64_t)g * a.x_grp;
+    int64_t xbytes = a.x_total - xoff;
+    if (xbytes > MAX_BUF_BYTES) xbytes = MAX_BUF_BYTES;
+    const i32x4 rs_x = rsrc_words(a.x + xoff, xbytes);
+    const int64_t wgrp = (int64_t)nstages * KT * a.CoP * 16;
+    const i32x4 rs_w = rsrc_words(a.w + (int64_t)g * wgrp, wgrp);
+    uint32_t voff_p[FP], lds_p[FP], voff_w[FW], lds_w[FW];
+    int tap_p[FP], tap_w[FW];
+#pragma unroll
+    for (int j = 0; j < FP; ++j) {
+        const int id = (wave + j * NW) % C::NPI, tap = id / (P / 64), pc = id % (P / 64);
+        int m = p0 + pc * 64 + lane;
+        m = m < a.M ? m : a.M - 1;
+        const uint32_t n = fd_div((uint32_t)m, a.dOHW), r = (uint32_t)m - n * a.dOHW.d;
+        const uint32_t oh = fd_div(r, a.dOW), ow = r - oh * a.dOW.d;
+        voff_p[j] = (uint32_t)((int64_t)(n - n0) * a.x_img) + oh * a.stride * a.x_row + ow * a.stride * 16;
+        tap_p[j] = tap;
+        lds_p[j] = tap * P * 16 + pc * 1024;
+    }
+#pragma unroll
+    for (int j = 0; j < FW; ++j) {
+        const int id = (wave + j * NW) % C::NWI, tap = id / (Q / 64), qc = id % (Q / 64);
+        voff_w[j] = (uint32_t)((q0 + qc * 64 + lane) * 16);
+        tap_w[j] = tap;
+        lds_w[j] = C::PIX_BYTES + tap * Q * 16 + qc * 1024;
+    }
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;   // LDS byte address of the ring
+    auto issue = [&](int st) {
+        const uint32_t slot = lds0 + (uint32_t)(st % NBUF) * SLOT;
+#pragma unroll
+        for (int j = 0; j < FP; ++j) lds_dma16(rs_x, slot + lds_p[j], voff_p[j], as_const(a.toff)[st * KT + tap_p[j]]);
+#pragma unroll
+        for (int j = 0; j < FW; ++j) lds_dma16(rs_w, slot + lds_w[j], voff_w[j], (st * KT + tap_w[j]) * a.CoP * 16);
+    };
+
+    f32x16 acc[TQ][TP];
+#pragma unroll
+    for (int j = 0; j < TQ; ++j)
+#pragma unroll
+        for (int i = 0; i < TP; ++i)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[j][i][q] = 0.f;
+
+    for (int st = 0; st < NBUF - 1 && st < nstages; ++st) issue(st);
+    const uint32_t rd_p = (uint32_t)((lane >> 5) * P * 16 + (wp * TP * 32 + (lane & 31)) * 16);
+    const uint32_t rd_w = (uint32_t)(C::PIX_BYTES + (lane >> 5) * Q * 16 + (wq * TQ * 32 + (lane & 31)) * 16);
+    for (int st = 0; st < nstages; ++st) {
+        // stage st has landed when at most the fetches of the later stages already issued are outstanding
+        const int later = (nstages - 1 - st) < (NBUF - 2) ? (nstages - 1 - st) : (NBUF - 2);
+        if (later >= 2)
+            wait_vm<2 * F>();
+        else if (later == 1)
+            wait_vm<F>();
+        else
+            wait_vm<0>();
+        __syncthreads();   // every wave's pieces of stage st are in LDS; every wave is done reading stage st - 1
+        if (st + NBUF - 1 < nstages) issue(st + NBUF - 1);
+        const char* slot = lds + (st % NBUF) * SLOT;
+#pragma unroll
+        for (int kk = 0; kk < KT / 2; ++kk) {
+            i32x4 bp[TP], aq[TQ];
+#pragma unroll
+            for (int i = 0; i < TP; ++i) bp[i] = *reinterpret_cast<const i32x4*>(slot + rd_p + kk * 2 * P * 16 + i * 512);
+#pragma unroll
+            for (int j = 0; j < TQ; ++j) aq[j] = *reinterpret_cast<const i32x4*>(slot + rd_w + kk * 2 * Q * 16 + j * 512);
+#pragma unroll
+            for (int j = 0; j < TQ; ++j)
+#pragma unroll
+                for (int i = 0; i < TP; ++i) acc[j][i] = mfma_bf16(aq[j], bp[i], acc[j][i]);
+        }
+    }
+
+    // ---- epilogue ----
+#pragma unroll
+    for (int i = 0; i < TP; ++i) {
+        const int m = p0 + (wp * TP + i) * 32 + (lane & 31);
+        if (m >= a.M) continue;
+        const uint32_t n = fd_div((uint32_t)m, a.dOHW), r = (uint32_t)m - n * a.dOHW.d;
+        const uint32_t oh = fd_div(r, a.dOW), ow = r - oh * a.dOW.d;
+        const int64_t ypix = (int64_t)(oh + a.y_halo) * a.y_w + ow + a.y_halo;
+        const int64_t ybpix = (int64_t)(oh + a.yb_halo) * a.yb_row + (int64_t)(ow + a.yb_halo) * 16 + 8 * (lane >> 5);
+#pragma unroll
+        for (int j = 0; j < TQ; ++j) {
+#pragma unroll
+            for (int qg = 0; qg < 4; ++qg) {
+                const int cog0 = q0 + (wq * TQ + j) * 32 + 8 * qg;   // first channel (within the group) of this 8-channel block
+                if (cog0 >= a.Cog) continue;
+                const int c0 = g * a.Cog + cog0 + 4 * (lane >> 5);   // this lane's 4 channels: c0 .. c0 + 3
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = acc[j][i][qg * 4 + e];
+                    if (a.bias) v[e] += a.bias[c0 + e];
+                    if (a.relu) v[e] = fmaxf(v[e], 0.f);
+                    if (a.mask) v[e] = a.mask[((int64_t)n * a.Ctot + c0 + e) * a.y_plane + ypix] > 0.f ? v[e] : 0.f;
+                    if (a.y) a.y[((int64_t)n * a.Ctot + c0 + e) * a.y_plane + ypix] = v[e];
+                }
+                if (a.yb) {
+                    uint2 o;
+                    o.x = pack_bf16(v[0], v[1]);
+                    o.y = pack_bf16(v[2], v[3]);
+                    *reinterpret_cast<uint2*>(a.yb + ((int64_t)n * a.yb_cb + (g * a.Cog + cog0) / 8) * a.yb_plane + ybpix) = o;
+                }
+            }
+        }
+    }
+}
+
+static int* upload_taps(int cg, int kh, int kw, int Hp, int Wp, int row_shift, int col_shift) {
+    const int nt = c8_taps(cg, kh, kw), ntp = c8_taps_padded(cg, kh, kw);
+    int* h = (int*)calloc(ntp, sizeof(int));
+    if (!h) return nullptr;
+    for (int t = 0; t < nt; ++t) {
+        const int kx = t % kw, ky = (t / kw) % kh, cb = t / (kw * kh);
+        h[t] = (((cb * Hp) + ky + row_shift) * Wp + kx + col_shift) * 16;
+    }
+    int* dev = nullptr;
+    if (hipMalloc((void**)&dev, sizeof(int) * ntp) != hipSuccess || hipMemcpy(dev, h, sizeof(int) * ntp, hipMemcpyHostToDevice) != hipSuccess) {
+        free(h);
+        return nullptr;
+    }
+    free(h);
+    return dev;
+}
+
+// the tap tables depend on the halos in force: built lazily, rebuilt by vl_conv_set_halo (which frees them through c8_free_tables)
+void conv_c8_free_tables(vl_conv_desc* d) {
+    if (!d) return;
+    if (d->c8_toff_fwd) (void)hipFree(d->c8_toff_fwd);
+    if (d->c8_toff_bwd) (void)hipFree(d->c8_toff_bwd);
+    d->c8_toff_fwd = d->c8_toff_bwd = nullptr;
+}
+
+static int c8_tables(vl_conv_desc* d) {
+    if (!d->c8_toff_fwd) {
+        VL_CHECK(d->fwd_padded && d->x_phase == 1, "conv c8: x needs the padded layout (halo >= SAME padding), not phase split");
+        d->c8_toff_fwd = upload_taps(d->cig, d->kh, d->kw, d->h + 2 * d->x_halo, d->w + 2 * d->x_halo, d->x_halo - d->pt, d->x_halo - d->pl);
+        VL_CHECK(d->c8_toff_fwd, "conv c8: tap table allocation failed");
+    }
+    if (!d->c8_toff_bwd && d->stride == 1 && d->bwd_padded) {
+        // dgrad: dx[h][w] = sum dy[h + ky' - (kh-1-pt)][..] Wflip[ky'][kx'] over dy with halo dy_halo
+        d->c8_toff_bwd = upload_taps(d->cog, d->kh, d->kw, d->oh + 2 * d->dy_halo, d->ow + 2 * d->dy_halo, d->dy_halo - (d->kh - 1 - d->pt),
+                                     d->dy_halo - (d->kw - 1 - d->pl));
+        VL_CHECK(d->c8_toff_bwd, "conv c8: tap table allocation failed");
+    }
+    return 0;
+}
+
+template <int WP, int WQ, int TP, int TQ>
+static int launch_c8(const C8ConvArgs& a, int groups, hipStream_t stream) {
+    using C = C8Cfg<WP, WQ, TP, TQ>;
+    auto kern = conv_c8_kernel<WP, WQ, TP, TQ>;
+    static bool attr = false;
+    if (!attr) {
+        VL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
+        attr = true;
+    }
+    const int tiles_q = (a.Cog + C::Q - 1) / C::Q, tiles_p = (a.M + C::P - 1) / C::P;
+    VL_CHECK(tiles_q * C::Q <= a.CoP, "conv c8: packed weights narrower than the channel tiling");
+    hipLaunchKernelGGL(kern, dim3(tiles_q * tiles_p, groups), dim3(C::NT), C::LDS_BYTES, stream, a, tiles_q);
+    VL_LAUNCH_CHECK();
+    return 0;
+}
+
+// channel tile by the group's channel count: 128-wide tiles, 192 as one tile of 192 (conv4 / conv5 dgrad), 64 for narrow groups
+static int dispatch_c8(const C8ConvArgs& a, int groups, hipStream_t stream) {
+    if (a.Cog <= 64) return launch_c8<4, 1, 2, 2>(a, groups, stream);          // 256 pixels x 64 channels, 4 waves
+    if (a.Cog % 128 != 0 && a.Cog % 192 == 0) return launch_c8<4, 2, 2, 3>(a, groups, stream);   // 256 x 192
+    return launch_c8<4, 2, 2, 2>(a, groups, stream);                           // 256 x 128
+}
+
+/* y = conv(x) + bias (ReLU) from the c8 operand xb and vl_conv_c8_pack_w(bwd = 0)'s weights: y (fp32 NCHW, y_halo) and / or yb
+ * (bf16 c8, y_halo) are written. */
+extern "C" int vl_conv_c8_fwd(vl_conv_desc* d, const void* xb, const void* wb, const float* bias, float* y, void* yb, int n, int relu,
+                              vl_stream_t stream) {
+    VL_CHECK(d && xb && wb && (y || yb) && n > 0, "vl_conv_c8_fwd: bad argument");
+    VL_CHECK(d->cig % 8 == 0 && d->cog % 8 == 0, "vl_conv_c8_fwd: channels per group must be a multiple of 8");
+    if (int rc = c8_tables(d)) return rc;
+    const int Hp = d->h + 2 * d->x_halo, Wp = d->w + 2 * d->x_halo, CB = d->cin / 8;
+    VL_CHECK((int64_t)n * d->oh * d->ow < (1ll << 31), "vl_conv_c8_fwd: too many output pixels");
+    C8ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = (const char*)xb;
+    a.x_img = (int64_t)CB * Hp * Wp * 16;
+    a.x_total = a.x_img * n;
+    a.x_grp = (int64_t)(d->cig / 8) * Hp * Wp * 16;
+    a.x_row = Wp * 16;
+    a.stride = d->stride;
+    a.OW = d->ow;
+    a.OHW = d->oh * d->ow;
+    a.M = n * a.OHW;
+    a.dOHW = make_fastdiv(a.OHW);
+    a.dOW = make_fastdiv(a.OW);
+    a.toff = d->c8_toff_fwd;
+    a.nstages = c8_taps_padded(d->cig, d->kh, d->kw) / KT;
+    a.w = (const char*)wb;
+    a.CoP = c8_cop(d->cog);
+    a.Cog = d->cog;
+    a.Ctot = d->cout;
+    a.bias = bias;
+    a.relu = relu;
+    a.y = y;
+    a.y_halo = d->y_halo;
+    a.y_w = d->ow + 2 * d->y_halo;
+    a.y_plane = (int64_t)(d->oh + 2 * d->y_halo) * a.y_w;
+    a.yb = (char*)yb;
+    a.yb_halo = d->y_halo;
+    a.yb_row = a.y_w * 16;
+    a.yb_plane = a.y_plane * 16;
+    a.yb_cb = d->cout / 8;
+    return dispatch_c8(a, d->groups, (hipStream_t)stream);
+}
+
+/* dx = d(loss)/dx from the c8 operand dyb (dy_halo) and vl_conv_c8_pack_w(bwd = 1)'s weights (stride-1 layers): dx (fp32 NCHW,
+ * dx_halo) and / or dxb (bf16 c8, dx_halo); relu_mask (fp32, dx's layout) fuses the ReluGrad of the producing layer. */
+extern "C" int vl_conv_c8_dgrad(vl_conv_desc* d, const void* dyb, const void* wbt, float* dx, void* dxb, const float* relu_mask, int n,
+                                vl_stream_t stream) {
+    VL_CHECK(d && dyb && wbt && (dx || dxb) && n > 0, "vl_conv_c8_dgrad: bad argument");
+    VL_CHECK(d->stride == 1 && d->bwd_padded, "vl_conv_c8_dgrad: stride-1 layers in the padded layout only");
+    VL_CHECK(d->cig % 8 == 0 && d->cog % 8 == 0, "vl_conv_c8_dgrad: channels per group must be a multiple of 8");
+    if (int rc = c8_tables(d)) return rc;
+    const int Hp = d->oh + 2 * d->dy_halo, Wp = d->ow + 2 * d->dy_halo, CB = d->cout / 8;
+    C8ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = (const char*)dyb;
+    a.x_img = (int64_t)CB * Hp * Wp * 16;
+    a.x_total = a.x_img * n;
+    a.x_grp = (int64_t)(d->cog / 8) * Hp * Wp * 16;
+    a.x_row = Wp * 16;
+    a.stride = 1;
+    a.OW = d->w;
+    a.OHW = d->h * d->w;
+    a.M = n * a.OHW;
+    a.dOHW = make_fastdiv(a.OHW);
+    a.dOW = make_fastdiv(a.OW);
+    a.toff = d->c8_toff_bwd;
+    a.nstages = c8_taps_padded(d->cog, d->kh, d->kw) / KT;
+    a.w = (const char*)wbt;
+    a.CoP = c8_cop(d->cig);
+    a.Cog = d->cig;
+    a.Ctot = d->cin;
+    a.mask = relu_mask;
+    a.y = dx;
+    a.y_halo = d->dx_halo;
+    a.y_w = d->w + 2 * d->dx_halo;
+    a.y_plane = (int64_t)(d->h + 2 * d->dx_halo) * a.y_w;
+    a.yb = (char*)dxb;
+    a.yb_halo = d->dx_halo;
+    a.yb_row = a.y_w * 16;
+    a.yb_plane = a.y_plane * 16;
+    a.yb_cb = d->cin / 8;
+    return dispatch_c8(a, d->groups, (hipStream_t)stream);
+}
+
+// ---- wgrad ---------------------------------------------------------------------------------------------------------------------
+// dW[tap = (cb, ky, kx)][ci][co] = sum over pixels x[pixel + tap][ci] * dy[pixel][co] for a stride-1 layer whose x and dy share one
+// padded plane geometry (x_halo == dy_halo: every SAME layer with an odd kernel).  Then a pixel of dy and its tap of x differ by a
+// CONSTANT number of chunks, so the reduction sweeps each image's plane linearly from the first to the last valid pixel (L = (OH - 1)
+// Wp + OW positions; the halo columns in between hold zeros in dy and cost 2 hh / Wp of the MFMAs) and no fetch needs a per-pixel
+// address: lane = (position in a group of 4, chunk), per-lane offset constant, the stage's position a scalar.  The only per-lane
+// work is a compare + select where a stage's 32 positions straddle two images or the end of the slab.
+// Both operands reduce over their STRIDED index, so the LDS image is [4-position group][position q][chunk ^ 4q] (16-byte chunks, 1 KB
+// per fetch = per group) and an MFMA operand is two ds_read_b64_tr_b16: each returns 4 positions x 1 column per lane out of a 4 x 16
+// block, i.e. the transpose.  The xor keeps the four rows of a block on different banks (conflict free per 32-lane half).
+// MFMA A = x taps (rows = (tap, ci)), B = dy (columns = co = lanes): the accumulators store coalesced along co into per-slab images
+// [slab][group][tap][ci][co], summed in slab order (deterministic) into HWIO by wgrad_c8_reduce_kernel.
+struct C8WgradArgs {
+    const char* x;        // c8 forward input
+    const char* dy;       // c8 output gradient
+    int64_t x_img, dy_img, x_grp, dy_grp, x_total, dy_total;   // bytes
+    int64_t dy_plane;     // bytes per channel-block plane of dy
+    const int* toff;      // forward tap offsets (c8_toff_fwd)
+    int ntaps;            // real taps per group
+    int Cog;              // output channels per group
+    int L;                // positions swept per image
+    int qstart;           // first valid position of a plane (hh * Wp + hh)
+    int nimg;
+    int64_t Rtot;         // nimg * L
+    int slab_len;         // positions per slab (multiple of 32)
+    float* ws;            // [slab][group][rowsP][CoP]
+    int rowsP, CoP;       // rows (taps * 8) / columns of a slab image, padded to the tiling
+    FastDiv dL;
+};
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i32x2 lds_read_tr(uint32_t addr) {   // ds_read_b64_tr_b16 at LDS byte address addr
+    return __builtin_bit_cast(i32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(uintptr_t)addr));
+}
+
+template <int WA, int WB>
+struct C8WgCfg {
+    static constexpr int NW = WA * WB, NT = 64 * NW, ROWS = 64 * WA, COLS = 64 * WB, TAPS = ROWS / 8, NBUF = 4, KP = 32;
+    static constexpr int SUBA = (TAPS + 15) / 16, SUBB = (COLS / 8 + 15) / 16;      // 16-chunk sub-images per operand
+    static constexpr int A_BYTES = SUBA * KP * 256, B_BYTES = SUBB * KP * 256, SLOT = A_BYTES + B_BYTES;
+    static constexpr int NAI = SUBA * KP / 4, NBI = SUBB * KP / 4;                  // 1 KB fetches per stage
+    static constexpr int FA = (NAI + NW - 1) / NW, FB = (NBI + NW - 1) / NW, F = FA + FB;
+    static constexpr size_t LDS_BYTES = (size_t)NBUF * SLOT;
+};
+
+template <int WA, int WB>
+__global__ __launch_bounds__(64 * WA * WB) void wgrad_c8_kernel(const C8WgradArgs a, int tiles_a, int tiles_b) {
+    using C = C8WgCfg<WA, WB>;
+    constexpr int NW = C::NW, NBUF = C::NBUF, SLOT = C::SLOT, KP = C::KP, FA = C::FA, FB = C::FB, F = C::F;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int bid = blockIdx.x;
+    const int ta = bid % tiles_a, tb = bid / tiles_a, g = blockIdx.y, zs = blockIdx.z;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wa = wave % WA, wb = wave / WA;
+    const int tap0 = ta * C::TAPS, co0 = tb * C::COLS;
+
+    const int64_t gp_begin = (int64_t)zs * a.slab_len;
+    int64_t gp_end = gp_begin + a.slab_len;
+    if (gp_end > a.Rtot) gp_end = a.Rtot;
+    const int nstages = gp_end > gp_begin ? (int)((gp_end - gp_begin + KP - 1) / KP) : 0;
+    const int n_first = (int)fd_div((uint32_t)gp_begin, a.dL);
+
+    // ---- fetch plan: lane = (position q = lane >> 4 of a 4-position group, chunk slot lane & 15 holding chunk (lane & 15) ^ 4q) ----
+    const int q4 = lane >> 4, ch = (lane & 15) ^ (q4 << 2);
+    const int64_t xo = (int64_t)n_first * a.x_img + (int64_t)g * a.x_grp, dyo = (int64_t)n_first * a.dy_img + (int64_t)g * a.dy_grp;
+    int64_t xb = a.x_total - xo, db = a.dy_total - dyo;
+    if (xb > MAX_BUF_BYTES) xb = MAX_BUF_BYTES;
+    if (db > MAX_BUF_BYTES) db = MAX_BUF_BYTES;
+    const i32x4 rs_x = rsrc_words(a.x + xo, xb), rs_dy = rsrc_words(a.dy + dyo, db);
+    uint32_t voff_a[FA], voff_b[FB], lds_a[FA], lds_b[FB];
+    int grp_a[FA], grp_b[FB];          // 4-position group (0 .. KP / 4 - 1) the fetch carries
+#pragma unroll
+    for (int j = 0; j < FA; ++j) {
+        const int id = (wave + j * NW) % C::NAI, sub = id / (KP / 4), pg = id % (KP / 4);
+        int t = tap0 + sub * 16 + ch;
+        t = t < a.ntaps ? t : 0;                                   // rows past the last tap: any valid address, discarded by the epilogue
+        voff_a[j] = (uint32_t)a.toff[t] + (uint32_t)(q4 * 16);
+        grp_a[j] = pg;
+        lds_a[j] = sub * KP * 256 + pg * 1024;
+    }
+#pragma unroll
+    for (int j = 0; j < FB; ++j) {
+        const int id = (wave + j * NW) % C::NBI, sub = id / (KP / 4), pg = id % (KP / 4);
+        int cb = co0 / 8 + sub * 16 + ch;
+        cb = cb < a.Cog / 8 ? cb : 0;
+        voff_b[j] = (uint32_t)((int64_t)cb * a.dy_plane) + (uint32_t)(q4 * 16);
+        grp_b[j] = pg;
+        lds_b[j] = C::A_BYTES + sub * KP * 256 + pg * 1024;
+    }
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+    const uint32_t dx_delta = (uint32_t)(a.x_img - (int64_t)a.L * 16), dy_delta = (uint32_t)(a.dy_img - (int64_t)a.L * 16);
+    constexpr uint32_t OOB = 0xF0000000u;
+    auto issue = [&](int st) {
+        const uint32_t slot = lds0 + (uint32_t)(st % NBUF) * SLOT;
+        const int64_t gp0 = gp_begin + (int64_t)st * KP;                       // first position of the stage
+        const int n_s = (int)fd_div((uint32_t)gp0, a.dL);                      // its image; at most one image boundary inside (L >= KP)
+        const int r0 = (int)(gp0 - (int64_t)n_s * a.L);                        // position within the image's sweep
+        const int to_next = a.L - r0;                                          // positions of the stage before the next image starts
+        const int to_end = (int)((gp_end - gp0) < KP ? (gp_end - gp0) : KP);   // positions before the slab ends
+        const uint32_t sx = (uint32_t)((int64_t)(n_s - n_first) * a.x_img) + (uint32_t)r0 * 16;
+        const uint32_t sdy = (uint32_t)((int64_t)(n_s - n_first) * a.dy_img) + (uint32_t)(a.qstart + r0) * 16;
+#pragma unroll
+        for (int j = 0; j < FA; ++j) {
+            const int p = grp_a[j] * 4 + q4;                                   // this lane's position within the stage
+            uint32_t v = voff_a[j] + (p >= to_next ? dx_delta : 0u);
+            v = p >= to_end ? OOB : v;
+            lds_dma16(rs_x, slot + lds_a[j], v, (int)(sx + (uint32_t)grp_a[j] * 64));
+        }
+#pragma unroll
+        for (int j = 0; j < FB; ++j) {
+            const int p = grp_b[j] * 4 + q4;
+            uint32_t v = voff_b[j] + (p >= to_next ? dy_delta : 0u);
+            v = p >= to_end ? OOB : v;
+            lds_dma16(rs_dy, slot + lds_b[j], v, (int)(sdy + (uint32_t)grp_b[j] * 64));
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+    for (int st = 0; st < NBUF - 1 && st < nstages; ++st) issue(st);
+    // transposed operand reads: 16-lane group g16 -> (columns 16 (g16 & 1) .. + 15 of the 32-wide block, positions 8 (g16 >> 1) .. + 7);
+    // lane 4 q + p of the group addresses row q, columns 4 p .. 4 p + 3 = chunk 2 (g16 & 1) + (p >> 1), byte 8 (p & 1)
+    const int g16 = lane >> 4, rq = (lane & 15) >> 2, rp = lane & 3;
+    const int cl = 2 * (g16 & 1) + (rp >> 1);                        // chunk within the block's 4 chunks
+    uint32_t rd_a[2], rd_b[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int ca = (wa * 2 + i) * 4 + cl, cbk = (wb * 2 + i) * 4 + cl;      // chunk within the tile: sub-image chunk >> 4, slot chunk & 15
+        rd_a[i] = lds0 + (uint32_t)((ca >> 4) * KP * 256 + (g16 >> 1) * 2048 + rq * 256 + (((ca & 15) ^ (rq << 2)) * 16) + 8 * (rp & 1));
+        rd_b[i] = lds0 + (uint32_t)(C::A_BYTES + (cbk >> 4) * KP * 256 + (g16 >> 1) * 2048 + rq * 256 + (((cbk & 15) ^ (rq << 2)) * 16) +
+                                    8 * (rp & 1));
+    }
+    for (int st = 0; st < nstages; ++st) {
+        const int later = (nstages - 1 - st) < (NBUF - 2) ? (nstages - 1 - st) : (NBUF - 2);
+        if (later >= 2)
+            wait_vm<2 * F>();
+        else if (later == 1)
+            wait_vm<F>();
+        else
+            wait_vm<0>();
+        __syncthreads();
+        if (st + NBUF - 1 < nstages) issue(st + NBUF - 1);
+        const uint32_t so = (uint32_t)(st % NBUF) * SLOT;
+#pragma unroll
+        for (int kk = 0; kk < KP / 16; ++kk) {
+            i32x4 av[2], bv[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const i32x2 a0 = lds_read_tr(rd_a[i] + so + kk * 4096), a1 = lds_read_tr(rd_a[i] + so + kk * 4096 + 1024);
+                const i32x2 b0 = lds_read_tr(rd_b[i] + so + kk * 4096), b1 = lds_read_tr(rd_b[i] + so + kk * 4096 + 1024);
+                av[i] = i32x4{a0[0], a0[1], a1[0], a1[1]};
+                bv[i] = i32x4{b0[0], b0[1], b1[0], b1[1]};
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma_bf16(av[i], bv[j], acc[i][j]);
+        }
+    }
+
+    // ---- epilogue: slab image [zs][g][row = tap * 8 + ci][co] ----
+    float* out = a.ws + ((int64_t)zs * gridDim.y + g) * a.rowsP * a.CoP;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = co0 + (wb * 2 + j) * 32 + (lane & 31);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int row = tap0 * 8 + (wa * 2 + i) * 32 + 8 * (q >> 2) + 4 * (lane >> 5) + (q & 3);
+                if (row < a.rowsP && col < a.CoP) out[(int64_t)row * a.CoP + col] = acc[i][j][q];
+            }
+        }
+}
+
+// dw[ky][kx][c][g * cog + co] = sum over slabs of ws[slab][g][((c / 8 * kh + ky) * kw + kx) * 8 + c % 8][co], in slab order
+__global__ void wgrad_c8_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int kh, int kw, int cig, int cog, int groups,
+                                       int rowsP, int CoP, int slabs, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int cout = cog * groups;
+    const int cf = (int)(idx % cout);
+    const int64_t r = idx / cout;
+    const int c = (int)(r % cig), kx = (int)((r / cig) % kw), ky = (int)(r / ((int64_t)cig * kw));
+    const int g = cf / cog, co = cf % cog;
+    const int row = (((c >> 3) * kh + ky) * kw + kx) * 8 + (c & 7);
+    const float* p = ws + ((int64_t)g * rowsP + row) * CoP + co;
+    const int64_t slab_stride = (int64_t)groups * rowsP * CoP;
+    float s = 0.f;
+    for (int z = 0; z < slabs; ++z) s += p[z * slab_stride];
+    dw[idx] = s;
+}
+
+struct C8WgPlan {
+    int wa, wb, tiles_a, tiles_b, slabs, slab_len, rowsP, CoP;
+    int64_t Rtot;
+    int L;
+};
+
+static int c8_wgrad_plan(const vl_conv_desc* d, int n, C8WgPlan* p) {
+    const int ntaps = c8_taps(d->cig, d->kh, d->kw);
+    p->wb = d->cog % 128 == 0 ? 2 : d->cog % 192 == 0 ? 3 : 2;
+    p->wa = p->wb == 3 ? 2 : 4;
+    const int taps_tile = p->wa * 8, cols_tile = p->wb * 64;
+    p->tiles_a = (ntaps + taps_tile - 1) / taps_tile;
+    p->tiles_b = (d->cog + cols_tile - 1) / cols_tile;
+    p->rowsP = p->tiles_a * taps_tile * 8;
+    p->CoP = p->tiles_b * cols_tile;
+    const int Wp = d->w + 2 * d->x_halo;
+    p->L = (d->oh - 1) * Wp + d->ow;
+    p->Rtot = (int64_t)n * p->L;
+    const int tiles = p->tiles_a * p->tiles_b * d->groups;
+    int slabs = (2 * 256 + tiles - 1) / tiles;                       // about two workgroups per CU in flight over the launch
+    const int64_t stages = (p->Rtot + 31) / 32;
+    if (slabs > stages / 8) slabs = (int)(stages / 8);               // at least 8 stages per slab
+    if (slabs < 1) slabs = 1;
+    int64_t per = (stages + slabs - 1) / slabs;
+    p->slab_len = (int)(per * 32);
+    p->slabs = (int)((p->Rtot + p->slab_len - 1) / p->slab_len);
+    return 0;
+}
+
+extern "C" size_t vl_conv_c8_wgrad_ws_bytes(const vl_conv_desc* d, int n) {
+    if (!d || n <= 0) return 0;
+    C8WgPlan p;
+    c8_wgrad_plan(d, n, &p);
+    return (size_t)p.slabs * d->groups * p.rowsP * p.CoP * sizeof(float);
+}
+
+template <int WA, int WB>
+static int launch_c8_wgrad(const C8WgradArgs& a, const C8WgPlan& p, int groups, hipStream_t stream) {
+    using C = C8WgCfg<WA, WB>;
+    auto kern = wgrad_c8_kernel<WA, WB>;
+    static bool attr = false;
+    if (!attr) {
+        VL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
+        attr = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.tiles_a * p.tiles_b, groups, p.slabs), dim3(C::NT), C::LDS_BYTES, stream, a, p.tiles_a, p.tiles_b);
+    VL_LAUNCH_CHECK();
+    return 0;
+}
+
+/* dw (HWIO fp32) = d(loss)/dw from the c8 operands xb (x_halo) and dyb (dy_halo == x_halo), stride-1 layers; deterministic slab
+ * reduction through ws (>= vl_conv_c8_wgrad_ws_bytes). */
+extern "C" int vl_conv_c8_wgrad(vl_conv_desc* d, const void* xb, const void* dyb, float* dw, void* ws, size_t ws_bytes, int n,
+                                vl_stream_t stream) {
+    VL_CHECK(d && xb && dyb && dw && ws && n > 0, "vl_conv_c8_wgrad: bad argument");
+    VL_CHECK(d->stride == 1 && d->x_halo == d->dy_halo && d->oh == d->h && d->ow == d->w, "vl_conv_c8_wgrad: stride-1 SAME layers with x_halo == dy_halo");
+    VL_CHECK(d->cig % 8 == 0 && d->cog % 8 == 0, "vl_conv_c8_wgrad: channels per group must be a multiple of 8");
+    if (int rc = c8_tables(d)) return rc;
+    C8WgPlan p;
+    c8_wgrad_plan(d, n, &p);
+    VL_CHECK(p.L >= 32, "vl_conv_c8_wgrad: plane too small");
+    VL_CHECK(ws_bytes >= (size_t)p.slabs * d->groups * p.rowsP * p.CoP * sizeof(float), "vl_conv_c8_wgrad: workspace too small");
+    VL_CHECK(p.Rtot < (1ll << 31), "vl_conv_c8_wgrad: too many positions");
+    const int Hp = d->h + 2 * d->x_halo, Wp = d->w + 2 * d->x_halo;
+    C8WgradArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = (const char*)xb;
+    a.dy = (const char*)dyb;
+    a.dy_plane = (int64_t)Hp * Wp * 16;
+    a.x_img = (int64_t)(d->cin / 8) * a.dy_plane;
+    a.dy_img = (int64_t)(d->cout / 8) * a.dy_plane;
+    a.x_grp = (int64_t)(d->cig / 8) * a.dy_plane;
+    a.dy_grp = (int64_t)(d->cog / 8) * a.dy_plane;
+    a.x_total = a.x_img * n;
+    a.dy_total = a.dy_img * n;
+    a.toff = d->c8_toff_fwd;
+    a.ntaps = c8_taps(d->cig, d->kh, d->kw);
+    a.Cog = d->cog;
+    a.L = p.L;
+    a.qstart = d->x_halo * Wp + d->x_halo;
+    a.nimg = n;
+    a.Rtot = p.Rtot;
+    a.slab_len = p.slab_len;
+    a.ws = (float*)ws;
+    a.rowsP = p.rowsP;
+    a.CoP = p.CoP;
+    a.dL = make_fastdiv(p.L);
+    int rc = p.wb == 3 ? launch_c8_wgrad<2, 3>(a, p, d->groups, (hipStream_t)stream) : launch_c8_wgrad<4, 2>(a, p, d->groups, (hipStream_t)stream);
+    if (rc) return rc;
+    const int64_t total = (int64_t)d->kh * d->kw * d->cig * d->cout;
+    hipLaunchKernelGGL(wgrad_c8_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)ws, dw,
+                       d->kh, d->kw, d->cig, d->cog, d->groups, p.rowsP, p.CoP, p.slabs, total);
+    VL_LAUNCH_CHECK();
+    return 0;
+}

@@ -34,6 +34,7 @@
 #include <string.h>
 
 #include "common.h"
+#include "conv_desc.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 // Read-only tables are read through the constant address space: a uniform read from it is always a scalar load (s_load).
@@ -1877,28 +1878,7 @@ extern "C" int vl_set_conv_math(int math) {
 extern "C" int vl_conv_math(void) { return g_conv_math; }
 
 // ---- convolution descriptor -------------------------------------------------------------------
-struct vl_conv_desc {
-    int cin, h, w, cout, kh, kw, stride, groups;
-    int oh, ow, pt, pl, pb, pr;   // SAME padding before / after
-    int cig, cog;
-    int K;    // kh*kw*cig
-    int Kd;   // kh*kw*cog (dgrad reduction length)
-    int x_halo, y_halo, dy_halo, dx_halo;
-    int x_phase;      // 1, or = stride: x is stored column-phase-split (vl_conv_set_x_phase_split)
-    int2* ktab2_fwd;  // natural order, checked mode: {byte offset, kh << 16 | kw} (device), halo-aware
-    int* ktab_fwd;    // natural order, padded mode: byte offset
-    // forward / dgrad run their reduction in the permuted order (build_ktabs): gather tables in that order + first weight
-    // row of every 16-row reduction tile.  wgrad keeps the natural-order tables above (its rows ARE the output rows).
-    int2* ptab2_fwd;
-    int2* ptab2_bwd;
-    int* ptab_fwd;
-    int* ptab_bwd;
-    int* rowtab_fwd;
-    int* rowtab_bwd;
-    int fwd_padded, bwd_padded;
-    uint32_t* wsplit_fwd;   // conv_wsplit_kernel's image of the forward / dgrad weights (split-product arithmetic only)
-    uint32_t* wsplit_bwd;
-};
+// struct vl_conv_desc: conv_desc.h (shared with conv_c8.hip)
 
 static void tf_same_pad(int in, int k, int s, int* out, int* before, int* after) {
     *out = (in + s - 1) / s;
@@ -2042,6 +2022,7 @@ extern "C" int vl_conv_set_halo(vl_conv_desc* d, int x_halo, int y_halo, int dy_
     VL_CHECK(x_halo >= 0 && y_halo >= 0 && dy_halo >= 0 && dx_halo >= 0 && x_halo < 64 && y_halo < 64 && dy_halo < 64 && dx_halo < 64,
              "vl_conv_set_halo: bad halo");
     d->x_halo = x_halo; d->y_halo = y_halo; d->dy_halo = dy_halo; d->dx_halo = dx_halo;
+    conv_c8_free_tables(d);            // conv_c8.hip rebuilds its tap tables for the new halos on first use
     VL_CHECK(rebuild_tables(d) == 0, "vl_conv_set_halo: device table allocation failed");
     return 0;
 }
@@ -2068,6 +2049,7 @@ extern "C" void vl_conv_destroy(vl_conv_desc* d) {
     free_dev(d->rowtab_bwd);
     free_dev(d->wsplit_fwd);
     free_dev(d->wsplit_bwd);
+    conv_c8_free_tables(d);
     free(d);
 }
 

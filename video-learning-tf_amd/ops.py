@@ -157,6 +157,68 @@ class Conv:
         _ffi.call("vl_conv_wgrad", self._d, _p(x), _p(dy), _p(dw), _p(db), _p(ws), nbytes, x.shape[0], stream())
 
 
+    # ---- the bf16 path: operands in the c8 layout [n][ceil(c/8)][h + 2 halo][w + 2 halo][8] bf16 (include/vltf.h) -------------
+    def c8_w_bytes(self, bwd=False):
+        return int(_ffi.lib().vl_conv_c8_w_bytes(self._d, int(bwd)))
+
+    def c8_pack_w(self, w, wb, bwd=False):
+        """HWIO fp32 weights -> packed bf16 operand of c8_fwd (bwd=False) / c8_dgrad (bwd=True); wb: uint8 tensor of c8_w_bytes."""
+        _f32(w); _dense(w, wb)
+        if wb.numel() * wb.element_size() < self.c8_w_bytes(bwd):
+            raise _ffi.VltfError("conv.c8_pack_w: weight buffer too small")
+        _ffi.call("vl_conv_c8_pack_w", self._d, _p(w), _p(wb), int(bwd), stream())
+
+    def _c8_check(self, t, n, c, h, w, halo, what):
+        if t is not None and (t.dtype != torch.bfloat16 or tuple(t.shape) != c8_shape(n, c, h, w, halo) or not t.is_contiguous()):
+            raise _ffi.VltfError("conv: %s must be a contiguous bf16 c8 tensor %s, got %s %s" % (what, c8_shape(n, c, h, w, halo),
+                                                                                                 t.dtype, tuple(t.shape)))
+
+    def c8_fwd(self, xb, wb, bias, y=None, yb=None, relu=True):
+        n = xb.shape[0]
+        _f32(bias, y); _dense(bias, y, wb)
+        self._c8_check(xb, n, self.cin, self.h, self.w, self.x_halo, "xb")
+        self._c8_check(yb, n, self.cout, self.oh, self.ow, self.y_halo, "yb")
+        if y is not None and tuple(y.shape) != self._shape(n, self.cout, self.oh, self.ow, self.y_halo):
+            raise _ffi.VltfError("conv.c8_fwd: y shape %s" % (tuple(y.shape),))
+        _ffi.call("vl_conv_c8_fwd", self._d, _p(xb), _p(wb), _p(bias), _p(y), _p(yb), n, int(relu), stream())
+
+    def c8_dgrad(self, dyb, wbt, dx=None, dxb=None, relu_mask=None):
+        n = dyb.shape[0]
+        _f32(dx, relu_mask); _dense(dx, relu_mask, wbt)
+        self._c8_check(dyb, n, self.cout, self.oh, self.ow, self.dy_halo, "dyb")
+        self._c8_check(dxb, n, self.cin, self.h, self.w, self.dx_halo, "dxb")
+        for t in (dx, relu_mask):
+            if t is not None and tuple(t.shape) != self._shape(n, self.cin, self.h, self.w, self.dx_halo):
+                raise _ffi.VltfError("conv.c8_dgrad: dx / relu_mask shape %s" % (tuple(t.shape),))
+        _ffi.call("vl_conv_c8_dgrad", self._d, _p(dyb), _p(wbt), _p(dx), _p(dxb), _p(relu_mask), n, stream())
+
+    def c8_wgrad_ws_bytes(self, n):
+        return int(_ffi.lib().vl_conv_c8_wgrad_ws_bytes(self._d, n))
+
+    def c8_wgrad(self, xb, dyb, dw, ws):
+        n = xb.shape[0]
+        _f32(dw); _dense(dw, ws)
+        self._c8_check(xb, n, self.cin, self.h, self.w, self.x_halo, "xb")
+        self._c8_check(dyb, n, self.cout, self.oh, self.ow, self.dy_halo, "dyb")
+        if tuple(dw.shape) != self.w_shape:
+            raise _ffi.VltfError("conv.c8_wgrad: dw shape %s" % (tuple(dw.shape),))
+        _ffi.call("vl_conv_c8_wgrad", self._d, _p(xb), _p(dyb), _p(dw), _p(ws), ws.numel() * ws.element_size(), n, stream())
+
+
+def c8_shape(n, c, h, w, halo):
+    return (n, (c + 7) // 8, h + 2 * halo, w + 2 * halo, 8)
+
+
+def pack_c8(x, xb, x_halo, xb_halo):
+    """fp32 NCHW (x_halo) -> bf16 c8 (xb_halo); xb zero-initialised once by the caller (only interiors are written)."""
+    _f32(x); _dense(x, xb)
+    n, c = x.shape[0], x.shape[1]
+    h, w = x.shape[2] - 2 * x_halo, x.shape[3] - 2 * x_halo
+    if xb.dtype != torch.bfloat16 or tuple(xb.shape) != c8_shape(n, c, h, w, xb_halo):
+        raise _ffi.VltfError("pack_c8: xb must be bf16 %s, got %s %s" % (c8_shape(n, c, h, w, xb_halo), xb.dtype, tuple(xb.shape)))
+    _ffi.call("vl_pack_c8", _p(x), _p(xb), n, c, h, w, x_halo, xb_halo, stream())
+
+
 def bias_grad_nchw(dy, db, ws):
     _f32(dy, db, ws); _dense(dy, db, ws)
     n, c = dy.shape[0], dy.shape[1]
