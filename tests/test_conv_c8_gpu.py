@@ -77,9 +77,10 @@ def test_pack_c8(ops):
 
 
 # n, h, w, cin, cout, k, groups: AlexNet's stride-1 layers (conv2 .. conv5; conv4's 192-channel groups take the 192-wide tile), a
-# narrow layer (24 output channels per group: the 64-wide tile; 18 taps -> a padded last stage) and a batch that ends inside a pixel tile
+# narrow layer (24 output channels per group: the 64-wide tile; 18 taps -> a padded last stage) a batch that ends inside a pixel tile, and
+# 3x3 planes (wgrad's sweep of an image is shorter than a 32-position stage)
 C8_CASES = [(3, 13, 13, 256, 384, 3, 1), (2, 27, 27, 96, 256, 5, 2), (2, 13, 13, 384, 384, 3, 2), (2, 13, 13, 384, 256, 3, 2),
-            (5, 9, 11, 32, 48, 3, 2), (21, 13, 13, 64, 128, 3, 1)]
+            (5, 9, 11, 32, 48, 3, 2), (21, 13, 13, 64, 128, 3, 1), (40, 3, 3, 16, 32, 3, 1)]
 
 
 @pytest.mark.parametrize("n,h,w,cin,cout,k,g", C8_CASES)

@@ -556,21 +556,40 @@ __global__ __launch_bounds__(64 * WA * WB) void wgrad_c8_kernel(const C8WgradArg
         const int r0 = (int)(gp0 - (int64_t)n_s * a.L);                        // position within the image's sweep
         const int to_next = a.L - r0;                                          // positions of the stage before the next image starts
         const int to_end = (int)((gp_end - gp0) < KP ? (gp_end - gp0) : KP);   // positions before the slab ends
-        const uint32_t sx = (uint32_t)((int64_t)(n_s - n_first) * a.x_img) + (uint32_t)r0 * 16;
-        const uint32_t sdy = (uint32_t)((int64_t)(n_s - n_first) * a.dy_img) + (uint32_t)(a.qstart + r0) * 16;
+        if (a.L >= KP) {                                                       // at most one image boundary inside the stage
+            const uint32_t sx = (uint32_t)((int64_t)(n_s - n_first) * a.x_img) + (uint32_t)r0 * 16;
+            const uint32_t sdy = (uint32_t)((int64_t)(n_s - n_first) * a.dy_img) + (uint32_t)(a.qstart + r0) * 16;
 #pragma unroll
-        for (int j = 0; j < FA; ++j) {
-            const int p = grp_a[j] * 4 + q4;                                   // this lane's position within the stage
-            uint32_t v = voff_a[j] + (p >= to_next ? dx_delta : 0u);
-            v = p >= to_end ? OOB : v;
-            lds_dma16(rs_x, slot + lds_a[j], v, (int)(sx + (uint32_t)grp_a[j] * 64));
-        }
+            for (int j = 0; j < FA; ++j) {
+                const int p = grp_a[j] * 4 + q4;                               // this lane's position within the stage
+                uint32_t v = voff_a[j] + (p >= to_next ? dx_delta : 0u);
+                v = p >= to_end ? OOB : v;
+                lds_dma16(rs_x, slot + lds_a[j], v, (int)(sx + (uint32_t)grp_a[j] * 64));
+            }
 #pragma unroll
-        for (int j = 0; j < FB; ++j) {
-            const int p = grp_b[j] * 4 + q4;
-            uint32_t v = voff_b[j] + (p >= to_next ? dy_delta : 0u);
-            v = p >= to_end ? OOB : v;
-            lds_dma16(rs_dy, slot + lds_b[j], v, (int)(sdy + (uint32_t)grp_b[j] * 64));
+            for (int j = 0; j < FB; ++j) {
+                const int p = grp_b[j] * 4 + q4;
+                uint32_t v = voff_b[j] + (p >= to_next ? dy_delta : 0u);
+                v = p >= to_end ? OOB : v;
+                lds_dma16(rs_dy, slot + lds_b[j], v, (int)(sdy + (uint32_t)grp_b[j] * 64));
+            }
+        } else {                                                               // tiny planes: every lane decodes its own image
+#pragma unroll
+            for (int j = 0; j < FA; ++j) {
+                const int p = grp_a[j] * 4 + q4;
+                const uint32_t gp = (uint32_t)gp0 + (uint32_t)p, n = fd_div(gp, a.dL), r = gp - n * (uint32_t)a.L;
+                uint32_t v = voff_a[j] - (uint32_t)(q4 * 16) + (uint32_t)((int64_t)((int)n - n_first) * a.x_img) + r * 16;   // (voff holds q4's 16 bytes)
+                v = p >= to_end ? OOB : v;
+                lds_dma16(rs_x, slot + lds_a[j], v, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < FB; ++j) {
+                const int p = grp_b[j] * 4 + q4;
+                const uint32_t gp = (uint32_t)gp0 + (uint32_t)p, n = fd_div(gp, a.dL), r = gp - n * (uint32_t)a.L;
+                uint32_t v = voff_b[j] - (uint32_t)(q4 * 16) + (uint32_t)((int64_t)((int)n - n_first) * a.dy_img) + (r + (uint32_t)a.qstart) * 16;
+                v = p >= to_end ? OOB : v;
+                lds_dma16(rs_dy, slot + lds_b[j], v, 0);
+            }
         }
     };
 
@@ -716,7 +735,6 @@ extern "C" int vl_conv_c8_wgrad(vl_conv_desc* d, const void* xb, const void* dyb
     if (int rc = c8_tables(d)) return rc;
     C8WgPlan p;
     c8_wgrad_plan(d, n, &p);
-    VL_CHECK(p.L >= 32, "vl_conv_c8_wgrad: plane too small");
     VL_CHECK(ws_bytes >= (size_t)p.slabs * d->groups * p.rowsP * p.CoP * sizeof(float), "vl_conv_c8_wgrad: workspace too small");
     VL_CHECK(p.Rtot < (1ll << 31), "vl_conv_c8_wgrad: too many positions");
     const int Hp = d->h + 2 * d->x_halo, Wp = d->w + 2 * d->x_halo;

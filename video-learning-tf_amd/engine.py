@@ -236,6 +236,21 @@ class LRCNEngine:
             L["conv"].set_halo(L["x_halo"], L["y_halo"], L["dy_halo"], dx_halo)
             if training:
                 ws_bytes = max(ws_bytes, L["conv"].wgrad_ws_bytes(N))
+        # conv_math "bf16" is a bf16 PATH for the stride-1 layers (csrc/conv_c8.hip): their operands live in memory as packed bf16
+        # ("c8": 8 channels of a pixel per 16-byte chunk) next to the fp32 tensors the pool / LRN / bias-gradient kernels read.
+        # xb: the layer's input; dyb: the gradient its dgrad / wgrad read; wb / wbt: the packed weights (rebuilt every step).
+        self.c8 = cfg.conv_math == "bf16"
+        if self.c8:
+            def cbuf(c_, h_, w_, halo):
+                return torch.zeros(ops.c8_shape(N, c_, h_, w_, halo), dtype=torch.bfloat16, device=dev)
+            for L in self.layers[1:]:
+                conv = L["conv"]
+                L["xb"] = cbuf(conv.cin, conv.h, conv.w, L["x_halo"])
+                L["wb"] = torch.zeros(conv.c8_w_bytes(False), dtype=torch.uint8, device=dev)
+                if training:
+                    L["dyb"] = cbuf(conv.cout, conv.oh, conv.ow, L["dy_halo"])
+                    L["wbt"] = torch.zeros(conv.c8_w_bytes(True), dtype=torch.uint8, device=dev)
+                    ws_bytes = max(ws_bytes, conv.c8_wgrad_ws_bytes(N))
         self.flat_dim = h * w * c
         self.f6 = buf(N, FC_DIM)
         self.f7 = buf(N, FC_DIM) if cfg.frame_encoding_layer != "fc6" else None
@@ -422,9 +437,16 @@ class LRCNEngine:
         P, cfg = self.P, self.cfg
         ops.set_conv_math(cfg.conv_math)             # process-wide switch: set per call so that engines of both kinds can coexist
         x = self.x0[:n]
-        for L in self.layers:
+        for li, L in enumerate(self.layers):
             name = L["name"]
-            self._run(name + ".fwd", L["conv"].fwd, x, P["dcnn/%sW" % name], P["dcnn/%sb" % name], L["y"][:n], relu=True)
+            nxt = self.layers[li + 1] if li + 1 < len(self.layers) else None
+            if self.c8 and li > 0:
+                # bf16 path: packed operands; a conv that feeds the next conv directly also writes that conv's packed input
+                L["conv"].c8_pack_w(P["dcnn/%sW" % name], L["wb"], False)
+                yb = nxt["xb"][:n] if (nxt is not None and not L["pool"]) else None
+                self._run(name + ".fwd", L["conv"].c8_fwd, L["xb"][:n], L["wb"], P["dcnn/%sb" % name], y=L["y"][:n], yb=yb, relu=True)
+            else:
+                self._run(name + ".fwd", L["conv"].fwd, x, P["dcnn/%sW" % name], P["dcnn/%sb" % name], L["y"][:n], relu=True)
             x = L["y"][:n]
             if L["lrn"] and L["pool"]:
                 # LRN + pool in one pass: the LRN output is only ever the pool's input and is never stored
@@ -433,6 +455,8 @@ class LRCNEngine:
             elif L["pool"]:
                 ops.maxpool_fwd(x, L["p"][:n], L["arg"][:n], hwc=L["hwc"], y_halo=L["p_halo"])
                 x = L["p"][:n]
+            if self.c8 and L["pool"] and nxt is not None:
+                ops.pack_c8(x, nxt["xb"][:n], L["p_halo"], nxt["x_halo"])
         ops.gemm(x, P["dcnn/fc6W"], self.f6, n, FC_DIM, self.flat_dim, bias=P["dcnn/fc6b"], relu=True, ws=self.ws)
         if self.f7 is not None:
             ops.gemm(self.f6, P["dcnn/fc7W"], self.f7, n, FC_DIM, FC_DIM, bias=P["dcnn/fc7b"], relu=True, ws=self.ws)
@@ -597,6 +621,19 @@ class LRCNEngine:
             elif L["pool"]:
                 self._pool_bwd(L, n, dy, L["y"][:n], L["dy_halo"])
             # else: dy was written (ReluGrad fused) by the next layer's dgrad epilogue
+            if self.c8 and li > 0:
+                if L["pool"]:
+                    ops.pack_c8(dy, L["dyb"][:n], L["dy_halo"], L["dy_halo"])
+                self._run(name + ".wgrad", conv.c8_wgrad, L["xb"][:n], L["dyb"][:n], G["dcnn/%sW" % name], self.ws)
+                ops.bias_grad_nchw(dy, G["dcnn/%sb" % name], sw)
+                prev = self.layers[li - 1]
+                conv.c8_pack_w(P["dcnn/%sW" % name], L["wbt"], True)
+                if prev["pool"]:
+                    self._run(name + ".dgrad", conv.c8_dgrad, L["dyb"][:n], L["wbt"], dx=prev["dp"][:n])
+                else:
+                    self._run(name + ".dgrad", conv.c8_dgrad, L["dyb"][:n], L["wbt"], dx=prev["dy"][:n], dxb=prev["dyb"][:n],
+                              relu_mask=prev["y"][:n])
+                continue
             if conv.fuses_bias():      # bias gradient comes out of the same pass over dy
                 self._run(name + ".wgrad", conv.wgrad, x_in, dy, G["dcnn/%sW" % name], self.ws, db=G["dcnn/%sb" % name])
             else:
