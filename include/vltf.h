@@ -119,7 +119,9 @@ int vl_conv_wgrad(const vl_conv_desc* d, const float* x, const float* dy, float*
  *   vl_conv_c8_pack_w      HWIO fp32 weights -> the packed operand of vl_conv_c8_fwd (bwd = 0) / vl_conv_c8_dgrad (bwd = 1);
  *                          wb: vl_conv_c8_w_bytes(d, bwd) bytes
  *   vl_conv_c8_fwd         y (fp32 NCHW, y_halo; may be NULL) and / or yb (c8, y_halo; may be NULL) = conv(xb) + bias (ReLU)
- *   vl_conv_c8_dgrad       dx (fp32 NCHW, dx_halo) and / or dxb (c8, dx_halo) from dyb (c8, dy_halo); relu_mask as vl_conv_dgrad
+ *   vl_conv_c8_dgrad       dx (fp32 NCHW, dx_halo) and / or dxb (c8, dx_halo) from dyb (c8, dy_halo); ReluGrad of the producing layer
+ *                          from relu_mask (fp32, as vl_conv_dgrad) or relu_mask_c8 (the layer's own packed input xb, x_halo)
+ *   vl_bias_grad_c8        db[c] = sum_{n,h,w} dy from the packed gradient (c8, halo); ws: float[64 * 8 * ceil(c/8)]
  *   vl_conv_c8_wgrad       dw (HWIO fp32) from xb and dyb; deterministic slab reduction through ws (vl_conv_c8_wgrad_ws_bytes) */
 size_t vl_c8_bytes(int n, int c, int h, int w, int halo);
 int vl_pack_c8(const float* x, void* xb, int n, int c, int h, int w, int x_halo, int xb_halo, vl_stream_t stream);
@@ -127,11 +129,20 @@ size_t vl_conv_c8_w_bytes(const vl_conv_desc* d, int bwd);
 int vl_conv_c8_pack_w(const vl_conv_desc* d, const float* w_hwio, void* wb, int bwd, vl_stream_t stream);
 int vl_conv_c8_fwd(vl_conv_desc* d, const void* xb, const void* wb, const float* bias, float* y, void* yb, int n, int relu,
                    vl_stream_t stream);
-int vl_conv_c8_dgrad(vl_conv_desc* d, const void* dyb, const void* wbt, float* dx, void* dxb, const float* relu_mask, int n,
-                     vl_stream_t stream);
+int vl_conv_c8_dgrad(vl_conv_desc* d, const void* dyb, const void* wbt, float* dx, void* dxb, const float* relu_mask,
+                     const void* relu_mask_c8, int n, vl_stream_t stream);
 size_t vl_conv_c8_wgrad_ws_bytes(const vl_conv_desc* d, int n);
 int vl_conv_c8_wgrad(vl_conv_desc* d, const void* xb, const void* dyb, float* dw, void* ws, size_t ws_bytes, int n,
                      vl_stream_t stream);
+int vl_bias_grad_c8(const void* dyb, float* db, float* ws, int n, int c, int h, int w, int halo, vl_stream_t stream);
+/* A strided first layer (conv1: 11 x 11 / 4 over 3 channels) on the same kernels: with kh = s a + py, kw = s b + px it is a ka x ka
+ * (ka = ceil(k / s), odd) STRIDE-1 layer over the cin s^2 channels (c, py, px) of the space-to-depth input -- identical products and
+ * sums, plus multiplies by zero where s a + py >= k.  The caller creates that layer's descriptor (cin s^2, oh, ow, cout, ka, ka, 1, 1;
+ * x_halo = dy_halo = (ka - 1) / 2) and runs vl_conv_c8_fwd / vl_conv_c8_wgrad on it with
+ *   vl_s2d_c8_from_x0   x0 (fp32, as the strided layer d's vl_conv_fwd takes it) -> packed input [n][cin s^2 / 8][oh + ka - 1][ow + ka - 1][8]
+ *   vl_s2d_weights      grad = 0: w [k][k][cin][cout] -> [ka][ka][cin s^2][cout];  grad = 1: the stride-1 layer's dw -> dw */
+int vl_s2d_c8_from_x0(const vl_conv_desc* d, const float* x0, void* xb, int n, vl_stream_t stream);
+int vl_s2d_weights(const vl_conv_desc* d, const float* src, float* dst, int grad, vl_stream_t stream);
 /* db[c] = sum_{n,h,w} dy[n][c][h][w]  (gradient of tf.nn.bias_add, alexnet.py:31).
  * ws: float[64*c] scratch. */
 int vl_bias_grad_nchw(const float* dy, float* db, float* ws, int n, int c, int hw, vl_stream_t stream);

@@ -115,6 +115,11 @@ def test_conv_c8_fwd_dgrad_wgrad(ops, n, h, w, cin, cout, k, g):
     assert not outside.any()
     conv.c8_fwd(xb, wb, torch.from_numpy(b).to(DEV), y=y, relu=True)
     close(nhwc(y.cpu().numpy()[:, :, 1:-1, 1:-1]), np.maximum(z, 0), msg="c8 fwd + relu")
+    conv.set_halo(pad, 0, pad, 2)                                                  # dense y: the LDS-staged 16-byte store path
+    yd = torch.full((n, cout, h, w), 7.0, device=DEV)
+    conv.c8_fwd(xb, wb, torch.from_numpy(b).to(DEV), y=yd, relu=False)
+    close(nhwc(yd.cpu().numpy()), z, msg="c8 fwd (dense fp32 out)")
+    conv.set_halo(pad, 1, pad, 2)
 
     dxo, dwo, _ = O.grouped_conv_grad(x, wr, dy, 1, g, need_dx=True)
     # dgrad
@@ -129,6 +134,11 @@ def test_conv_c8_fwd_dgrad_wgrad(ops, n, h, w, cin, cout, k, g):
     mask = rng.standard_normal(x.shape).astype(np.float32)
     conv.c8_dgrad(dyb, wbt, dx=dx, relu_mask=torch.from_numpy(pad_nchw(nchw(mask), 2)).to(DEV))
     close(nhwc(dx.cpu().numpy()[:, :, 2:-2, 2:-2]), dxo * (mask > 0), msg="c8 dgrad + mask")
+    conv.c8_dgrad(dyb, wbt, dx=dx, relu_mask_c8=xb)                                # ReluGrad from the layer's own packed input
+    close(nhwc(dx.cpu().numpy()[:, :, 2:-2, 2:-2]), dxo * (x > 0), msg="c8 dgrad + packed mask")
+    db = torch.empty(cout, device=DEV)
+    ops.bias_grad_c8(dyb, db, torch.empty(64 * 8 * ((cout + 7) // 8), device=DEV), cout, pad)
+    close(db.cpu().numpy(), dy.reshape(-1, cout).sum(0), msg="bias grad from the packed gradient")
     # wgrad (twice: bitwise reproducible)
     dw = torch.empty_like(wd)
     ws = torch.empty(max(conv.c8_wgrad_ws_bytes(n) // 4, 1), device=DEV)
@@ -163,3 +173,44 @@ def test_c8_matches_the_in_loop_bf16_mode(ops):
     conv.c8_fwd(xb, wb, bd, y=y2, relu=False)
     torch.cuda.synchronize()
     close(y2.cpu().numpy(), y1.cpu().numpy(), rtol=1e-5, atol_rel=1e-5)
+
+
+@pytest.mark.parametrize("n,h,w,cout,phase", [(2, 67, 67, 96, True), (3, 37, 41, 24, False), (2, 227, 227, 96, True)])
+def test_strided_first_layer_as_a_stride1_layer(ops, n, h, w, cout, phase):
+    """conv1 (11x11 / 4 over 3 channels) through vl_s2d_*: the packed space-to-depth input and the rearranged weights run the
+    stride-1 c8 kernels and must reproduce the oracle's strided convolution and its weight gradient (bf16-rounded operands)."""
+    rng = np.random.default_rng(h)
+    k, s, cin = 11, 4, 3
+    x = bf16_round(rng.standard_normal((n, h, w, cin)) * 50)
+    wt = (rng.standard_normal((k, k, cin, cout)) / math.sqrt(k * k * cin)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    conv = ops.Conv(cin, h, w, cout, k, k, s, 1)
+    pad = conv.same_pad()
+    conv.set_halo(pad, 0, 0, 0)
+    ph = conv.set_x_phase_split(True) if phase else 1
+    xp = pad_nchw(nchw(x), pad)
+    if ph > 1:
+        wq = -(-xp.shape[3] // ph)
+        xp = np.pad(xp, ((0, 0), (0, 0), (0, 0), (0, wq * ph - xp.shape[3])))
+        xp = np.ascontiguousarray(xp.reshape(n, cin, xp.shape[2], wq, ph).transpose(0, 1, 4, 2, 3)).reshape(n, cin * ph, xp.shape[2], wq)
+    x0 = torch.from_numpy(np.ascontiguousarray(xp)).to(DEV)
+    eq = conv.s2d_layer()
+    assert (eq.cin, eq.kh, eq.stride, eq.oh, eq.ow) == (cin * s * s, 3, 1, conv.oh, conv.ow)
+    xb = torch.zeros(ops.c8_shape(n, eq.cin, eq.h, eq.w, 1), dtype=torch.bfloat16, device=DEV)
+    conv.s2d_c8_from_x0(x0, xb)
+    wd = torch.from_numpy(wt).to(DEV)
+    ws2d = torch.empty(eq.w_shape, device=DEV)
+    conv.s2d_weights(wd, ws2d)
+    wb = torch.zeros(eq.c8_w_bytes(False), dtype=torch.uint8, device=DEV)
+    eq.c8_pack_w(ws2d, wb, False)
+    y = torch.empty((n, cout, conv.oh, conv.ow), device=DEV)
+    eq.c8_fwd(xb, wb, torch.from_numpy(b).to(DEV), y=y, relu=False)
+    torch.cuda.synchronize()
+    wr = bf16_round(wt)
+    close(nhwc(y.cpu().numpy()), O.grouped_conv(x, wr, b, s, 1), msg="strided conv through space-to-depth")
+    dy = bf16_round(rng.standard_normal((n, conv.oh, conv.ow, cout)))
+    _, dwo, _ = O.grouped_conv_grad(x, wr, dy, s, 1, need_dx=False)
+    dws2d, dw = torch.empty(eq.w_shape, device=DEV), torch.empty_like(wd)
+    eq.c8_wgrad(xb, to_c8(dy, 1), dws2d, torch.empty(max(eq.c8_wgrad_ws_bytes(n) // 4, 1), device=DEV))
+    conv.s2d_weights(dws2d, dw, grad=True)
+    close(dw.cpu().numpy(), dwo, msg="strided wgrad through space-to-depth")

@@ -100,7 +100,7 @@ static constexpr int KT = 4;   // taps (32 reduction positions = two MFMA steps)
 // taps of one group: t = (cb * kh + ky) * kw + kx over the group's cbg channel blocks, padded to a multiple of KT
 static int c8_taps(int cg, int kh, int kw) { return ((cg + 7) / 8) * kh * kw; }
 static int c8_taps_padded(int cg, int kh, int kw) { return (c8_taps(cg, kh, kw) + KT - 1) / KT * KT; }
-static int c8_cop(int cog) { return (cog + 63) / 64 * 64; }   // channel pitch of the packed weights: whole 64-channel fetches
+static int c8_cop(int cog) { return (cog + 63) / 64 * 64; }   // channel pitch of the packed weights: whole 64-channel fetches (96 -> 128)
 
 // out[g][t][co < CoP][8]: forward  (bwd = 0): W[ky][kx][cb * 8 + j][g * cog + co]              (reduce over input channels)
 //                         dgrad    (bwd = 1): W[kh-1-ky][kw-1-kx][co][g * cog + cb * 8 + j]     (reduce over output channels; "co" = ci)
@@ -170,27 +170,34 @@ struct C8ConvArgs {
     float* y;               // fp32 NCHW output with halo (null: not written)
     const float* mask;      // fp32, y's layout: out = mask > 0 ? out : 0 (fused ReluGrad), or null
     int y_halo, y_w;        // y: plane width (OW + 2 halo)
+    int y_wide;             // y is dense (no halo) and unmasked: staged through LDS and stored 16 bytes per lane
     int64_t y_plane;        // floats per plane
     char* yb;               // bf16 c8 output with halo (null: not written)
     int yb_halo, yb_row;    // bytes per row
     int64_t yb_plane;       // bytes per plane
     int yb_cb;              // channel blocks per image
+    const char* maskb;      // bf16 c8 ReluGrad mask (the producing layer's packed output), or null
+    int mb_halo, mb_row;
+    int64_t mb_plane;
 };
 
 template <int WP, int WQ, int TP, int TQ>
 struct C8Cfg {
-    static constexpr int NW = WP * WQ, NT = 64 * NW, P = 32 * WP * TP, Q = 32 * WQ * TQ, NBUF = 4;
-    static constexpr int PIX_BYTES = KT * P * 16, W_BYTES = KT * Q * 16, SLOT = PIX_BYTES + W_BYTES;
-    static constexpr int NPI = KT * P / 64, NWI = KT * Q / 64;             // 1 KB fetches per stage: pixels, weights
+    static constexpr int NW = WP * WQ, NT = 64 * NW, P = 32 * WP * TP, Q = 32 * WQ * TQ;
+    static constexpr int NBUF = NW == 4 ? 3 : 4;                           // 4-wave tiles: 60-72 KB of LDS, two workgroups per CU
+    static constexpr int QF = (Q + 63) / 64 * 64;                          // channels fetched per tap: whole 64-lane fetches (96 -> 128)
+    static constexpr int PIX_BYTES = KT * P * 16, W_BYTES = KT * QF * 16, SLOT = PIX_BYTES + W_BYTES;
+    static constexpr int NPI = KT * P / 64, NWI = KT * QF / 64;            // 1 KB fetches per stage: pixels, weights
     static constexpr int FP = (NPI + NW - 1) / NW, FW = (NWI + NW - 1) / NW, F = FP + FW;
-    static constexpr size_t LDS_BYTES = (size_t)NBUF * SLOT;
-    static_assert(Q % 64 == 0 && P % 64 == 0, "whole 64-lane fetches");
+    static constexpr int STG = 32 * TQ * 36;                               // floats per wave of the wide-store staging ([channel][32 pixels + 4])
+    static constexpr size_t LDS_BYTES = (size_t)NBUF * SLOT > (size_t)NW * STG * 4 ? (size_t)NBUF * SLOT : (size_t)NW * STG * 4;
+    static_assert(P % 64 == 0, "whole 64-lane fetches");
 };
 
 template <int WP, int WQ, int TP, int TQ>
 __global__ __launch_bounds__(64 * WP * WQ) void conv_c8_kernel(const C8ConvArgs a, int tiles_q) {
     using C = C8Cfg<WP, WQ, TP, TQ>;
-    constexpr int NW = C::NW, P = C::P, Q = C::Q, NBUF = C::NBUF, SLOT = C::SLOT, FP = C::FP, FW = C::FW, F = C::F;
+    constexpr int NW = C::NW, P = C::P, Q = C::Q, QF = C::QF, NBUF = C::NBUF, SLOT = C::SLOT, FP = C::FP, FW = C::FW, F = C::F;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int bid = xcd_swizzle(blockIdx.x, gridDim.x);
     const int tq = bid % tiles_q, tp = bid / tiles_q, g = blockIdx.y;
@@ -223,10 +230,10 @@ __global__ __launch_bounds__(64 * WP * WQ) void conv_c8_kernel(const C8ConvArgs 
     }
 #pragma unroll
     for (int j = 0; j < FW; ++j) {
-        const int id = (wave + j * NW) % C::NWI, tap = id / (Q / 64), qc = id % (Q / 64);
+        const int id = (wave + j * NW) % C::NWI, tap = id / (QF / 64), qc = id % (QF / 64);
         voff_w[j] = (uint32_t)((q0 + qc * 64 + lane) * 16);
         tap_w[j] = tap;
-        lds_w[j] = C::PIX_BYTES + tap * Q * 16 + qc * 1024;
+        lds_w[j] = C::PIX_BYTES + tap * QF * 16 + qc * 1024;
     }
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;   // LDS byte address of the ring
     auto issue = [&](int st) {
@@ -247,7 +254,7 @@ __global__ __launch_bounds__(64 * WP * WQ) void conv_c8_kernel(const C8ConvArgs 
 
     for (int st = 0; st < NBUF - 1 && st < nstages; ++st) issue(st);
     const uint32_t rd_p = (uint32_t)((lane >> 5) * P * 16 + (wp * TP * 32 + (lane & 31)) * 16);
-    const uint32_t rd_w = (uint32_t)(C::PIX_BYTES + (lane >> 5) * Q * 16 + (wq * TQ * 32 + (lane & 31)) * 16);
+    const uint32_t rd_w = (uint32_t)(C::PIX_BYTES + (lane >> 5) * QF * 16 + (wq * TQ * 32 + (lane & 31)) * 16);
     for (int st = 0; st < nstages; ++st) {
         // stage st has landed when at most the fetches of the later stages already issued are outstanding
         const int later = (nstages - 1 - st) < (NBUF - 2) ? (nstages - 1 - st) : (NBUF - 2);
@@ -266,7 +273,7 @@ __global__ __launch_bounds__(64 * WP * WQ) void conv_c8_kernel(const C8ConvArgs 
 #pragma unroll
             for (int i = 0; i < TP; ++i) bp[i] = *reinterpret_cast<const i32x4*>(slot + rd_p + kk * 2 * P * 16 + i * 512);
 #pragma unroll
-            for (int j = 0; j < TQ; ++j) aq[j] = *reinterpret_cast<const i32x4*>(slot + rd_w + kk * 2 * Q * 16 + j * 512);
+            for (int j = 0; j < TQ; ++j) aq[j] = *reinterpret_cast<const i32x4*>(slot + rd_w + kk * 2 * QF * 16 + j * 512);
 #pragma unroll
             for (int j = 0; j < TQ; ++j)
 #pragma unroll
@@ -275,35 +282,74 @@ __global__ __launch_bounds__(64 * WP * WQ) void conv_c8_kernel(const C8ConvArgs 
     }
 
     // ---- epilogue ----
+    typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte access at 4-byte alignment
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const bool wide = a.y_wide != 0;        // (uniform) dense unmasked fp32 output: staged through LDS, stored 16 bytes per lane
+    float* stg = reinterpret_cast<float*>(lds) + wave * C::STG;             // this wave's [32 TQ channels][32 pixels + 4]
+    if (wide) __syncthreads();                                              // every wave is done with the ring
 #pragma unroll
     for (int i = 0; i < TP; ++i) {
-        const int m = p0 + (wp * TP + i) * 32 + (lane & 31);
-        if (m >= a.M) continue;
-        const uint32_t n = fd_div((uint32_t)m, a.dOHW), r = (uint32_t)m - n * a.dOHW.d;
-        const uint32_t oh = fd_div(r, a.dOW), ow = r - oh * a.dOW.d;
-        const int64_t ypix = (int64_t)(oh + a.y_halo) * a.y_w + ow + a.y_halo;
-        const int64_t ybpix = (int64_t)(oh + a.yb_halo) * a.yb_row + (int64_t)(ow + a.yb_halo) * 16 + 8 * (lane >> 5);
+        const int mb = p0 + (wp * TP + i) * 32;                             // first pixel of this 32-pixel block (uniform)
+        const int m = mb + (lane & 31);
+        if (m < a.M) {
+            const uint32_t n = fd_div((uint32_t)m, a.dOHW), r = (uint32_t)m - n * a.dOHW.d;
+            const uint32_t oh = fd_div(r, a.dOW), ow = r - oh * a.dOW.d;
+            const int64_t ypix = (int64_t)(oh + a.y_halo) * a.y_w + ow + a.y_halo;
+            const int64_t ybpix = (int64_t)(oh + a.yb_halo) * a.yb_row + (int64_t)(ow + a.yb_halo) * 16 + 8 * (lane >> 5);
+            const int64_t mbpix = (int64_t)(oh + a.mb_halo) * a.mb_row + (int64_t)(ow + a.mb_halo) * 16 + 8 * (lane >> 5);
 #pragma unroll
-        for (int j = 0; j < TQ; ++j) {
+            for (int j = 0; j < TQ; ++j) {
 #pragma unroll
-            for (int qg = 0; qg < 4; ++qg) {
-                const int cog0 = q0 + (wq * TQ + j) * 32 + 8 * qg;   // first channel (within the group) of this 8-channel block
-                if (cog0 >= a.Cog) continue;
-                const int c0 = g * a.Cog + cog0 + 4 * (lane >> 5);   // this lane's 4 channels: c0 .. c0 + 3
-                float v[4];
+                for (int qg = 0; qg < 4; ++qg) {
+                    const int cog0 = q0 + (wq * TQ + j) * 32 + 8 * qg;   // first channel (within the group) of this 8-channel block
+                    if (cog0 >= a.Cog) continue;
+                    const int c0 = g * a.Cog + cog0 + 4 * (lane >> 5);   // this lane's 4 channels: c0 .. c0 + 3
+                    float v[4];
+                    uint2 mk = {0x3f803f80u, 0x3f803f80u};
+                    if (a.maskb)
+                        mk = *reinterpret_cast<const uint2*>(a.maskb + ((int64_t)n * a.yb_cb + (g * a.Cog + cog0) / 8) * a.mb_plane + mbpix);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = acc[j][i][qg * 4 + e];
-                    if (a.bias) v[e] += a.bias[c0 + e];
-                    if (a.relu) v[e] = fmaxf(v[e], 0.f);
-                    if (a.mask) v[e] = a.mask[((int64_t)n * a.Ctot + c0 + e) * a.y_plane + ypix] > 0.f ? v[e] : 0.f;
-                    if (a.y) a.y[((int64_t)n * a.Ctot + c0 + e) * a.y_plane + ypix] = v[e];
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = acc[j][i][qg * 4 + e];
+                        if (a.bias) v[e] += a.bias[c0 + e];
+                        if (a.relu) v[e] = fmaxf(v[e], 0.f);
+                        if (a.mask) v[e] = a.mask[((int64_t)n * a.Ctot + c0 + e) * a.y_plane + ypix] > 0.f ? v[e] : 0.f;
+                        const uint32_t mw = e < 2 ? mk.x : mk.y;
+                        if (a.maskb) v[e] = (int16_t)((e & 1) ? (mw >> 16) : (mw & 0xffffu)) > 0 ? v[e] : 0.f;   // bf16 > 0
+                        if (a.y && !wide) a.y[((int64_t)n * a.Ctot + c0 + e) * a.y_plane + ypix] = v[e];
+                        if (wide) stg[(j * 32 + qg * 8 + 4 * (lane >> 5) + e) * 36 + (lane & 31)] = v[e];
+                    }
+                    if (a.yb) {
+                        uint2 o;
+                        o.x = pack_bf16(v[0], v[1]);
+                        o.y = pack_bf16(v[2], v[3]);
+                        *reinterpret_cast<uint2*>(a.yb + ((int64_t)n * a.yb_cb + (g * a.Cog + cog0) / 8) * a.yb_plane + ybpix) = o;
+                    }
                 }
-                if (a.yb) {
-                    uint2 o;
-                    o.x = pack_bf16(v[0], v[1]);
-                    o.y = pack_bf16(v[2], v[3]);
-                    *reinterpret_cast<uint2*>(a.yb + ((int64_t)n * a.yb_cb + (g * a.Cog + cog0) / 8) * a.yb_plane + ybpix) = o;
+            }
+        }
+        if (wide) {
+            // the block's 32 pixels x 32 TQ channels leave as 16-byte stores: lane = (pixel quad lane & 7, channel lane >> 3 of 8 per pass).
+            // y is dense, so consecutive pixels of an image are consecutive floats; a quad that straddles two images (or the end) goes
+            // pixel by pixel.
+            const int m4 = mb + (lane & 7) * 4;
+            const uint32_t n4 = fd_div((uint32_t)(m4 < a.M ? m4 : 0), a.dOHW), r4 = (uint32_t)(m4 < a.M ? m4 : 0) - n4 * a.dOHW.d;
+            const bool whole = m4 + 3 < a.M && (int)r4 + 3 < a.OHW;
+#pragma unroll
+            for (int it = 0; it < TQ * 4; ++it) {
+                const int ch = it * 8 + (lane >> 3), cog = q0 + wq * TQ * 32 + ch;
+                if (cog >= a.Cog || m4 >= a.M) continue;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(stg + ch * 36 + (lane & 7) * 4);
+                float* dst = a.y + ((int64_t)n4 * a.Ctot + g * a.Cog + cog) * a.y_plane + r4;
+                if (whole) {
+                    *reinterpret_cast<f32x4u*>(dst) = v;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (m4 + e >= a.M) break;
+                        const bool next = (int)r4 + e >= a.OHW;        // this pixel is in the next image
+                        dst[(next ? (int64_t)a.Ctot * a.y_plane - a.OHW : 0) + e] = v[e];
+                    }
                 }
             }
         }
@@ -360,7 +406,7 @@ static int launch_c8(const C8ConvArgs& a, int groups, hipStream_t stream) {
         attr = true;
     }
     const int tiles_q = (a.Cog + C::Q - 1) / C::Q, tiles_p = (a.M + C::P - 1) / C::P;
-    VL_CHECK(tiles_q * C::Q <= a.CoP, "conv c8: packed weights narrower than the channel tiling");
+    VL_CHECK((tiles_q - 1) * C::Q + C::QF <= a.CoP, "conv c8: packed weights narrower than the channel tiling");
     hipLaunchKernelGGL(kern, dim3(tiles_q * tiles_p, groups), dim3(C::NT), C::LDS_BYTES, stream, a, tiles_q);
     VL_LAUNCH_CHECK();
     return 0;
@@ -369,6 +415,7 @@ static int launch_c8(const C8ConvArgs& a, int groups, hipStream_t stream) {
 // channel tile by the group's channel count: 128-wide tiles, 192 as one tile of 192 (conv4 / conv5 dgrad), 64 for narrow groups
 static int dispatch_c8(const C8ConvArgs& a, int groups, hipStream_t stream) {
     if (a.Cog <= 64) return launch_c8<4, 1, 2, 2>(a, groups, stream);          // 256 pixels x 64 channels, 4 waves
+    if (a.Cog <= 96) return launch_c8<4, 1, 2, 3>(a, groups, stream);          // 256 x 96 (conv1 as a 3x3 conv over 48 channels)
     if (a.Cog % 128 != 0 && a.Cog % 192 == 0) return launch_c8<4, 2, 2, 3>(a, groups, stream);   // 256 x 192
     return launch_c8<4, 2, 2, 2>(a, groups, stream);                           // 256 x 128
 }
@@ -404,6 +451,7 @@ extern "C" int vl_conv_c8_fwd(vl_conv_desc* d, const void* xb, const void* wb, c
     a.bias = bias;
     a.relu = relu;
     a.y = y;
+    a.y_wide = (y != nullptr && d->y_halo == 0 && d->oh * d->ow >= 4) ? 1 : 0;
     a.y_halo = d->y_halo;
     a.y_w = d->ow + 2 * d->y_halo;
     a.y_plane = (int64_t)(d->oh + 2 * d->y_halo) * a.y_w;
@@ -416,9 +464,10 @@ extern "C" int vl_conv_c8_fwd(vl_conv_desc* d, const void* xb, const void* wb, c
 }
 
 /* dx = d(loss)/dx from the c8 operand dyb (dy_halo) and vl_conv_c8_pack_w(bwd = 1)'s weights (stride-1 layers): dx (fp32 NCHW,
- * dx_halo) and / or dxb (bf16 c8, dx_halo); relu_mask (fp32, dx's layout) fuses the ReluGrad of the producing layer. */
-extern "C" int vl_conv_c8_dgrad(vl_conv_desc* d, const void* dyb, const void* wbt, float* dx, void* dxb, const float* relu_mask, int n,
-                                vl_stream_t stream) {
+ * dx_halo) and / or dxb (bf16 c8, dx_halo); relu_mask (fp32, dx's layout) or relu_mask_c8 (the layer's own packed input xb, x_halo)
+ * fuses the ReluGrad of the producing layer. */
+extern "C" int vl_conv_c8_dgrad(vl_conv_desc* d, const void* dyb, const void* wbt, float* dx, void* dxb, const float* relu_mask,
+                                const void* relu_mask_c8, int n, vl_stream_t stream) {
     VL_CHECK(d && dyb && wbt && (dx || dxb) && n > 0, "vl_conv_c8_dgrad: bad argument");
     VL_CHECK(d->stride == 1 && d->bwd_padded, "vl_conv_c8_dgrad: stride-1 layers in the padded layout only");
     VL_CHECK(d->cig % 8 == 0 && d->cog % 8 == 0, "vl_conv_c8_dgrad: channels per group must be a multiple of 8");
@@ -444,6 +493,10 @@ extern "C" int vl_conv_c8_dgrad(vl_conv_desc* d, const void* dyb, const void* wb
     a.Cog = d->cig;
     a.Ctot = d->cin;
     a.mask = relu_mask;
+    a.maskb = (const char*)relu_mask_c8;
+    a.mb_halo = d->x_halo;
+    a.mb_row = (d->w + 2 * d->x_halo) * 16;
+    a.mb_plane = (int64_t)(d->h + 2 * d->x_halo) * a.mb_row;
     a.y = dx;
     a.y_halo = d->dx_halo;
     a.y_w = d->w + 2 * d->dx_halo;
@@ -491,9 +544,9 @@ __device__ __forceinline__ i32x2 lds_read_tr(uint32_t addr) {   // ds_read_b64_t
     return __builtin_bit_cast(i32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(uintptr_t)addr));
 }
 
-template <int WA, int WB>
+template <int WA, int WB, int TB>
 struct C8WgCfg {
-    static constexpr int NW = WA * WB, NT = 64 * NW, ROWS = 64 * WA, COLS = 64 * WB, TAPS = ROWS / 8, NBUF = 4, KP = 32;
+    static constexpr int NW = WA * WB, NT = 64 * NW, ROWS = 64 * WA, COLS = 32 * TB * WB, TAPS = ROWS / 8, NBUF = 4, KP = 32;
     static constexpr int SUBA = (TAPS + 15) / 16, SUBB = (COLS / 8 + 15) / 16;      // 16-chunk sub-images per operand
     static constexpr int A_BYTES = SUBA * KP * 256, B_BYTES = SUBB * KP * 256, SLOT = A_BYTES + B_BYTES;
     static constexpr int NAI = SUBA * KP / 4, NBI = SUBB * KP / 4;                  // 1 KB fetches per stage
@@ -501,9 +554,9 @@ struct C8WgCfg {
     static constexpr size_t LDS_BYTES = (size_t)NBUF * SLOT;
 };
 
-template <int WA, int WB>
+template <int WA, int WB, int TB>
 __global__ __launch_bounds__(64 * WA * WB) void wgrad_c8_kernel(const C8WgradArgs a, int tiles_a, int tiles_b) {
-    using C = C8WgCfg<WA, WB>;
+    using C = C8WgCfg<WA, WB, TB>;
     constexpr int NW = C::NW, NBUF = C::NBUF, SLOT = C::SLOT, KP = C::KP, FA = C::FA, FB = C::FB, F = C::F;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int bid = blockIdx.x;
@@ -593,11 +646,11 @@ __global__ __launch_bounds__(64 * WA * WB) void wgrad_c8_kernel(const C8WgradArg
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][TB];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TB; ++j)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
@@ -606,11 +659,15 @@ __global__ __launch_bounds__(64 * WA * WB) void wgrad_c8_kernel(const C8WgradArg
     // lane 4 q + p of the group addresses row q, columns 4 p .. 4 p + 3 = chunk 2 (g16 & 1) + (p >> 1), byte 8 (p & 1)
     const int g16 = lane >> 4, rq = (lane & 15) >> 2, rp = lane & 3;
     const int cl = 2 * (g16 & 1) + (rp >> 1);                        // chunk within the block's 4 chunks
-    uint32_t rd_a[2], rd_b[2];
+    uint32_t rd_a[2], rd_b[TB];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int ca = (wa * 2 + i) * 4 + cl, cbk = (wb * 2 + i) * 4 + cl;      // chunk within the tile: sub-image chunk >> 4, slot chunk & 15
+        const int ca = (wa * 2 + i) * 4 + cl;                                   // chunk within the tile: sub-image chunk >> 4, slot chunk & 15
         rd_a[i] = lds0 + (uint32_t)((ca >> 4) * KP * 256 + (g16 >> 1) * 2048 + rq * 256 + (((ca & 15) ^ (rq << 2)) * 16) + 8 * (rp & 1));
+    }
+#pragma unroll
+    for (int i = 0; i < TB; ++i) {
+        const int cbk = (wb * TB + i) * 4 + cl;
         rd_b[i] = lds0 + (uint32_t)(C::A_BYTES + (cbk >> 4) * KP * 256 + (g16 >> 1) * 2048 + rq * 256 + (((cbk & 15) ^ (rq << 2)) * 16) +
                                     8 * (rp & 1));
     }
@@ -627,18 +684,21 @@ __global__ __launch_bounds__(64 * WA * WB) void wgrad_c8_kernel(const C8WgradArg
         const uint32_t so = (uint32_t)(st % NBUF) * SLOT;
 #pragma unroll
         for (int kk = 0; kk < KP / 16; ++kk) {
-            i32x4 av[2], bv[2];
+            i32x4 av[2], bv[TB];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const i32x2 a0 = lds_read_tr(rd_a[i] + so + kk * 4096), a1 = lds_read_tr(rd_a[i] + so + kk * 4096 + 1024);
-                const i32x2 b0 = lds_read_tr(rd_b[i] + so + kk * 4096), b1 = lds_read_tr(rd_b[i] + so + kk * 4096 + 1024);
                 av[i] = i32x4{a0[0], a0[1], a1[0], a1[1]};
+            }
+#pragma unroll
+            for (int i = 0; i < TB; ++i) {
+                const i32x2 b0 = lds_read_tr(rd_b[i] + so + kk * 4096), b1 = lds_read_tr(rd_b[i] + so + kk * 4096 + 1024);
                 bv[i] = i32x4{b0[0], b0[1], b1[0], b1[1]};
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = mfma_bf16(av[i], bv[j], acc[i][j]);
+                for (int j = 0; j < TB; ++j) acc[i][j] = mfma_bf16(av[i], bv[j], acc[i][j]);
         }
     }
 
@@ -647,8 +707,8 @@ __global__ __launch_bounds__(64 * WA * WB) void wgrad_c8_kernel(const C8WgradArg
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = co0 + (wb * 2 + j) * 32 + (lane & 31);
+        for (int j = 0; j < TB; ++j) {
+            const int col = co0 + (wb * TB + j) * 32 + (lane & 31);
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int row = tap0 * 8 + (wa * 2 + i) * 32 + 8 * (q >> 2) + 4 * (lane >> 5) + (q & 3);
@@ -676,16 +736,20 @@ __global__ void wgrad_c8_reduce_kernel(const float* __restrict__ ws, float* __re
 }
 
 struct C8WgPlan {
-    int wa, wb, tiles_a, tiles_b, slabs, slab_len, rowsP, CoP;
+    int wa, wb, tb, tiles_a, tiles_b, slabs, slab_len, rowsP, CoP;
     int64_t Rtot;
     int L;
 };
 
 static int c8_wgrad_plan(const vl_conv_desc* d, int n, C8WgPlan* p) {
     const int ntaps = c8_taps(d->cig, d->kh, d->kw);
+    // waves (taps x channels) and 32-channel blocks per wave: 32 taps x 128 channels; 192-channel groups: 16 taps x 192;
+    // up to 96 channels (conv1 as a 3x3 conv over 48 channels): 32 taps x 96 with every wave on all 96
+    p->tb = 2;
     p->wb = d->cog % 128 == 0 ? 2 : d->cog % 192 == 0 ? 3 : 2;
     p->wa = p->wb == 3 ? 2 : 4;
-    const int taps_tile = p->wa * 8, cols_tile = p->wb * 64;
+    if (d->cog <= 96 && d->cog > 64) p->wa = 4, p->wb = 1, p->tb = 3;
+    const int taps_tile = p->wa * 8, cols_tile = p->wb * p->tb * 32;
     p->tiles_a = (ntaps + taps_tile - 1) / taps_tile;
     p->tiles_b = (d->cog + cols_tile - 1) / cols_tile;
     p->rowsP = p->tiles_a * taps_tile * 8;
@@ -711,10 +775,10 @@ extern "C" size_t vl_conv_c8_wgrad_ws_bytes(const vl_conv_desc* d, int n) {
     return (size_t)p.slabs * d->groups * p.rowsP * p.CoP * sizeof(float);
 }
 
-template <int WA, int WB>
+template <int WA, int WB, int TB>
 static int launch_c8_wgrad(const C8WgradArgs& a, const C8WgPlan& p, int groups, hipStream_t stream) {
-    using C = C8WgCfg<WA, WB>;
-    auto kern = wgrad_c8_kernel<WA, WB>;
+    using C = C8WgCfg<WA, WB, TB>;
+    auto kern = wgrad_c8_kernel<WA, WB, TB>;
     static bool attr = false;
     if (!attr) {
         VL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
@@ -761,11 +825,148 @@ extern "C" int vl_conv_c8_wgrad(vl_conv_desc* d, const void* xb, const void* dyb
     a.rowsP = p.rowsP;
     a.CoP = p.CoP;
     a.dL = make_fastdiv(p.L);
-    int rc = p.wb == 3 ? launch_c8_wgrad<2, 3>(a, p, d->groups, (hipStream_t)stream) : launch_c8_wgrad<4, 2>(a, p, d->groups, (hipStream_t)stream);
+    int rc = p.tb == 3   ? launch_c8_wgrad<4, 1, 3>(a, p, d->groups, (hipStream_t)stream)
+             : p.wb == 3 ? launch_c8_wgrad<2, 3, 2>(a, p, d->groups, (hipStream_t)stream)
+                         : launch_c8_wgrad<4, 2, 2>(a, p, d->groups, (hipStream_t)stream);
     if (rc) return rc;
     const int64_t total = (int64_t)d->kh * d->kw * d->cig * d->cout;
     hipLaunchKernelGGL(wgrad_c8_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)ws, dw,
                        d->kh, d->kw, d->cig, d->cog, d->groups, p.rowsP, p.CoP, p.slabs, total);
+    VL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- bias gradient from the packed gradient: db[c] = sum over images and pixels of dyb (halo zeros add nothing) ----------------
+// grid (CB, S): block (cb, s) sums the 8 channels of block cb over images [s * per, (s + 1) * per): wave w takes images w, w + 4, ..,
+// lanes take 16-byte chunks; fixed order -> bitwise reproducible.  ws: float[S][8 CB].
+__device__ __forceinline__ float bf16_lo(uint32_t v) { return __uint_as_float(v << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t v) { return __uint_as_float(v & 0xffff0000u); }
+
+__global__ void bias_grad_c8_stage1(const uint4* __restrict__ dyb, float* __restrict__ ws, int n, int CB, int plane, int per) {
+    __shared__ float sm[4][8];
+    const int cb = blockIdx.x, s = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n0 = s * per, n1 = min(n, n0 + per);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int img = n0 + wave; img < n1; img += 4) {
+        const uint4* p = dyb + ((int64_t)img * CB + cb) * plane;
+        for (int i = lane; i < plane; i += 64) {
+            const uint4 v = p[i];
+            acc[0] += bf16_lo(v.x);
+            acc[1] += bf16_hi(v.x);
+            acc[2] += bf16_lo(v.y);
+            acc[3] += bf16_hi(v.y);
+            acc[4] += bf16_lo(v.z);
+            acc[5] += bf16_hi(v.z);
+            acc[6] += bf16_lo(v.w);
+            acc[7] += bf16_hi(v.w);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float t = wave_sum(acc[j]);
+        if (lane == 0) sm[wave][j] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) ws[((int64_t)s * CB + cb) * 8 + threadIdx.x] = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
+}
+
+__global__ void bias_grad_c8_stage2(const float* __restrict__ ws, float* __restrict__ db, int C, int CP, int S) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float a = 0.f;
+    for (int s = 0; s < S; ++s) a += ws[(int64_t)s * CP + c];
+    db[c] = a;
+}
+
+/* db[c] = sum_{n,h,w} dy[n][c][h][w] from the packed gradient dyb (c8, halo); ws: float[64 * 8 * ceil(c / 8)]. */
+extern "C" int vl_bias_grad_c8(const void* dyb, float* db, float* ws, int n, int c, int h, int w, int halo, vl_stream_t stream) {
+    VL_CHECK(dyb && db && ws && n > 0 && c > 0 && h > 0 && w > 0 && halo >= 0, "vl_bias_grad_c8: bad argument");
+    const int CB = (c + 7) / 8, plane = (h + 2 * halo) * (w + 2 * halo);
+    const int S = n < 64 ? n : 64, per = ceil_div(n, S), S2 = ceil_div(n, per);
+    hipLaunchKernelGGL(bias_grad_c8_stage1, dim3(CB, S2), dim3(256), 0, (hipStream_t)stream, (const uint4*)dyb, ws, n, CB, plane, per);
+    VL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bias_grad_c8_stage2, dim3(ceil_div(c, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)ws, db, c, CB * 8, S2);
+    VL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- a strided first layer as a stride-1 layer: space to depth ---------------------------------------------------------------------
+// conv1 (11 x 11, stride s = 4, 3 input channels) has neither 8 channels for a chunk nor unit stride.  With kh = s a + py, kw = s b +
+// px it IS a ka x ka stride-1 convolution (ka = ceil(k / s) = 3) over the C s^2 = 48 "channels" (c, py, px) of the space-to-depth input
+//   x'[n][(c, py, px)][R][S] = xpad[c][s R + py][s S + px]      (xpad: x behind its pt / pl leading SAME zeros; R = oh + a, S = ow + b)
+//   W'[a][b][(c, py, px)][co] = W[s a + py][s b + px][c][co]    (zero where s a + py or s b + px >= k)
+// -- same products, same sums, 19 % more multiplies by zero -- so forward and wgrad run the c8 kernels above on a 48-channel layer
+// whose packed input is written in its "SAME halo 1" form (R, S run over oh + 2, ow + 2: the halo positions hold data here).
+__global__ void s2d_c8_kernel(const float* __restrict__ x0, uint4* __restrict__ xb, int C, int s, int H, int W, int halo, int phase, int pt,
+                              int pl, int OHp, int OWp, int CB, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int S = (int)(idx % OWp), R = (int)((idx / OWp) % OHp), cb = (int)((idx / ((int64_t)OWp * OHp)) % CB);
+    const int n = (int)(idx / ((int64_t)OWp * OHp * CB));
+    const int Hp = H + 2 * halo, Wfull = W + 2 * halo, Wq = phase > 1 ? (Wfull + phase - 1) / phase : Wfull;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int cp = cb * 8 + j, px = cp % s, py = (cp / s) % s, c = cp / (s * s);
+        const int row = s * R + py - pt + halo, col = s * S + px - pl + halo;       // physical position in x0's padded plane
+        float t = 0.f;
+        if (c < C && row >= 0 && row < Hp && col >= 0 && col < Wfull)
+            t = phase > 1 ? x0[((((int64_t)n * C + c) * phase + col % phase) * Hp + row) * Wq + col / phase]
+                          : x0[(((int64_t)n * C + c) * Hp + row) * Wq + col];
+        v[j] = t;
+    }
+    uint4 o;
+    o.x = pack_bf16(v[0], v[1]);
+    o.y = pack_bf16(v[2], v[3]);
+    o.z = pack_bf16(v[4], v[5]);
+    o.w = pack_bf16(v[6], v[7]);
+    xb[idx] = o;
+}
+
+// fwd (grad = 0): ws[a][b][(c, py, px)][co] = W[s a + py][s b + px][c][co] or 0;  grad = 1: dW[kh][kw][c][co] = dws[kh / s][kw / s][(c, kh % s, kw % s)][co]
+__global__ void s2d_weights_kernel(const float* __restrict__ src, float* __restrict__ dst, int k, int s, int C, int cout, int ka, int grad,
+                                   int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int co = (int)(idx % cout);
+    if (!grad) {
+        const int cp = (int)((idx / cout) % (C * s * s)), b = (int)((idx / ((int64_t)cout * C * s * s)) % ka), a = (int)(idx / ((int64_t)cout * C * s * s * ka));
+        const int px = cp % s, py = (cp / s) % s, c = cp / (s * s), kh = s * a + py, kw = s * b + px;
+        dst[idx] = (kh < k && kw < k) ? src[((int64_t)(kh * k + kw) * C + c) * cout + co] : 0.f;
+    } else {
+        const int c = (int)((idx / cout) % C), kw = (int)((idx / ((int64_t)cout * C)) % k), kh = (int)(idx / ((int64_t)cout * C * k));
+        const int cp = (c * s + kh % s) * s + kw % s;
+        dst[idx] = src[((int64_t)((kh / s) * ka + kw / s) * (C * s * s) + cp) * cout + co];
+    }
+}
+
+static int s2d_check(const vl_conv_desc* d, const char* who) {
+    VL_CHECK(d && d->stride > 1 && d->groups == 1 && d->kh == d->kw && d->fwd_padded, "%s: a strided, ungrouped, square layer in the padded layout", who);
+    VL_CHECK((((d->kh - 1) / d->stride + 1) & 1) == 1, "%s: ceil(k / stride) must be odd", who);
+    return 0;
+}
+
+/* x0 (fp32, the strided layer's input as vl_conv_fwd takes it: x_halo, plain or phase split) -> the packed space-to-depth input of
+ * the equivalent stride-1 layer: c8 [n][cin s^2 / 8][oh + ka - 1][ow + ka - 1][8], ka = ceil(k / stride). */
+extern "C" int vl_s2d_c8_from_x0(const vl_conv_desc* d, const float* x0, void* xb, int n, vl_stream_t stream) {
+    VL_CHECK(x0 && xb && n > 0, "vl_s2d_c8_from_x0: bad argument");
+    if (int rc = s2d_check(d, "vl_s2d_c8_from_x0")) return rc;
+    const int s = d->stride, ka = (d->kh - 1) / s + 1, OHp = d->oh + ka - 1, OWp = d->ow + ka - 1, CB = (d->cin * s * s + 7) / 8;
+    const int64_t total = (int64_t)n * CB * OHp * OWp;
+    hipLaunchKernelGGL(s2d_c8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x0, (uint4*)xb, d->cin, s, d->h,
+                       d->w, d->x_halo, d->x_phase > 1 ? d->x_phase : 1, d->pt, d->pl, OHp, OWp, CB, total);
+    VL_LAUNCH_CHECK();
+    return 0;
+}
+
+/* grad = 0: w (HWIO [k][k][cin][cout]) -> w_s2d ([ka][ka][cin s^2][cout]);  grad = 1: dw_s2d -> dw (the inverse gather). */
+extern "C" int vl_s2d_weights(const vl_conv_desc* d, const float* src, float* dst, int grad, vl_stream_t stream) {
+    VL_CHECK(src && dst, "vl_s2d_weights: bad argument");
+    if (int rc = s2d_check(d, "vl_s2d_weights")) return rc;
+    const int s = d->stride, ka = (d->kh - 1) / s + 1;
+    const int64_t total = grad ? (int64_t)d->kh * d->kw * d->cin * d->cout : (int64_t)ka * ka * d->cin * s * s * d->cout;
+    hipLaunchKernelGGL(s2d_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, dst, d->kh, s, d->cin,
+                       d->cout, ka, grad, total);
     VL_LAUNCH_CHECK();
     return 0;
 }

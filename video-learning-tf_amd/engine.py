@@ -251,6 +251,16 @@ class LRCNEngine:
                     L["dyb"] = cbuf(conv.cout, conv.oh, conv.ow, L["dy_halo"])
                     L["wbt"] = torch.zeros(conv.c8_w_bytes(True), dtype=torch.uint8, device=dev)
                     ws_bytes = max(ws_bytes, conv.c8_wgrad_ws_bytes(N))
+            # conv1 (strided, 3 channels) runs the same kernels as the equivalent stride-1 layer over its space-to-depth input
+            L0 = self.layers[0]
+            eq = L0["eq"] = L0["conv"].s2d_layer()
+            L0["xb"] = cbuf(eq.cin, eq.h, eq.w, eq.x_halo)
+            L0["ws2d"] = torch.zeros(eq.w_shape, device=dev)
+            L0["wb"] = torch.zeros(eq.c8_w_bytes(False), dtype=torch.uint8, device=dev)
+            if training:
+                L0["dyb"] = cbuf(eq.cout, eq.oh, eq.ow, eq.dy_halo)
+                L0["dws2d"] = torch.zeros(eq.w_shape, device=dev)
+                ws_bytes = max(ws_bytes, eq.c8_wgrad_ws_bytes(N))
         self.flat_dim = h * w * c
         self.f6 = buf(N, FC_DIM)
         self.f7 = buf(N, FC_DIM) if cfg.frame_encoding_layer != "fc6" else None
@@ -440,11 +450,18 @@ class LRCNEngine:
         for li, L in enumerate(self.layers):
             name = L["name"]
             nxt = self.layers[li + 1] if li + 1 < len(self.layers) else None
-            if self.c8 and li > 0:
+            if self.c8 and li == 0:
+                conv = L["conv"]
+                conv.s2d_c8_from_x0(x, L["xb"][:n])
+                conv.s2d_weights(P["dcnn/%sW" % name], L["ws2d"])
+                L["eq"].c8_pack_w(L["ws2d"], L["wb"], False)
+                self._run(name + ".fwd", L["eq"].c8_fwd, L["xb"][:n], L["wb"], P["dcnn/%sb" % name], y=L["y"][:n], relu=True)
+            elif self.c8:
                 # bf16 path: packed operands; a conv that feeds the next conv directly also writes that conv's packed input
                 L["conv"].c8_pack_w(P["dcnn/%sW" % name], L["wb"], False)
                 yb = nxt["xb"][:n] if (nxt is not None and not L["pool"]) else None
-                self._run(name + ".fwd", L["conv"].c8_fwd, L["xb"][:n], L["wb"], P["dcnn/%sb" % name], y=L["y"][:n], yb=yb, relu=True)
+                y = L["y"][:n] if yb is None else None       # fp32 output only where a pool / LRN kernel reads it
+                self._run(name + ".fwd", L["conv"].c8_fwd, L["xb"][:n], L["wb"], P["dcnn/%sb" % name], y=y, yb=yb, relu=True)
             else:
                 self._run(name + ".fwd", L["conv"].fwd, x, P["dcnn/%sW" % name], P["dcnn/%sb" % name], L["y"][:n], relu=True)
             x = L["y"][:n]
@@ -621,18 +638,24 @@ class LRCNEngine:
             elif L["pool"]:
                 self._pool_bwd(L, n, dy, L["y"][:n], L["dy_halo"])
             # else: dy was written (ReluGrad fused) by the next layer's dgrad epilogue
-            if self.c8 and li > 0:
+            if self.c8 and li == 0:
+                eq = L["eq"]
+                ops.pack_c8(dy, L["dyb"][:n], L["dy_halo"], eq.dy_halo)
+                self._run(name + ".wgrad", eq.c8_wgrad, L["xb"][:n], L["dyb"][:n], L["dws2d"], self.ws)
+                conv.s2d_weights(L["dws2d"], G["dcnn/%sW" % name], grad=True)
+                ops.bias_grad_c8(L["dyb"][:n], G["dcnn/%sb" % name], sw, conv.cout, eq.dy_halo)
+                continue
+            if self.c8:
                 if L["pool"]:
                     ops.pack_c8(dy, L["dyb"][:n], L["dy_halo"], L["dy_halo"])
                 self._run(name + ".wgrad", conv.c8_wgrad, L["xb"][:n], L["dyb"][:n], G["dcnn/%sW" % name], self.ws)
-                ops.bias_grad_nchw(dy, G["dcnn/%sb" % name], sw)
+                ops.bias_grad_c8(L["dyb"][:n], G["dcnn/%sb" % name], sw, conv.cout, L["dy_halo"])
                 prev = self.layers[li - 1]
                 conv.c8_pack_w(P["dcnn/%sW" % name], L["wbt"], True)
                 if prev["pool"]:
                     self._run(name + ".dgrad", conv.c8_dgrad, L["dyb"][:n], L["wbt"], dx=prev["dp"][:n])
-                else:
-                    self._run(name + ".dgrad", conv.c8_dgrad, L["dyb"][:n], L["wbt"], dx=prev["dy"][:n], dxb=prev["dyb"][:n],
-                              relu_mask=prev["y"][:n])
+                else:      # straight into the previous conv's packed gradient; its ReluGrad reads this layer's packed input
+                    self._run(name + ".dgrad", conv.c8_dgrad, L["dyb"][:n], L["wbt"], dxb=prev["dyb"][:n], relu_mask_c8=L["xb"][:n])
                 continue
             if conv.fuses_bias():      # bias gradient comes out of the same pass over dy
                 self._run(name + ".wgrad", conv.wgrad, x_in, dy, G["dcnn/%sW" % name], self.ws, db=G["dcnn/%sb" % name])

@@ -182,15 +182,43 @@ class Conv:
             raise _ffi.VltfError("conv.c8_fwd: y shape %s" % (tuple(y.shape),))
         _ffi.call("vl_conv_c8_fwd", self._d, _p(xb), _p(wb), _p(bias), _p(y), _p(yb), n, int(relu), stream())
 
-    def c8_dgrad(self, dyb, wbt, dx=None, dxb=None, relu_mask=None):
+    def c8_dgrad(self, dyb, wbt, dx=None, dxb=None, relu_mask=None, relu_mask_c8=None):
+        """relu_mask (fp32, dx's layout) or relu_mask_c8 (this layer's packed input xb): fused ReluGrad of the producing layer."""
         n = dyb.shape[0]
+        self._c8_check(relu_mask_c8, n, self.cin, self.h, self.w, self.x_halo, "relu_mask_c8")
         _f32(dx, relu_mask); _dense(dx, relu_mask, wbt)
         self._c8_check(dyb, n, self.cout, self.oh, self.ow, self.dy_halo, "dyb")
         self._c8_check(dxb, n, self.cin, self.h, self.w, self.dx_halo, "dxb")
         for t in (dx, relu_mask):
             if t is not None and tuple(t.shape) != self._shape(n, self.cin, self.h, self.w, self.dx_halo):
                 raise _ffi.VltfError("conv.c8_dgrad: dx / relu_mask shape %s" % (tuple(t.shape),))
-        _ffi.call("vl_conv_c8_dgrad", self._d, _p(dyb), _p(wbt), _p(dx), _p(dxb), _p(relu_mask), n, stream())
+        _ffi.call("vl_conv_c8_dgrad", self._d, _p(dyb), _p(wbt), _p(dx), _p(dxb), _p(relu_mask), _p(relu_mask_c8), n, stream())
+
+    # a strided first layer as a stride-1 layer over its space-to-depth input (include/vltf.h: vl_s2d_*)
+    def s2d_layer(self):
+        """Descriptor of the equivalent stride-1 layer (halos 1 for x and dy, dense y)."""
+        s, ka = self.stride, (self.kh - 1) // self.stride + 1
+        eq = Conv(self.cin * s * s, self.oh, self.ow, self.cout, ka, ka, 1, 1)
+        eq.set_halo((ka - 1) // 2, 0, (ka - 1) // 2, 0)
+        return eq
+
+    def s2d_c8_from_x0(self, x0, xb):
+        _f32(x0); _dense(x0, xb)
+        n = x0.shape[0]
+        s, ka = self.stride, (self.kh - 1) // self.stride + 1
+        if tuple(x0.shape) != self.x_shape(n) or xb.dtype != torch.bfloat16 or \
+                tuple(xb.shape) != c8_shape(n, self.cin * s * s, self.oh, self.ow, (ka - 1) // 2):
+            raise _ffi.VltfError("conv.s2d_c8_from_x0: shape mismatch x0=%s xb=%s" % (tuple(x0.shape), tuple(xb.shape)))
+        _ffi.call("vl_s2d_c8_from_x0", self._d, _p(x0), _p(xb), n, stream())
+
+    def s2d_weights(self, src, dst, grad=False):
+        """grad=False: w [k][k][cin][cout] -> [ka][ka][cin s^2][cout]; grad=True: the stride-1 layer's dw -> dw."""
+        _f32(src, dst); _dense(src, dst)
+        s, ka = self.stride, (self.kh - 1) // self.stride + 1
+        big, small = (ka, ka, self.cin * s * s, self.cout), self.w_shape
+        if (tuple(src.shape), tuple(dst.shape)) != ((big, small) if grad else (small, big)):
+            raise _ffi.VltfError("conv.s2d_weights: shape mismatch %s -> %s" % (tuple(src.shape), tuple(dst.shape)))
+        _ffi.call("vl_s2d_weights", self._d, _p(src), _p(dst), int(grad), stream())
 
     def c8_wgrad_ws_bytes(self, n):
         return int(_ffi.lib().vl_conv_c8_wgrad_ws_bytes(self._d, n))
@@ -203,6 +231,15 @@ class Conv:
         if tuple(dw.shape) != self.w_shape:
             raise _ffi.VltfError("conv.c8_wgrad: dw shape %s" % (tuple(dw.shape),))
         _ffi.call("vl_conv_c8_wgrad", self._d, _p(xb), _p(dyb), _p(dw), _p(ws), ws.numel() * ws.element_size(), n, stream())
+
+
+def bias_grad_c8(dyb, db, ws, c, halo):
+    """db[c] = sum over images and pixels of the packed gradient dyb (c8 with `halo`)."""
+    _f32(db, ws); _dense(dyb, db, ws)
+    n, cb, hp, wp, _ = dyb.shape
+    if dyb.dtype != torch.bfloat16 or cb != (c + 7) // 8 or ws.numel() < 64 * 8 * cb:
+        raise _ffi.VltfError("bias_grad_c8: dyb must be bf16 c8 of %d channels, ws >= 64 * 8 * blocks floats" % c)
+    _ffi.call("vl_bias_grad_c8", _p(dyb), _p(db), _p(ws), n, c, hp - 2 * halo, wp - 2 * halo, halo, stream())
 
 
 def c8_shape(n, c, h, w, halo):
