@@ -140,8 +140,12 @@ int vl_bias_grad_c8(const void* dyb, float* db, float* ws, int n, int c, int h, 
  * sums, plus multiplies by zero where s a + py >= k.  The caller creates that layer's descriptor (cin s^2, oh, ow, cout, ka, ka, 1, 1;
  * x_halo = dy_halo = (ka - 1) / 2) and runs vl_conv_c8_fwd / vl_conv_c8_wgrad on it with
  *   vl_s2d_c8_from_x0   x0 (fp32, as the strided layer d's vl_conv_fwd takes it) -> packed input [n][cin s^2 / 8][oh + ka - 1][ow + ka - 1][8]
- *   vl_s2d_weights      grad = 0: w [k][k][cin][cout] -> [ka][ka][cin s^2][cout];  grad = 1: the stride-1 layer's dw -> dw */
+ *   vl_s2d_weights      grad = 0: w [k][k][cin][cout] -> [ka][ka][cin s^2][cout];  grad = 1: the stride-1 layer's dw -> dw
+ *   vl_input_prep_u8_s2d  the uint8 frames straight into that packed input (arguments as vl_input_prep_u8; the crop is d's h x w):
+ *                       the same values as vl_input_prep_u8 followed by vl_s2d_c8_from_x0 */
 int vl_s2d_c8_from_x0(const vl_conv_desc* d, const float* x0, void* xb, int n, vl_stream_t stream);
+int vl_input_prep_u8_s2d(const vl_conv_desc* d, const uint8_t* src, void* xb, int n, int raw_h, int raw_w, const int32_t* crop_y,
+                         const int32_t* crop_x, const uint8_t* mirror, const float* mean_bgr, vl_stream_t stream);
 int vl_s2d_weights(const vl_conv_desc* d, const float* src, float* dst, int grad, vl_stream_t stream);
 /* db[c] = sum_{n,h,w} dy[n][c][h][w]  (gradient of tf.nn.bias_add, alexnet.py:31).
  * ws: float[64*c] scratch. */

@@ -214,3 +214,26 @@ def test_strided_first_layer_as_a_stride1_layer(ops, n, h, w, cout, phase):
     eq.c8_wgrad(xb, to_c8(dy, 1), dws2d, torch.empty(max(eq.c8_wgrad_ws_bytes(n) // 4, 1), device=DEV))
     conv.s2d_weights(dws2d, dw, grad=True)
     close(dw.cpu().numpy(), dwo, msg="strided wgrad through space-to-depth")
+
+
+def test_frames_straight_into_the_packed_input(ops):
+    """vl_input_prep_u8_s2d == vl_input_prep_u8 followed by vl_s2d_c8_from_x0, bit for bit (crop offsets, mirror, mean)."""
+    rng = np.random.default_rng(11)
+    n, rh, rw, h, w = 5, 80, 90, 67, 71
+    frames = torch.from_numpy(rng.integers(0, 256, (n, rh, rw, 3), dtype=np.uint8)).to(DEV)
+    cy = torch.from_numpy(rng.integers(0, rh - h + 1, n).astype(np.int32)).to(DEV)
+    cx = torch.from_numpy(rng.integers(0, rw - w + 1, n).astype(np.int32)).to(DEV)
+    mir = torch.from_numpy(rng.integers(0, 2, n).astype(np.uint8)).to(DEV)
+    mean = torch.tensor([99.2, 105.3, 109.5], device=DEV)
+    conv = ops.Conv(3, h, w, 96, 11, 11, 4, 1)
+    pad = conv.same_pad()
+    conv.set_halo(pad, 0, 0, 0)
+    ph = conv.set_x_phase_split(True)
+    x0 = torch.zeros(ops.phase_split_shape(n, 3, h, w, pad, ph), device=DEV)
+    ops.input_prep_u8(frames, x0, cy, cx, mir, mean, halo=pad, phase=ph, out_hw=(h, w))
+    shape = ops.c8_shape(n, 48, conv.oh, conv.ow, 1)
+    a, b = torch.zeros(shape, dtype=torch.bfloat16, device=DEV), torch.zeros(shape, dtype=torch.bfloat16, device=DEV)
+    conv.s2d_c8_from_x0(x0, a)
+    conv.input_prep_u8_s2d(frames, b, cy, cx, mir, mean)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and float(a.float().abs().max()) > 50

@@ -39,6 +39,7 @@ SIGNATURES = {
     "vl_conv_c8_fwd": (i32, [p, p, p, p, p, p, i32, i32, p]),
     "vl_conv_c8_dgrad": (i32, [p, p, p, p, p, p, p, i32, p]),
     "vl_s2d_c8_from_x0": (i32, [p, p, p, i32, p]),
+    "vl_input_prep_u8_s2d": (i32, [p, p, p, i32, i32, i32, p, p, p, p, p]),
     "vl_s2d_weights": (i32, [p, p, p, i32, p]),
     "vl_bias_grad_c8": (i32, [p, p, p, i32, i32, i32, i32, i32, p]),
     "vl_conv_c8_wgrad_ws_bytes": (sz, [p, i32]),

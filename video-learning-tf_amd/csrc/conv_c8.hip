@@ -970,3 +970,45 @@ extern "C" int vl_s2d_weights(const vl_conv_desc* d, const float* src, float* ds
     VL_LAUNCH_CHECK();
     return 0;
 }
+
+// The TFRecord frames straight into that packed input: Dataset.process_image (dataset_.py:481-501: crop, mirror, mean) as
+// vl_input_prep_u8 does it, the fp32 difference rounded to bf16 -- identical values to vl_input_prep_u8 + vl_s2d_c8_from_x0.
+__global__ void input_prep_u8_s2d_kernel(const uint8_t* __restrict__ src, uint4* __restrict__ xb, int C, int s, int H, int W, int rh, int rw,
+                                         const int32_t* __restrict__ cy, const int32_t* __restrict__ cx, const uint8_t* __restrict__ mir,
+                                         const float* __restrict__ mean, int pt, int pl, int OHp, int OWp, int CB, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int S = (int)(idx % OWp), R = (int)((idx / OWp) % OHp), cb = (int)((idx / ((int64_t)OWp * OHp)) % CB);
+    const int n = (int)(idx / ((int64_t)OWp * OHp * CB));
+    const int oy = cy ? cy[n] : 0, ox = cx ? cx[n] : 0;
+    const bool flip = mir && mir[n];
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int cp = cb * 8 + j, px = cp % s, py = (cp / s) % s, c = cp / (s * s);
+        const int ih = s * R + py - pt, iw = s * S + px - pl;
+        float t = 0.f;
+        if (c < C && ih >= 0 && ih < H && iw >= 0 && iw < W)
+            t = (float)src[(((int64_t)n * rh + ih + oy) * rw + (flip ? W - 1 - iw : iw) + ox) * C + c] - (mean ? mean[c] : 0.f);
+        v[j] = t;
+    }
+    uint4 o;
+    o.x = pack_bf16(v[0], v[1]);
+    o.y = pack_bf16(v[2], v[3]);
+    o.z = pack_bf16(v[4], v[5]);
+    o.w = pack_bf16(v[6], v[7]);
+    xb[idx] = o;
+}
+
+extern "C" int vl_input_prep_u8_s2d(const vl_conv_desc* d, const uint8_t* src, void* xb, int n, int raw_h, int raw_w, const int32_t* crop_y,
+                                    const int32_t* crop_x, const uint8_t* mirror, const float* mean_bgr, vl_stream_t stream) {
+    VL_CHECK(src && xb && n > 0, "vl_input_prep_u8_s2d: bad argument");
+    if (int rc = s2d_check(d, "vl_input_prep_u8_s2d")) return rc;
+    VL_CHECK(d->h <= raw_h && d->w <= raw_w, "vl_input_prep_u8_s2d: bad shape");
+    const int s = d->stride, ka = (d->kh - 1) / s + 1, OHp = d->oh + ka - 1, OWp = d->ow + ka - 1, CB = (d->cin * s * s + 7) / 8;
+    const int64_t total = (int64_t)n * CB * OHp * OWp;
+    hipLaunchKernelGGL(input_prep_u8_s2d_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, (uint4*)xb, d->cin,
+                       s, d->h, d->w, raw_h, raw_w, crop_y, crop_x, mirror, mean_bgr, d->pt, d->pl, OHp, OWp, CB, total);
+    VL_LAUNCH_CHECK();
+    return 0;
+}

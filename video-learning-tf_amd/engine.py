@@ -240,6 +240,7 @@ class LRCNEngine:
         # ("c8": 8 channels of a pixel per 16-byte chunk) next to the fp32 tensors the pool / LRN / bias-gradient kernels read.
         # xb: the layer's input; dyb: the gradient its dgrad / wgrad read; wb / wbt: the packed weights (rebuilt every step).
         self.c8 = cfg.conv_math == "bf16"
+        self._xb_fed = False                          # feed_u8 wrote conv1's packed input directly
         if self.c8:
             def cbuf(c_, h_, w_, halo):
                 return torch.zeros(ops.c8_shape(N, c_, h_, w_, halo), dtype=torch.bfloat16, device=dev)
@@ -431,6 +432,10 @@ class LRCNEngine:
         if mean_bgr is not None:
             self.mean_dev.copy_(torch.as_tensor(np.asarray(mean_bgr, np.float32)), non_blocking=True)
             mean = self.mean_dev
+        if self.c8:     # bf16 path: the frames go straight into conv1's packed (space-to-depth) input; x0 is not written
+            self.layers[0]["conv"].input_prep_u8_s2d(frames_u8, self.layers[0]["xb"][:n], crop_y, crop_x, mirror, mean)
+            self._xb_fed = True
+            return n, b
         ops.input_prep_u8(frames_u8, self.x0[:n], crop_y, crop_x, mirror, mean, halo=self.x0_halo, phase=self.x0_phase,
                           out_hw=self.cfg.image_shape[:2])
         return n, b
@@ -440,6 +445,7 @@ class LRCNEngine:
         n = frames.shape[0]
         b = self._check_frames(n)
         ops.nhwc_to_nchw(frames, self.x0[:n], halo=self.x0_halo, phase=self.x0_phase)
+        self._xb_fed = False
         return n, b
 
     # ---- forward -------------------------------------------------------------------------------
@@ -452,7 +458,8 @@ class LRCNEngine:
             nxt = self.layers[li + 1] if li + 1 < len(self.layers) else None
             if self.c8 and li == 0:
                 conv = L["conv"]
-                conv.s2d_c8_from_x0(x, L["xb"][:n])
+                if not self._xb_fed:                      # fed as fp32 frames (feed_f32_nhwc): pack x0
+                    conv.s2d_c8_from_x0(x, L["xb"][:n])
                 conv.s2d_weights(P["dcnn/%sW" % name], L["ws2d"])
                 L["eq"].c8_pack_w(L["ws2d"], L["wb"], False)
                 self._run(name + ".fwd", L["eq"].c8_fwd, L["xb"][:n], L["wb"], P["dcnn/%sb" % name], y=L["y"][:n], relu=True)

@@ -211,6 +211,21 @@ class Conv:
             raise _ffi.VltfError("conv.s2d_c8_from_x0: shape mismatch x0=%s xb=%s" % (tuple(x0.shape), tuple(xb.shape)))
         _ffi.call("vl_s2d_c8_from_x0", self._d, _p(x0), _p(xb), n, stream())
 
+    def input_prep_u8_s2d(self, src, xb, crop_y=None, crop_x=None, mirror=None, mean_bgr=None):
+        """uint8 frames [n, raw_h, raw_w, 3] -> the packed space-to-depth input (= input_prep_u8 + s2d_c8_from_x0)."""
+        if src.dtype != torch.uint8 or not src.is_cuda or src.dim() != 4 or src.shape[3] != self.cin:
+            raise _ffi.VltfError("conv.input_prep_u8_s2d: src must be a device uint8 [n, h, w, %d] tensor" % self.cin)
+        _f32(mean_bgr); _dense(src, xb, mean_bgr)
+        n = src.shape[0]
+        s, ka = self.stride, (self.kh - 1) // self.stride + 1
+        if xb.dtype != torch.bfloat16 or tuple(xb.shape) != c8_shape(n, self.cin * s * s, self.oh, self.ow, (ka - 1) // 2):
+            raise _ffi.VltfError("conv.input_prep_u8_s2d: xb shape %s" % (tuple(xb.shape),))
+        for t, dt in ((crop_y, torch.int32), (crop_x, torch.int32), (mirror, torch.uint8)):
+            if t is not None and (t.dtype != dt or t.numel() < n or not t.is_contiguous()):
+                raise _ffi.VltfError("conv.input_prep_u8_s2d: crop / mirror must be contiguous int32 / uint8 tensors of n entries")
+        _ffi.call("vl_input_prep_u8_s2d", self._d, _p(src), _p(xb), n, src.shape[1], src.shape[2], _p(crop_y), _p(crop_x), _p(mirror),
+                  _p(mean_bgr), stream())
+
     def s2d_weights(self, src, dst, grad=False):
         """grad=False: w [k][k][cin][cout] -> [ka][ka][cin s^2][cout]; grad=True: the stride-1 layer's dw -> dw."""
         _f32(src, dst); _dense(src, dst)
