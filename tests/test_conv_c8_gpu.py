@@ -237,3 +237,47 @@ def test_frames_straight_into_the_packed_input(ops):
     conv.input_prep_u8_s2d(frames, b, cy, cx, mir, mean)
     torch.cuda.synchronize()
     assert torch.equal(a, b) and float(a.float().abs().max()) > 50
+
+
+@pytest.mark.parametrize("n,h,w,c,halo", [(2, 9, 7, 96, 1), (3, 13, 13, 256, 2), (2, 27, 27, 16, 1), (1, 55, 55, 96, 1)])
+@pytest.mark.parametrize("relu", [True, False])
+def test_pool_lrn_bwd_packed_output(ops, n, h, w, c, halo, relu):
+    """vl_pool_lrn_bwd_c8 = vl_pool_lrn_bwd with the result rounded to bf16 into the c8 layout (same arithmetic before the rounding)."""
+    rng = np.random.default_rng(c + h)
+    x = torch.from_numpy(np.maximum(rng.standard_normal((n, c, h, w)) * 30, 0).astype(np.float32)).to(DEV)
+    oh, ow = ops.pool_out(h), ops.pool_out(w)
+    p = torch.zeros((n, c, oh + 2, ow + 2), device=DEV)
+    arg = torch.zeros((n, c, oh + 2, ow + 2), dtype=torch.uint8, device=DEV)
+    ops.lrn_pool_fwd(x, p, arg, p_halo=1)
+    dp = torch.zeros_like(p)
+    dp[:, :, 1:-1, 1:-1] = torch.from_numpy(rng.standard_normal((n, c, oh, ow)).astype(np.float32)).to(DEV)
+    dx = torch.zeros((n, c, h + 2 * halo, w + 2 * halo), device=DEV)
+    ops.pool_lrn_bwd(x, dp, arg, dx, p_halo=1, dx_halo=halo, relu_fused=relu)
+    dxb = torch.zeros(ops.c8_shape(n, c, h, w, halo), dtype=torch.bfloat16, device=DEV)
+    ops.pool_lrn_bwd_c8(x, dp, arg, dxb, p_halo=1, dxb_halo=halo, relu_fused=relu)
+    want = torch.zeros_like(dxb)
+    ops.pack_c8(dx, want, halo, halo)
+    torch.cuda.synchronize()
+    # the two instantiations (5- and 8-channel chunks) may contract an fma differently: the last fp32 bit, hence now and then the
+    # bf16 rounding, can differ -- every element within one bf16 ulp of the fp32 kernel's, all but a handful identical
+    a, b = dxb.float(), want.float()
+    assert float((a - b).abs().max()) <= 2.0 ** -7 * float(b.abs().max())
+    assert torch.all((a - b).abs() <= 2.0 ** -7 * b.abs() + 1e-30)
+    assert float((a != b).float().mean()) < 1e-3 and float(a.abs().max()) > 0
+
+
+@pytest.mark.parametrize("n,h,w,c,halo", [(2, 9, 7, 96, 1), (3, 13, 13, 256, 2), (1, 55, 55, 96, 2)])
+def test_lrn_pool_fwd_packed_output(ops, n, h, w, c, halo):
+    """vl_lrn_pool_fwd_c8 = vl_lrn_pool_fwd with the pooled output rounded to bf16 into the c8 layout; same arg-max map."""
+    rng = np.random.default_rng(c + w)
+    x = torch.from_numpy(np.maximum(rng.standard_normal((n, c, h, w)) * 30, 0).astype(np.float32)).to(DEV)
+    oh, ow = ops.pool_out(h), ops.pool_out(w)
+    p = torch.zeros((n, c, oh + 2 * halo, ow + 2 * halo), device=DEV)
+    arg, arg2 = torch.zeros(p.shape, dtype=torch.uint8, device=DEV), torch.zeros(p.shape, dtype=torch.uint8, device=DEV)
+    ops.lrn_pool_fwd(x, p, arg, p_halo=halo)
+    pb = torch.zeros(ops.c8_shape(n, c, oh, ow, halo), dtype=torch.bfloat16, device=DEV)
+    ops.lrn_pool_fwd_c8(x, pb, arg2, p_halo=halo)
+    want = torch.zeros_like(pb)
+    ops.pack_c8(p, want, halo, halo)
+    torch.cuda.synchronize()
+    assert torch.equal(pb, want) and torch.equal(arg, arg2) and float(pb.float().abs().max()) > 0

@@ -309,7 +309,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t pw_rsrc(const void* base, int6
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)(uint32_t)bytes, 0x00020000);
 }
 
-template <int CHK, int NST, bool RELU>
+// C8: dx is the packed-bf16 "c8" gradient [image][C / 8][H + 2 halo][W + 2 halo][8] (conv_c8.hip) instead of fp32 NCHW.  The chunk is
+// then 8 channels starting at a multiple of 8: its outputs are channels c0 - 4 .. c0 + 3, i.e. the upper half of one 16-byte chunk and
+// the lower half of the next, each stored as ONE 8-byte word per pixel (4 bf16, rounded to nearest even).
+template <int CHK, int NST, bool RELU, bool C8 = false>
 __global__ __launch_bounds__(256) void pool_lrn_bwd_stream_kernel(const float* __restrict__ x, const float* __restrict__ dp,
                                                                   const uint8_t* __restrict__ arg, float* __restrict__ dx, int C,
                                                                   int H, int W, int OH, int OW, int64_t ps_n, int ps_c, int ps_h,
@@ -360,11 +363,14 @@ __global__ __launch_bounds__(256) void pool_lrn_bwd_stream_kernel(const float* _
     const __amdgpu_buffer_rsrc_t rs_x = pw_rsrc(x + (int64_t)img * C * HW, (int64_t)C * HW * 4);
     const int wp = W + 2 * halo;
     const int dplane = (H + 2 * halo) * wp;
-    const __amdgpu_buffer_rsrc_t rs_dx = pw_rsrc(dx + (int64_t)img * C * dplane, (int64_t)C * dplane * 4);
+    static_assert(!C8 || CHK == 8, "packed output: 8-channel chunks");
+    const int CB = (C + 7) / 8;
+    const __amdgpu_buffer_rsrc_t rs_dx = C8 ? pw_rsrc(reinterpret_cast<const char*>(dx) + (int64_t)img * CB * dplane * 16, (int64_t)CB * dplane * 16)
+                                            : pw_rsrc(dx + (int64_t)img * C * dplane, (int64_t)C * dplane * 4);
     const __amdgpu_buffer_rsrc_t rs_dp = pw_rsrc(dp + (int64_t)img * ps_n, pooled_bytes_f);
     const __amdgpu_buffer_rsrc_t rs_arg = pw_rsrc(arg + (int64_t)img * ps_n, pooled_bytes_f / 4);
     const uint32_t voff_x = valid ? (uint32_t)p * 4u : PW_OOB;
-    const uint32_t voff_dx = valid ? (uint32_t)((py + halo) * wp + px + halo) * 4u : PW_OOB;
+    const uint32_t voff_dx = valid ? (uint32_t)((py + halo) * wp + px + halo) * (C8 ? 16u : 4u) : PW_OOB;
     const int x_cs = HW * 4, dx_cs = dplane * 4;                      // channel strides in bytes
 
     float dpv[NST];
@@ -402,6 +408,7 @@ __global__ __launch_bounds__(256) void pool_lrn_bwd_stream_kernel(const float* _
     auto chunk = [&](int c0, int buf, const float (&xin)[CHK]) {
         const uint32_t b0 = (uint32_t)(buf * BUF) * 8u;
         uint32_t a0 = b0 + rowaddr[0], a1 = b0 + rowaddr[1];
+        float rr[4];
 #pragma unroll
         for (int i = 0; i < CHK; ++i) {
             const int cc = c0 + i;
@@ -429,8 +436,22 @@ __global__ __launch_bounds__(256) void pool_lrn_bwd_stream_kernel(const float* _
             a += tw0; a += tw1; a += tw2; a += tw3; a += tw4;
             float r = uw0 - k2ab * xw0 * a;
             if (RELU) r = xw0 > 0.f ? r : 0.f;
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, r), rs_dx, (int)((oc >= 0 && oc < C) ? voff_dx : PW_OOB),
-                                                  oc * dx_cs, 0);
+            if constexpr (C8) {
+                rr[i & 3] = r;
+                if ((i & 3) == 3) {                                   // channels oc - 3 .. oc: half a chunk of block (oc - 3) >> 3
+                    typedef float f2 __attribute__((ext_vector_type(2)));
+                    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+                    typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+                    const u2 w = {__builtin_bit_cast(uint32_t, __builtin_convertvector(f2{rr[0], rr[1]}, b2)),
+                                  __builtin_bit_cast(uint32_t, __builtin_convertvector(f2{rr[2], rr[3]}, b2))};
+                    const int blk = (oc - 3) >> 3;                    // uniform; outside [0, CB): dropped by the range check
+                    __builtin_amdgcn_raw_buffer_store_b64(w, rs_dx, (int)((oc - 3 >= 0 && blk < CB) ? voff_dx + (((oc - 3) & 7) * 2) : PW_OOB),
+                                                          blk * dplane * 16, 0);
+                }
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, r), rs_dx, (int)((oc >= 0 && oc < C) ? voff_dx : PW_OOB),
+                                                      oc * dx_cs, 0);
+            }
         }
     };
 
@@ -505,6 +526,34 @@ extern "C" int vl_pool_lrn_bwd(const float* x, const float* dp, const uint8_t* a
     return 0;
 }
 
+/* vl_pool_lrn_bwd writing the packed-bf16 gradient dxb ("c8" layout of conv_c8.hip, dxb_halo) instead of fp32 dx: what the bf16 conv
+ * path's wgrad / dgrad / bias gradient read.  Channel-stream form only (beta 0.75, planes that fit its staging). */
+extern "C" int vl_pool_lrn_bwd_c8(const float* x, const float* dp, const uint8_t* argmax, void* dxb, int n, int c, int h, int w, int p_halo,
+                                  int radius, float alpha, float beta, float bias, int relu_fused, int dxb_halo, vl_stream_t stream) {
+    VL_CHECK(x && dp && argmax && dxb && n > 0 && c > 0 && h >= 3 && w >= 3 && p_halo >= 0 && dxb_halo >= 0, "vl_pool_lrn_bwd_c8: bad argument");
+    VL_CHECK(radius == 2 && beta == 0.75f, "vl_pool_lrn_bwd_c8: only depth_radius 2, beta 0.75 are built (alexnet.py:81-84)");
+    VL_CHECK(n <= 65535, "vl_pool_lrn_bwd_c8: batch %d exceeds the grid limit", n);
+    const int oh = (h - 3) / 2 + 1, ow = (w - 3) / 2 + 1;
+    const int owp = ow + 2 * p_halo;
+    const int64_t pplane = (int64_t)(oh + 2 * p_halo) * owp;
+    const int64_t origin = (int64_t)p_halo * owp + p_halo;
+    const int rows = (255 + w - 1) / w + 1, max_prow = rows / 2 + 2;
+    const int64_t bytes_x = (int64_t)(c + 24) * h * w * 4, bytes_dx = (int64_t)((c + 7) / 8 + 3) * (h + 2 * dxb_halo) * (w + 2 * dxb_halo) * 16;
+    const int64_t pooled_f = ((int64_t)c * pplane - origin) * 4;
+    VL_CHECK(bytes_x < (1ll << 31) && bytes_dx < (1ll << 31) && pooled_f < (1ll << 31) && pplane < (1 << 24) && (int64_t)8 * max_prow * ow <= 5 * 256,
+             "vl_pool_lrn_bwd_c8: plane too large for the channel-stream form");
+    const dim3 grid(ceil_div((int64_t)h * w, 256), n);
+    const int64_t psn = (int64_t)c * pplane;
+    if (relu_fused)
+        hipLaunchKernelGGL((pool_lrn_bwd_stream_kernel<8, 5, true, true>), grid, dim3(256), 0, (hipStream_t)stream, x, dp + origin, argmax + origin,
+                           (float*)dxb, c, h, w, oh, ow, psn, (int)pplane, owp, pooled_f, alpha, bias, dxb_halo);
+    else
+        hipLaunchKernelGGL((pool_lrn_bwd_stream_kernel<8, 5, false, true>), grid, dim3(256), 0, (hipStream_t)stream, x, dp + origin, argmax + origin,
+                           (float*)dxb, c, h, w, oh, ow, psn, (int)pplane, owp, pooled_f, alpha, bias, dxb_halo);
+    VL_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int vl_lrn_fwd(const float* x, float* y, int n, int c, int hw, int radius, float alpha, float beta, float bias,
                           vl_stream_t stream) {
     VL_CHECK(x && y && n > 0 && c > 0 && hw > 0, "vl_lrn_fwd: bad argument");
@@ -537,7 +586,9 @@ extern "C" int vl_lrn_bwd(const float* x, const float* dy, float* dx, int n, int
 // the next chunk's loads in flight behind the current chunk's math.  Each chunk of CHK LRN outputs goes to LDS (two buffers,
 // one barrier per chunk); the chunk's pooled outputs (<= NSL per thread, their window origins decoded once) take the
 // strict-> first maximum of 9 LDS reads, exactly vl_maxpool_fwd's scan order, and are stored in the pool-output halo layout.
-template <int CHK, int PPT, int NSL>
+// C8: pout is the packed-bf16 "c8" tensor [image][C / 8][pooled plane][8] (conv_c8.hip) instead of fp32 NCHW: each pooled output is
+// stored as one bf16 (nearest even) at its channel's slot of the pixel's chunk; the arg-max map is unchanged.
+template <int CHK, int PPT, int NSL, bool C8 = false>
 __global__ __launch_bounds__(512) void lrn_pool_fwd_kernel(const float* __restrict__ x, float* __restrict__ pout,
                                                            uint8_t* __restrict__ argout, int C, int H, int W, int OH, int OW, int prb,
                                                            int pplane, int owp, int p_halo, float alpha, float bias) {
@@ -550,7 +601,9 @@ __global__ __launch_bounds__(512) void lrn_pool_fwd_kernel(const float* __restri
     const int p_base = 2 * oh_a * W;
     const int HW = H * W;
     const __amdgpu_buffer_rsrc_t rs_x = pw_rsrc(x + (int64_t)img * C * HW, (int64_t)C * HW * 4);
-    const __amdgpu_buffer_rsrc_t rs_p = pw_rsrc(pout + (int64_t)img * C * pplane, (int64_t)C * pplane * 4);
+    const int CB = (C + 7) / 8;
+    const __amdgpu_buffer_rsrc_t rs_p = C8 ? pw_rsrc(reinterpret_cast<const char*>(pout) + (int64_t)img * CB * pplane * 16, (int64_t)CB * pplane * 16)
+                                           : pw_rsrc(pout + (int64_t)img * C * pplane, (int64_t)C * pplane * 4);
     const __amdgpu_buffer_rsrc_t rs_a = pw_rsrc(argout + (int64_t)img * C * pplane, (int64_t)C * pplane);
     uint32_t voff_x[PPT];
     int lpix[PPT];                                                    // band-local pixel, -1 = none
@@ -625,7 +678,13 @@ __global__ __launch_bounds__(512) void lrn_pool_fwd_kernel(const float* __restri
                         }
                     }
                 const int off = c * pplane + (s_out[sl] & 0xffffff);
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, best), rs_p, off * 4, 0, 0);
+                if constexpr (C8) {
+                    const __bf16 hb = (__bf16)best;
+                    __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(uint16_t, hb), rs_p,
+                                                          ((c >> 3) * pplane + (s_out[sl] & 0xffffff)) * 16 + (c & 7) * 2, 0, 0);
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, best), rs_p, off * 4, 0, 0);
+                }
                 __builtin_amdgcn_raw_buffer_store_b8((uint8_t)bi, rs_a, off, 0, 0);
             }
         }
@@ -641,7 +700,7 @@ __global__ __launch_bounds__(512) void lrn_pool_fwd_kernel(const float* __restri
     }
 }
 
-template <int CHK, int PPT, int NSL>
+template <int CHK, int PPT, int NSL, bool C8 = false>
 static int launch_lrn_pool_fwd(const float* x, float* p, uint8_t* argmax, int n, int c, int h, int w, int p_halo, float alpha, float bias,
                                hipStream_t stream) {
     const int oh = (h - 3) / 2 + 1, ow = (w - 3) / 2 + 1;
@@ -669,7 +728,7 @@ static int launch_lrn_pool_fwd(const float* x, float* p, uint8_t* argmax, int n,
     }
     const size_t lds = (size_t)2 * CHK * (2 * prb + 1) * w * sizeof(float);
     if (getenv("VL_LRN_POOL_VERBOSE")) fprintf(stderr, "lrn_pool_fwd<%d,%d,%d>: bands %d prb %d threads %d lds %zu\n", CHK, PPT, NSL, bands, prb, threads, lds);
-    hipLaunchKernelGGL((lrn_pool_fwd_kernel<CHK, PPT, NSL>), dim3(bands, n), dim3(threads), lds, stream, x, p, argmax, c, h,
+    hipLaunchKernelGGL((lrn_pool_fwd_kernel<CHK, PPT, NSL, C8>), dim3(bands, n), dim3(threads), lds, stream, x, p, argmax, c, h,
                        w, oh, ow, prb, (int)pplane, owp, p_halo, alpha, bias);
     VL_LAUNCH_CHECK();
     return 0;
@@ -693,6 +752,20 @@ extern "C" int vl_lrn_pool_fwd(const float* x, float* p, uint8_t* argmax, int n,
     hipStream_t s = (hipStream_t)stream;
     if (r1) return launch_lrn_pool_fwd<8, 3, 6>(x, p, argmax, n, c, h, w, p_halo, alpha, bias, s);
     return launch_lrn_pool_fwd<2, 2, 1>(x, p, argmax, n, c, h, w, p_halo, alpha, bias, s);
+}
+
+/* vl_lrn_pool_fwd with the pooled output written as packed bf16 (pb: "c8" layout of the bf16 conv path, p_halo; nearest even) instead of
+ * fp32 p -- the next conv's operand; argmax keeps the fp32 form's NCHW layout with p_halo. */
+extern "C" int vl_lrn_pool_fwd_c8(const float* x, void* pb, uint8_t* argmax, int n, int c, int h, int w, int p_halo, int radius, float alpha,
+                                  float beta, float bias, vl_stream_t stream) {
+    VL_CHECK(x && pb && argmax && n > 0 && c > 0 && h >= 3 && w >= 3 && p_halo >= 0, "vl_lrn_pool_fwd_c8: bad argument");
+    VL_CHECK(radius == 2 && beta == 0.75f, "vl_lrn_pool_fwd_c8: only depth_radius 2, beta 0.75 are built (alexnet.py:81-84)");
+    VL_CHECK(n <= 65535, "vl_lrn_pool_fwd_c8: batch %d exceeds the grid limit", n);
+    const int oh = (h - 3) / 2 + 1, ow = (w - 3) / 2 + 1;
+    const int64_t pplane = (int64_t)(oh + 2 * p_halo) * (ow + 2 * p_halo);
+    VL_CHECK((int64_t)(c + 16) * h * w * 4 < (1ll << 31) && (int64_t)((c + 7) / 8) * pplane * 16 < (1ll << 31) && pplane < (1 << 24),
+             "vl_lrn_pool_fwd_c8: image too large for 32-bit buffer offsets");
+    return launch_lrn_pool_fwd<2, 2, 1, true>(x, (float*)pb, argmax, n, c, h, w, p_halo, alpha, bias, (hipStream_t)stream);
 }
 
 // ---- max-pool VALID (alexnet.py:91-98) --------------------------------------------------------

@@ -472,14 +472,18 @@ class LRCNEngine:
             else:
                 self._run(name + ".fwd", L["conv"].fwd, x, P["dcnn/%sW" % name], P["dcnn/%sb" % name], L["y"][:n], relu=True)
             x = L["y"][:n]
-            if L["lrn"] and L["pool"]:
+            if L["lrn"] and L["pool"] and self.c8:
+                # bf16 path: the pooled output is only ever the next conv's packed operand -- written packed, fp32 p stays unused
+                ops.lrn_pool_fwd_c8(x, nxt["xb"][:n], L["arg"][:n], p_halo=L["p_halo"], **LRN)
+                x = None
+            elif L["lrn"] and L["pool"]:
                 # LRN + pool in one pass: the LRN output is only ever the pool's input and is never stored
                 ops.lrn_pool_fwd(x, L["p"][:n], L["arg"][:n], p_halo=L["p_halo"], **LRN)
                 x = L["p"][:n]
             elif L["pool"]:
                 ops.maxpool_fwd(x, L["p"][:n], L["arg"][:n], hwc=L["hwc"], y_halo=L["p_halo"])
                 x = L["p"][:n]
-            if self.c8 and L["pool"] and nxt is not None:
+            if self.c8 and L["pool"] and not L["lrn"] and nxt is not None:
                 ops.pack_c8(x, nxt["xb"][:n], L["p_halo"], nxt["x_halo"])
         ops.gemm(x, P["dcnn/fc6W"], self.f6, n, FC_DIM, self.flat_dim, bias=P["dcnn/fc6b"], relu=True, ws=self.ws)
         if self.f7 is not None:
@@ -638,7 +642,11 @@ class LRCNEngine:
             name, conv = L["name"], L["conv"]
             x_in = self.layers[li - 1]["out"][:n] if li > 0 else self.x0[:n]
             dy = L["dy"][:n]
-            if L["pool"] and L["lrn"]:
+            if L["pool"] and L["lrn"] and self.c8:
+                # bf16 path: the gradient is only ever read packed (wgrad, dgrad, bias gradient) -- written packed, fp32 dy stays unused
+                ops.pool_lrn_bwd_c8(L["y"][:n], L["dp"][:n], L["arg"][:n], L["dyb"][:n], p_halo=L["p_halo"],
+                                    dxb_halo=(L["eq"].dy_halo if li == 0 else L["dy_halo"]), relu_fused=True, **LRN)
+            elif L["pool"] and L["lrn"]:
                 # pool -> LRN -> ReLU backward in one pass: d(lrn out) is never written
                 ops.pool_lrn_bwd(L["y"][:n], L["dp"][:n], L["arg"][:n], dy, p_halo=L["p_halo"], dx_halo=L["dy_halo"],
                                  relu_fused=True, **LRN)
@@ -647,13 +655,12 @@ class LRCNEngine:
             # else: dy was written (ReluGrad fused) by the next layer's dgrad epilogue
             if self.c8 and li == 0:
                 eq = L["eq"]
-                ops.pack_c8(dy, L["dyb"][:n], L["dy_halo"], eq.dy_halo)
                 self._run(name + ".wgrad", eq.c8_wgrad, L["xb"][:n], L["dyb"][:n], L["dws2d"], self.ws)
                 conv.s2d_weights(L["dws2d"], G["dcnn/%sW" % name], grad=True)
                 ops.bias_grad_c8(L["dyb"][:n], G["dcnn/%sb" % name], sw, conv.cout, eq.dy_halo)
                 continue
             if self.c8:
-                if L["pool"]:
+                if L["pool"] and not L["lrn"]:
                     ops.pack_c8(dy, L["dyb"][:n], L["dy_halo"], L["dy_halo"])
                 self._run(name + ".wgrad", conv.c8_wgrad, L["xb"][:n], L["dyb"][:n], G["dcnn/%sW" % name], self.ws)
                 ops.bias_grad_c8(L["dyb"][:n], G["dcnn/%sb" % name], sw, conv.cout, L["dy_halo"])
