@@ -96,6 +96,12 @@ extern "C" int vl_pack_c8(const float* x, void* xb, int n, int c, int h, int w, 
 
 // ---- reduction taps and packed weights -------------------------------------------------------------------------------------
 static constexpr int KT = 4;   // taps (32 reduction positions = two MFMA steps) per pipeline stage of conv_c8_kernel
+#ifndef C8_NBUF
+#define C8_NBUF 0     // 0: by tile (C8Cfg)
+#endif
+#ifndef C8_WG_NBUF
+#define C8_WG_NBUF 3
+#endif
 
 // taps of one group: t = (cb * kh + ky) * kw + kx over the group's cbg channel blocks, padded to a multiple of KT
 static int c8_taps(int cg, int kh, int kw) { return ((cg + 7) / 8) * kh * kw; }
@@ -184,18 +190,22 @@ struct C8ConvArgs {
 template <int WP, int WQ, int TP, int TQ>
 struct C8Cfg {
     static constexpr int NW = WP * WQ, NT = 64 * NW, P = 32 * WP * TP, Q = 32 * WQ * TQ;
-    static constexpr int NBUF = NW == 4 ? 3 : 4;                           // 4-wave tiles: 60-72 KB of LDS, two workgroups per CU
     static constexpr int QF = (Q + 63) / 64 * 64;                          // channels fetched per tap: whole 64-lane fetches (96 -> 128)
     static constexpr int PIX_BYTES = KT * P * 16, W_BYTES = KT * QF * 16, SLOT = PIX_BYTES + W_BYTES;
+    // ring depth: 3 stages where that lets TWO workgroups share a CU's 160 KB (measured: conv3 forward 0.42 -> 0.32 ms, one
+    // workgroup's prologue / epilogue behind the other's loop), else 4
+    static constexpr int NBUF = C8_NBUF ? C8_NBUF : (3 * SLOT <= 80 * 1024 ? 3 : 4);
     static constexpr int NPI = KT * P / 64, NWI = KT * QF / 64;            // 1 KB fetches per stage: pixels, weights
     static constexpr int FP = (NPI + NW - 1) / NW, FW = (NWI + NW - 1) / NW, F = FP + FW;
     static constexpr int STG = 32 * TQ * 36;                               // floats per wave of the wide-store staging ([channel][32 pixels + 4])
-    static constexpr size_t LDS_BYTES = (size_t)NBUF * SLOT > (size_t)NW * STG * 4 ? (size_t)NBUF * SLOT : (size_t)NW * STG * 4;
+    static constexpr int RING_BYTES = NBUF * SLOT > NW * STG * 4 ? NBUF * SLOT : NW * STG * 4;   // ring, later the staging
+    static constexpr size_t LDS_BYTES = (size_t)RING_BYTES + QF * 4;                       // + the tile's bias vector
+    static constexpr int WPS = (2 * LDS_BYTES <= 160 * 1024 ? 2 : 1) * NW / 4;             // waves per SIMD the registers must allow
     static_assert(P % 64 == 0, "whole 64-lane fetches");
 };
 
 template <int WP, int WQ, int TP, int TQ>
-__global__ __launch_bounds__(64 * WP * WQ) void conv_c8_kernel(const C8ConvArgs a, int tiles_q) {
+__global__ __launch_bounds__(64 * WP * WQ, (C8Cfg<WP, WQ, TP, TQ>::WPS)) void conv_c8_kernel(const C8ConvArgs a, int tiles_q) {
     using C = C8Cfg<WP, WQ, TP, TQ>;
     constexpr int NW = C::NW, P = C::P, Q = C::Q, QF = C::QF, NBUF = C::NBUF, SLOT = C::SLOT, FP = C::FP, FW = C::FW, F = C::F;
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -236,12 +246,26 @@ __global__ __launch_bounds__(64 * WP * WQ) void conv_c8_kernel(const C8ConvArgs 
         lds_w[j] = C::PIX_BYTES + tap * QF * 16 + qc * 1024;
     }
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;   // LDS byte address of the ring
+    // the tile's bias vector -> LDS (read back in the epilogue: a global load between two stores would make the wave wait for every
+    // store in flight, one counter orders both); visible after the loop's first barrier
+    float* bias_l = reinterpret_cast<float*>(lds + C::RING_BYTES);
+    if ((int)threadIdx.x < QF) {
+        const int cg = q0 + threadIdx.x;
+        bias_l[threadIdx.x] = (a.bias && cg < a.Cog) ? a.bias[g * a.Cog + cg] : 0.f;
+    }
+    // the tap offsets of the NEXT stage to be issued are fetched (scalar loads) one stage ahead: read at the point of use, each
+    // would put a scalar-memory round trip between the barrier and the fetch it feeds (the table has KT spare entries)
+    int toff_next[FP];
+#pragma unroll
+    for (int j = 0; j < FP; ++j) toff_next[j] = as_const(a.toff)[tap_p[j]];
     auto issue = [&](int st) {
         const uint32_t slot = lds0 + (uint32_t)(st % NBUF) * SLOT;
 #pragma unroll
-        for (int j = 0; j < FP; ++j) lds_dma16(rs_x, slot + lds_p[j], voff_p[j], as_const(a.toff)[st * KT + tap_p[j]]);
+        for (int j = 0; j < FP; ++j) lds_dma16(rs_x, slot + lds_p[j], voff_p[j], toff_next[j]);
 #pragma unroll
         for (int j = 0; j < FW; ++j) lds_dma16(rs_w, slot + lds_w[j], voff_w[j], (st * KT + tap_w[j]) * a.CoP * 16);
+#pragma unroll
+        for (int j = 0; j < FP; ++j) toff_next[j] = as_const(a.toff)[(st + 1) * KT + tap_p[j]];
     };
 
     f32x16 acc[TQ][TP];
@@ -297,21 +321,35 @@ __global__ __launch_bounds__(64 * WP * WQ) void conv_c8_kernel(const C8ConvArgs 
             const int64_t ypix = (int64_t)(oh + a.y_halo) * a.y_w + ow + a.y_halo;
             const int64_t ybpix = (int64_t)(oh + a.yb_halo) * a.yb_row + (int64_t)(ow + a.yb_halo) * 16 + 8 * (lane >> 5);
             const int64_t mbpix = (int64_t)(oh + a.mb_halo) * a.mb_row + (int64_t)(ow + a.mb_halo) * 16 + 8 * (lane >> 5);
+            // packed ReluGrad masks: the 4 words of channel block j + 1 are requested before the stores of block j go out
+            uint2 mkn[4];
+            auto load_masks = [&](int j) {
+#pragma unroll
+                for (int qg = 0; qg < 4; ++qg) {
+                    const int cog0 = q0 + (wq * TQ + j) * 32 + 8 * qg;
+                    mkn[qg] = uint2{0x3f803f80u, 0x3f803f80u};
+                    if (a.maskb && cog0 < a.Cog)
+                        mkn[qg] = *reinterpret_cast<const uint2*>(a.maskb + ((int64_t)n * a.yb_cb + (g * a.Cog + cog0) / 8) * a.mb_plane + mbpix);
+                }
+            };
+            load_masks(0);
 #pragma unroll
             for (int j = 0; j < TQ; ++j) {
+                uint2 mkc[4];
+#pragma unroll
+                for (int qg = 0; qg < 4; ++qg) mkc[qg] = mkn[qg];
+                if (j + 1 < TQ) load_masks(j + 1);
 #pragma unroll
                 for (int qg = 0; qg < 4; ++qg) {
                     const int cog0 = q0 + (wq * TQ + j) * 32 + 8 * qg;   // first channel (within the group) of this 8-channel block
                     if (cog0 >= a.Cog) continue;
                     const int c0 = g * a.Cog + cog0 + 4 * (lane >> 5);   // this lane's 4 channels: c0 .. c0 + 3
                     float v[4];
-                    uint2 mk = {0x3f803f80u, 0x3f803f80u};
-                    if (a.maskb)
-                        mk = *reinterpret_cast<const uint2*>(a.maskb + ((int64_t)n * a.yb_cb + (g * a.Cog + cog0) / 8) * a.mb_plane + mbpix);
+                    const f32x4 bq = *reinterpret_cast<const f32x4*>(bias_l + (wq * TQ + j) * 32 + 8 * qg + 4 * (lane >> 5));
+                    const uint2 mk = mkc[qg];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        v[e] = acc[j][i][qg * 4 + e];
-                        if (a.bias) v[e] += a.bias[c0 + e];
+                        v[e] = acc[j][i][qg * 4 + e] + bq[e];
                         if (a.relu) v[e] = fmaxf(v[e], 0.f);
                         if (a.mask) v[e] = a.mask[((int64_t)n * a.Ctot + c0 + e) * a.y_plane + ypix] > 0.f ? v[e] : 0.f;
                         const uint32_t mw = e < 2 ? mk.x : mk.y;
@@ -358,14 +396,15 @@ __global__ __launch_bounds__(64 * WP * WQ) void conv_c8_kernel(const C8ConvArgs 
 
 static int* upload_taps(int cg, int kh, int kw, int Hp, int Wp, int row_shift, int col_shift) {
     const int nt = c8_taps(cg, kh, kw), ntp = c8_taps_padded(cg, kh, kw);
-    int* h = (int*)calloc(ntp, sizeof(int));
+    int* h = (int*)calloc(ntp + KT, sizeof(int));     // + KT: conv_c8_kernel reads one stage past the last (prefetch)
     if (!h) return nullptr;
     for (int t = 0; t < nt; ++t) {
         const int kx = t % kw, ky = (t / kw) % kh, cb = t / (kw * kh);
         h[t] = (((cb * Hp) + ky + row_shift) * Wp + kx + col_shift) * 16;
     }
     int* dev = nullptr;
-    if (hipMalloc((void**)&dev, sizeof(int) * ntp) != hipSuccess || hipMemcpy(dev, h, sizeof(int) * ntp, hipMemcpyHostToDevice) != hipSuccess) {
+    if (hipMalloc((void**)&dev, sizeof(int) * (ntp + KT)) != hipSuccess ||
+        hipMemcpy(dev, h, sizeof(int) * (ntp + KT), hipMemcpyHostToDevice) != hipSuccess) {
         free(h);
         return nullptr;
     }
@@ -546,7 +585,7 @@ __device__ __forceinline__ i32x2 lds_read_tr(uint32_t addr) {   // ds_read_b64_t
 
 template <int WA, int WB, int TB>
 struct C8WgCfg {
-    static constexpr int NW = WA * WB, NT = 64 * NW, ROWS = 64 * WA, COLS = 32 * TB * WB, TAPS = ROWS / 8, NBUF = 4, KP = 32;
+    static constexpr int NW = WA * WB, NT = 64 * NW, ROWS = 64 * WA, COLS = 32 * TB * WB, TAPS = ROWS / 8, NBUF = C8_WG_NBUF, KP = 32;
     static constexpr int SUBA = (TAPS + 15) / 16, SUBB = (COLS / 8 + 15) / 16;      // 16-chunk sub-images per operand
     static constexpr int A_BYTES = SUBA * KP * 256, B_BYTES = SUBB * KP * 256, SLOT = A_BYTES + B_BYTES;
     static constexpr int NAI = SUBA * KP / 4, NBI = SUBB * KP / 4;                  // 1 KB fetches per stage
