@@ -49,6 +49,14 @@ __device__ __forceinline__ f32x16 mfma_bf16(const i32x4& a, const i32x4& b, cons
 __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {   // round to nearest even (v_cvt_pk_bf16_f32)
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
 }
+template <int I> struct IntC { static constexpr int value = I; };
+template <int B, int E, typename F>
+__device__ __forceinline__ void static_for(F&& f) {     // f(IntC<B>) ... f(IntC<E-1>): indices that must be compile-time constants
+    if constexpr (B < E) {
+        f(IntC<B>{});
+        static_for<B + 1, E>(f);
+    }
+}
 __device__ __forceinline__ int xcd_swizzle(int id, int n) {
     const int q = n >> 3, r = n & 7, xcd = id & 7, k = id >> 3;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
@@ -579,8 +587,12 @@ struct C8WgradArgs {
 };
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ i32x2 lds_read_tr(uint32_t addr) {   // ds_read_b64_tr_b16 at LDS byte address addr
-    return __builtin_bit_cast(i32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(uintptr_t)addr));
+typedef __attribute__((address_space(3))) char* lds_ptr;
+// ds_read_b64_tr_b16 at p + IMM: pointer arithmetic on the LDS array (not an integer cast), so that IMM lands in the instruction's
+// offset field instead of costing a vector add per read
+template <int IMM>
+__device__ __forceinline__ i32x2 lds_read_tr(lds_ptr p) {
+    return __builtin_bit_cast(i32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + IMM)));
 }
 
 template <int WA, int WB, int TB>
@@ -702,13 +714,12 @@ __global__ __launch_bounds__(64 * WA * WB) void wgrad_c8_kernel(const C8WgradArg
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int ca = (wa * 2 + i) * 4 + cl;                                   // chunk within the tile: sub-image chunk >> 4, slot chunk & 15
-        rd_a[i] = lds0 + (uint32_t)((ca >> 4) * KP * 256 + (g16 >> 1) * 2048 + rq * 256 + (((ca & 15) ^ (rq << 2)) * 16) + 8 * (rp & 1));
+        rd_a[i] = (uint32_t)((ca >> 4) * KP * 256 + (g16 >> 1) * 2048 + rq * 256 + (((ca & 15) ^ (rq << 2)) * 16) + 8 * (rp & 1));
     }
 #pragma unroll
     for (int i = 0; i < TB; ++i) {
         const int cbk = (wb * TB + i) * 4 + cl;
-        rd_b[i] = lds0 + (uint32_t)(C::A_BYTES + (cbk >> 4) * KP * 256 + (g16 >> 1) * 2048 + rq * 256 + (((cbk & 15) ^ (rq << 2)) * 16) +
-                                    8 * (rp & 1));
+        rd_b[i] = (uint32_t)(C::A_BYTES + (cbk >> 4) * KP * 256 + (g16 >> 1) * 2048 + rq * 256 + (((cbk & 15) ^ (rq << 2)) * 16) + 8 * (rp & 1));
     }
     for (int st = 0; st < nstages; ++st) {
         const int later = (nstages - 1 - st) < (NBUF - 2) ? (nstages - 1 - st) : (NBUF - 2);
@@ -720,25 +731,39 @@ __global__ __launch_bounds__(64 * WA * WB) void wgrad_c8_kernel(const C8WgradArg
             wait_vm<0>();
         __syncthreads();
         if (st + NBUF - 1 < nstages) issue(st + NBUF - 1);
-        const uint32_t so = (uint32_t)(st % NBUF) * SLOT;
+        const uint32_t so = lds0 + (uint32_t)(st % NBUF) * SLOT;
+        lds_ptr pa[2], pb[TB];
+        // one vector add per operand block and stage; the asm pins the sum in a register so that every read below is base + immediate
 #pragma unroll
-        for (int kk = 0; kk < KP / 16; ++kk) {
+        for (int i = 0; i < 2; ++i) {
+            uint32_t t = so + rd_a[i];
+            asm volatile("" : "+v"(t));
+            pa[i] = (lds_ptr)(uintptr_t)t;
+        }
+#pragma unroll
+        for (int i = 0; i < TB; ++i) {
+            uint32_t t = so + rd_b[i];
+            asm volatile("" : "+v"(t));
+            pb[i] = (lds_ptr)(uintptr_t)t;
+        }
+        static_for<0, KP / 16>([&](auto kc) {
+            constexpr int kk = decltype(kc)::value;
             i32x4 av[2], bv[TB];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const i32x2 a0 = lds_read_tr(rd_a[i] + so + kk * 4096), a1 = lds_read_tr(rd_a[i] + so + kk * 4096 + 1024);
+                const i32x2 a0 = lds_read_tr<kk * 4096>(pa[i]), a1 = lds_read_tr<kk * 4096 + 1024>(pa[i]);
                 av[i] = i32x4{a0[0], a0[1], a1[0], a1[1]};
             }
 #pragma unroll
             for (int i = 0; i < TB; ++i) {
-                const i32x2 b0 = lds_read_tr(rd_b[i] + so + kk * 4096), b1 = lds_read_tr(rd_b[i] + so + kk * 4096 + 1024);
+                const i32x2 b0 = lds_read_tr<kk * 4096>(pb[i]), b1 = lds_read_tr<kk * 4096 + 1024>(pb[i]);
                 bv[i] = i32x4{b0[0], b0[1], b1[0], b1[1]};
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < TB; ++j) acc[i][j] = mfma_bf16(av[i], bv[j], acc[i][j]);
-        }
+        });
     }
 
     // ---- epilogue: slab image [zs][g][row = tap * 8 + ci][co] ----
@@ -797,7 +822,7 @@ static int c8_wgrad_plan(const vl_conv_desc* d, int n, C8WgPlan* p) {
     p->L = (d->oh - 1) * Wp + d->ow;
     p->Rtot = (int64_t)n * p->L;
     const int tiles = p->tiles_a * p->tiles_b * d->groups;
-    int slabs = (2 * 256 + tiles - 1) / tiles;                       // about two workgroups per CU in flight over the launch
+    int slabs = (2 * 256) / tiles;                                   // ONE round of two workgroups per CU: a 513th workgroup would run alone
     const int64_t stages = (p->Rtot + 31) / 32;
     if (slabs > stages / 8) slabs = (int)(stages / 8);               // at least 8 stages per slab
     if (slabs < 1) slabs = 1;
