@@ -285,7 +285,7 @@ def main():
             out_x = eng_x.train_step_u8(frames, onehot, lr=1e-3, clip_norm=10.0, mean_bgr=MEAN_BGR, fetch=True)
             del eng_x
             what = {"bf16x3": "split bf16 products, 2 pieces / 3 products", "bf16x6": "split bf16 products, 3 pieces / 6 products",
-                    "bf16": "plain bf16 products (reduced precision)"}[math]
+                    "bf16": "the bf16 path: packed-bf16 operands in memory (csrc/conv_c8.hip), v_mfma_f32_32x32x16_bf16, reduced precision"}[math]
             return {"value": round(clips * args.steps / tx, 2), "unit": "clips/s", "ms_per_step": round(tx / args.steps * 1e3, 3),
                     "dtype": "%s (conv fwd/dgrad/wgrad: %s, fp32 accumulate) + f32 (dense GEMMs, LSTM, pointwise)" % (math, what),
                     "per_launch_ms": {k: round(sum(v) / len(v), 3) for k, v in sorted(per_x.items())},
@@ -350,8 +350,10 @@ def main():
                      "traffic": traffic_rec["bytes_per_launch"] if (traffic_rec and n == 1024 and f32_main) else None,
                      "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes)",
                      "traffic_source": traffic_src if n == 1024 else None,
-                     "algorithmic_bytes_per_launch": alg_bytes,
-                     "kernel": DOMINANT_SYMBOL if f32_main else "conv_ring4_kernel / conv_ring_kernel (%s)" % args.conv_math,
+                     "algorithmic_bytes_per_launch": alg_bytes if f32_main else None,
+                     "kernel": DOMINANT_SYMBOL if f32_main else
+                               ("conv_c8_kernel<4, 2, 2, 2> (packed-bf16 operands, csrc/conv_c8.hip)" if args.conv_math == "bf16" else
+                                "conv_ring4_kernel / conv_ring_kernel (%s)" % args.conv_math),
                      "launches": list(DOMINANT),
                      "flop_per_launch": dom_flop, "ms_per_launch": round(dom_ms, 4),
                      "conv_stack": {"tflops": round(stack_flop / (stack_ms * 1e-3) / 1e12, 2),
@@ -359,7 +361,7 @@ def main():
                                     "ms_per_step": round(stack_ms, 3),
                                     "per_launch_ms": {k: round(v, 3) for k, v in sorted(avg.items())}},
                      "flop_per_clip_train": train_flop,
-                     "step_frac_of_mfma_roofline": round(value / world * train_flop / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)},
+                     "step_frac_of_mfma_roofline": round(value / world * train_flop / 1e12 / peak, 4)},
         "forward_only": None if fwd_ms is None else
                         {"value": round(clips / (fwd_ms * 1e-3), 2), "unit": "clips/s per GPU", "ms_per_batch": round(fwd_ms, 3),
                          "frac_of_mfma_roofline": round(clips / (fwd_ms * 1e-3) * fwd_flop / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)},

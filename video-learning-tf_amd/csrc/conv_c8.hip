@@ -319,59 +319,72 @@ __global__ __launch_bounds__(64 * WP * WQ, (C8Cfg<WP, WQ, TP, TQ>::WPS)) void co
     const bool wide = a.y_wide != 0;        // (uniform) dense unmasked fp32 output: staged through LDS, stored 16 bytes per lane
     float* stg = reinterpret_cast<float*>(lds) + wave * C::STG;             // this wave's [32 TQ channels][32 pixels + 4]
     if (wide) __syncthreads();                                              // every wave is done with the ring
+    // Outputs and masks go through buffer instructions: per-lane 32-bit offset (pixel within the tile's first image n0, + this lane
+    // half's 4-channel step) + a scalar channel offset -- no 64-bit address arithmetic per store; pixels past the end carry an
+    // offset that fails the range check (loads answer 0, stores are dropped), so the epilogue has no per-lane branch.
+    constexpr uint32_t OOB = 0xF0000000u;
+    const int nimg = a.M / a.OHW;
+    auto out_rsrc = [&](const void* base, int64_t img_bytes) {
+        int64_t bytes = (int64_t)(nimg - n0) * img_bytes;
+        if (bytes > MAX_BUF_BYTES) bytes = MAX_BUF_BYTES;
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(base)) + (int64_t)n0 * img_bytes, 0,
+                                                 (int)(uint32_t)bytes, 0x00020000);
+    };
+    const int64_t y_img = (int64_t)a.Ctot * a.y_plane * 4, yb_img = (int64_t)a.yb_cb * a.yb_plane, mb_img = (int64_t)a.yb_cb * a.mb_plane;
+    const __amdgpu_buffer_rsrc_t rs_y = out_rsrc(a.y ? (const void*)a.y : (const void*)a.x, y_img);
+    const __amdgpu_buffer_rsrc_t rs_yb = out_rsrc(a.yb ? (const void*)a.yb : (const void*)a.x, yb_img);
+    const __amdgpu_buffer_rsrc_t rs_mb = out_rsrc(a.maskb ? (const void*)a.maskb : (const void*)a.x, mb_img);
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
     for (int i = 0; i < TP; ++i) {
         const int mb = p0 + (wp * TP + i) * 32;                             // first pixel of this 32-pixel block (uniform)
         const int m = mb + (lane & 31);
-        if (m < a.M) {
-            const uint32_t n = fd_div((uint32_t)m, a.dOHW), r = (uint32_t)m - n * a.dOHW.d;
-            const uint32_t oh = fd_div(r, a.dOW), ow = r - oh * a.dOW.d;
-            const int64_t ypix = (int64_t)(oh + a.y_halo) * a.y_w + ow + a.y_halo;
-            const int64_t ybpix = (int64_t)(oh + a.yb_halo) * a.yb_row + (int64_t)(ow + a.yb_halo) * 16 + 8 * (lane >> 5);
-            const int64_t mbpix = (int64_t)(oh + a.mb_halo) * a.mb_row + (int64_t)(ow + a.mb_halo) * 16 + 8 * (lane >> 5);
-            // packed ReluGrad masks: the 4 words of channel block j + 1 are requested before the stores of block j go out
-            uint2 mkn[4];
-            auto load_masks = [&](int j) {
+        const bool valid = m < a.M;
+        const int mc = valid ? m : a.M - 1;
+        const uint32_t n = fd_div((uint32_t)mc, a.dOHW), r = (uint32_t)mc - n * a.dOHW.d;
+        const uint32_t oh = fd_div(r, a.dOW), ow = r - oh * a.dOW.d;
+        const int64_t ypix = (int64_t)(oh + a.y_halo) * a.y_w + ow + a.y_halo;
+        const uint32_t dn = n - (uint32_t)n0;
+        const uint32_t voff_y = valid ? (uint32_t)(dn * y_img) + (uint32_t)((ypix + (int64_t)4 * (lane >> 5) * a.y_plane) * 4) : OOB;
+        const uint32_t voff_yb = valid ? (uint32_t)(dn * yb_img) + (uint32_t)((oh + a.yb_halo) * a.yb_row + (ow + a.yb_halo) * 16 + 8 * (lane >> 5)) : OOB;
+        const uint32_t voff_mb = valid ? (uint32_t)(dn * mb_img) + (uint32_t)((oh + a.mb_halo) * a.mb_row + (ow + a.mb_halo) * 16 + 8 * (lane >> 5)) : OOB;
+        // packed ReluGrad masks: the 4 words of channel block j + 1 are requested before the stores of block j go out
+        u32x2 mkn[4];
+        auto load_masks = [&](int j) {
 #pragma unroll
-                for (int qg = 0; qg < 4; ++qg) {
-                    const int cog0 = q0 + (wq * TQ + j) * 32 + 8 * qg;
-                    mkn[qg] = uint2{0x3f803f80u, 0x3f803f80u};
-                    if (a.maskb && cog0 < a.Cog)
-                        mkn[qg] = *reinterpret_cast<const uint2*>(a.maskb + ((int64_t)n * a.yb_cb + (g * a.Cog + cog0) / 8) * a.mb_plane + mbpix);
+            for (int qg = 0; qg < 4; ++qg) {
+                const int cog0 = q0 + (wq * TQ + j) * 32 + 8 * qg;
+                mkn[qg] = u32x2{0x3f803f80u, 0x3f803f80u};
+                if (a.maskb && cog0 < a.Cog)
+                    mkn[qg] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_mb, (int)voff_mb, (int)(((g * a.Cog + cog0) >> 3) * a.mb_plane), 0));
+            }
+        };
+        load_masks(0);
+#pragma unroll
+        for (int j = 0; j < TQ; ++j) {
+            u32x2 mkc[4];
+#pragma unroll
+            for (int qg = 0; qg < 4; ++qg) mkc[qg] = mkn[qg];
+            if (j + 1 < TQ) load_masks(j + 1);
+#pragma unroll
+            for (int qg = 0; qg < 4; ++qg) {
+                const int cog0 = q0 + (wq * TQ + j) * 32 + 8 * qg;   // first channel (within the group) of this 8-channel block
+                if (cog0 >= a.Cog) continue;                         // (uniform)
+                const int cu = g * a.Cog + cog0;                     // uniform part of the channel; this lane's 4: cu + 4 (lane >> 5) + e
+                float v[4];
+                const f32x4 bq = *reinterpret_cast<const f32x4*>(bias_l + (wq * TQ + j) * 32 + 8 * qg + 4 * (lane >> 5));
+                const u32x2 mk = mkc[qg];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = acc[j][i][qg * 4 + e] + bq[e];
+                    if (a.relu) v[e] = fmaxf(v[e], 0.f);
+                    if (a.mask && valid) v[e] = a.mask[((int64_t)n * a.Ctot + cu + 4 * (lane >> 5) + e) * a.y_plane + ypix] > 0.f ? v[e] : 0.f;
+                    const uint32_t mw = e < 2 ? mk[0] : mk[1];
+                    if (a.maskb) v[e] = (int16_t)((e & 1) ? (mw >> 16) : (mw & 0xffffu)) > 0 ? v[e] : 0.f;   // bf16 > 0
+                    if (a.y && !wide) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v[e]), rs_y, (int)voff_y, (int)((cu + e) * a.y_plane * 4), 0);
+                    if (wide) stg[(j * 32 + qg * 8 + 4 * (lane >> 5) + e) * 36 + (lane & 31)] = v[e];
                 }
-            };
-            load_masks(0);
-#pragma unroll
-            for (int j = 0; j < TQ; ++j) {
-                uint2 mkc[4];
-#pragma unroll
-                for (int qg = 0; qg < 4; ++qg) mkc[qg] = mkn[qg];
-                if (j + 1 < TQ) load_masks(j + 1);
-#pragma unroll
-                for (int qg = 0; qg < 4; ++qg) {
-                    const int cog0 = q0 + (wq * TQ + j) * 32 + 8 * qg;   // first channel (within the group) of this 8-channel block
-                    if (cog0 >= a.Cog) continue;
-                    const int c0 = g * a.Cog + cog0 + 4 * (lane >> 5);   // this lane's 4 channels: c0 .. c0 + 3
-                    float v[4];
-                    const f32x4 bq = *reinterpret_cast<const f32x4*>(bias_l + (wq * TQ + j) * 32 + 8 * qg + 4 * (lane >> 5));
-                    const uint2 mk = mkc[qg];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[e] = acc[j][i][qg * 4 + e] + bq[e];
-                        if (a.relu) v[e] = fmaxf(v[e], 0.f);
-                        if (a.mask) v[e] = a.mask[((int64_t)n * a.Ctot + c0 + e) * a.y_plane + ypix] > 0.f ? v[e] : 0.f;
-                        const uint32_t mw = e < 2 ? mk.x : mk.y;
-                        if (a.maskb) v[e] = (int16_t)((e & 1) ? (mw >> 16) : (mw & 0xffffu)) > 0 ? v[e] : 0.f;   // bf16 > 0
-                        if (a.y && !wide) a.y[((int64_t)n * a.Ctot + c0 + e) * a.y_plane + ypix] = v[e];
-                        if (wide) stg[(j * 32 + qg * 8 + 4 * (lane >> 5) + e) * 36 + (lane & 31)] = v[e];
-                    }
-                    if (a.yb) {
-                        uint2 o;
-                        o.x = pack_bf16(v[0], v[1]);
-                        o.y = pack_bf16(v[2], v[3]);
-                        *reinterpret_cast<uint2*>(a.yb + ((int64_t)n * a.yb_cb + (g * a.Cog + cog0) / 8) * a.yb_plane + ybpix) = o;
-                    }
-                }
+                if (a.yb) __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])}, rs_yb, (int)voff_yb, (int)((cu >> 3) * a.yb_plane), 0);
             }
         }
         if (wide) {
@@ -660,7 +673,14 @@ __global__ __launch_bounds__(64 * WA * WB) void wgrad_c8_kernel(const C8WgradArg
         const int r0 = (int)(gp0 - (int64_t)n_s * a.L);                        // position within the image's sweep
         const int to_next = a.L - r0;                                          // positions of the stage before the next image starts
         const int to_end = (int)((gp_end - gp0) < KP ? (gp_end - gp0) : KP);   // positions before the slab ends
-        if (a.L >= KP) {                                                       // at most one image boundary inside the stage
+        if (to_next >= KP && to_end >= KP) {                                   // the whole stage inside one image: no per-lane work at all
+            const uint32_t sx = (uint32_t)((int64_t)(n_s - n_first) * a.x_img) + (uint32_t)r0 * 16;
+            const uint32_t sdy = (uint32_t)((int64_t)(n_s - n_first) * a.dy_img) + (uint32_t)(a.qstart + r0) * 16;
+#pragma unroll
+            for (int j = 0; j < FA; ++j) lds_dma16(rs_x, slot + lds_a[j], voff_a[j], (int)(sx + (uint32_t)grp_a[j] * 64));
+#pragma unroll
+            for (int j = 0; j < FB; ++j) lds_dma16(rs_dy, slot + lds_b[j], voff_b[j], (int)(sdy + (uint32_t)grp_b[j] * 64));
+        } else if (a.L >= KP) {                                                // at most one image boundary inside the stage
             const uint32_t sx = (uint32_t)((int64_t)(n_s - n_first) * a.x_img) + (uint32_t)r0 * 16;
             const uint32_t sdy = (uint32_t)((int64_t)(n_s - n_first) * a.dy_img) + (uint32_t)(a.qstart + r0) * 16;
 #pragma unroll
