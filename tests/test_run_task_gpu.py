@@ -38,11 +38,13 @@ def write_cfg(folder, name, data_path, phase, resume=None, epochs=2, optimizer="
     return path
 
 
-@pytest.mark.parametrize("prefetch,math", [("2", "f32"), ("0", "f32"), ("2", "bf16x3")])
+@pytest.mark.parametrize("prefetch,math", [("2", "f32"), ("0", "f32"), ("2", "bf16x3"), ("2", "bf16")])
 def test_train_resume_validate(tmp_path, monkeypatch, prefetch, math):
     """prefetch 2: batches read and uploaded ahead of the loop by the feeder's background thread (the default);
     prefetch 0: the reference's synchronous feed.  Same checkpoints, logs, resume behaviour and validation results.
-    math bf16x3: the whole workflow with the opt-in split-bf16 conv arithmetic (VLTF_CONV_MATH), same checks."""
+    math bf16x3: the whole workflow with the opt-in split-bf16 conv arithmetic (VLTF_CONV_MATH), same checks.
+    math bf16: the whole workflow on the bf16 conv PATH (packed operands, csrc/conv_c8.hip): reduced precision by design, so the
+    validation logits are held to 5e-2 of the oracle's on the trained weights instead of 1e-3."""
     monkeypatch.setenv("VLTF_PREFETCH", prefetch)
     monkeypatch.setenv("VLTF_CONV_MATH", math)
     from vltf_amd import run_task
@@ -83,8 +85,11 @@ def test_train_resume_validate(tmp_path, monkeypatch, prefetch, math):
     x = np.stack([O.process_image(f, WANT, (cy, cx), MEAN) for f in frames])
     clip_logits, _ = O.lrcn_forward(params, x, 3)
     want = O.clip_fusion_per_video(clip_logits, [2, 1, 2], "avg")
-    np.testing.assert_allclose(got, want, rtol=1e-3, atol=1e-3)
-    assert acc == float(np.mean(want.argmax(1) == np.array(vlabels)))
+    tol = 5e-2 if math == "bf16" else 1e-3
+    np.testing.assert_allclose(got, want, rtol=tol, atol=tol)
+    srt = np.sort(want, axis=1)
+    if math != "bf16" or float((srt[:, -1] - srt[:, -2]).min()) > 2 * tol:          # (reduced precision may flip a near tie)
+        assert acc == float(np.mean(want.argmax(1) == np.array(vlabels)))
 
 
 def test_adam_resume_equals_uninterrupted(tmp_path, monkeypatch):
