@@ -443,7 +443,7 @@ void conv_c8_free_tables(vl_conv_desc* d) {
 
 static int c8_tables(vl_conv_desc* d) {
     if (!d->c8_toff_fwd) {
-        VL_CHECK(d->fwd_padded && d->x_phase == 1, "conv c8: x needs the padded layout (halo >= SAME padding), not phase split");
+        VL_CHECK(d->fwd_padded && d->x_phase <= 1, "conv c8: x needs the padded layout (halo >= SAME padding), not phase split");
         d->c8_toff_fwd = upload_taps(d->cig, d->kh, d->kw, d->h + 2 * d->x_halo, d->w + 2 * d->x_halo, d->x_halo - d->pt, d->x_halo - d->pl);
         VL_CHECK(d->c8_toff_fwd, "conv c8: tap table allocation failed");
     }

@@ -2008,7 +2008,10 @@ extern "C" int vl_conv_create(vl_conv_desc** out, int cin, int h, int w, int cou
     // weight images of the split-product kernels: [groups][ceil(K / 16)][8 x planes][channels rounded up to 128] dwords each
     const size_t sf = (size_t)groups * ceil_div(d->K, KBLK) * 24 * (ceil_div(d->cog, 128) * 128) * 4;     // up to three planes (bf16x6)
     const size_t sb = (size_t)groups * ceil_div(d->Kd, KBLK) * 24 * (ceil_div(d->cig, 128) * 128) * 4;
-    if (rebuild_tables(d) || hipMalloc((void**)&d->wsplit_fwd, sf) != hipSuccess || hipMalloc((void**)&d->wsplit_bwd, sb) != hipSuccess) {
+    // (a descriptor of a dense layer -- fc6 as a 1 x 1 layer of the bf16 path, csrc/conv_c8.hip -- would hold 2 x 226 MB here: none
+    // above 64 MB; such a layer keeps fp32 products in vl_conv_fwd / vl_conv_dgrad whatever vl_set_conv_math says)
+    const bool images = sf <= (64u << 20) && sb <= (64u << 20);
+    if (rebuild_tables(d) || (images && (hipMalloc((void**)&d->wsplit_fwd, sf) != hipSuccess || hipMalloc((void**)&d->wsplit_bwd, sb) != hipSuccess))) {
         vl_conv_destroy(d);
         vl_set_error("vl_conv_create: device table allocation failed");
         return 2;
@@ -2455,7 +2458,7 @@ static int dispatch_conv(const ConvGeom& g, const float* w, int64_t w_ld, int w_
     // output-channel tile: 128 when it divides well, else 96 (conv1: 96, conv4: 192) or 64 (conv2 dgrad: 48)
     const int w128 = ceil_div(Cog, 128) * 128, w96 = ceil_div(Cog, 96) * 96, w64 = ceil_div(Cog, 64) * 64;
     // split products: the ring kernel (128-channel tiles; its 16-byte im2col fetches need unit column stride in memory)
-    if (g_conv_math != 0 && PADDED && g.col_mul == 1) {
+    if (g_conv_math != 0 && PADDED && g.col_mul == 1 && wsplit != nullptr) {
         if (Cog >= 96) return launch_conv_ring<128>(g, w, w_ld, w_grp_stride, row_tab, Cog, Cout_total, o, wsplit, s);
         if (Cog >= 40 && Cog <= 64) return launch_conv_ring<64>(g, w, w_ld, w_grp_stride, row_tab, Cog, Cout_total, o, wsplit, s);
     }
