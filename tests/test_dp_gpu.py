@@ -74,7 +74,7 @@ def test_two_rank_step_equals_one_rank():
     assert tag == "ok" and worst < 1e-3 and gn_err < 1e-5, (worst, gn_err)
 
 
-def nccl_worker(port, q):
+def nccl_worker(port, q, math="f32"):
     """ONE rank, backend nccl (= RCCL): the collective path of the data-parallel step on a single GPU."""
     os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     from vltf_amd import dp
@@ -82,7 +82,7 @@ def nccl_worker(port, q):
     r, w, _ = dp.init_from_env(backend="nccl", force=True)
     assert (r, w) == (0, 1) and torch.distributed.get_backend() == "nccl"
     shape, ncls, fpc, clips, hid = (67, 67, 3), 5, 2, 4, 6
-    cfg = NetConfig(image_shape=shape, num_classes=ncls, fpc=fpc, lstm_hidden=hid)
+    cfg = NetConfig(image_shape=shape, num_classes=ncls, fpc=fpc, lstm_hidden=hid, conv_math=math)
     rng = np.random.default_rng(11)
     p = O.init_params(rng, ncls, "fc6", hid, 1, shape, well_scaled=True)
     frames = torch.tensor(rng.integers(0, 256, (clips * fpc,) + shape, dtype=np.uint8), device="cuda:0")
@@ -119,3 +119,20 @@ def test_one_rank_rccl_step_equals_plain_step():
     tag, same, worst, outs, issued, nchunks = q.get(timeout=10)
     assert tag == "ok" and issued == 3 * nchunks and nchunks >= 3, (issued, nchunks)
     assert same, "parameters differ from the plain step by up to %.3e; losses / norms per step: %s" % (worst, outs)
+
+
+def test_one_rank_rccl_step_on_the_bf16_path():
+    """BASELINE config 5 is the bf16 conv path under data parallelism: the same one-rank RCCL step with conv_math="bf16" (packed
+    operands, csrc/conv_c8.hip).  The data-parallel form computes fc6's weight gradient in row blocks with fp32 products where the
+    plain step uses one split-bf16 GEMM, so the two runs agree to bf16 level, not bitwise."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    pr = ctx.Process(target=nccl_worker, args=(free_port(), q, "bf16"))
+    pr.start()
+    pr.join(300)
+    assert pr.exitcode == 0, "rank exited with %s" % pr.exitcode
+    tag, same, worst, outs, issued, nchunks = q.get(timeout=10)
+    assert tag == "ok" and issued == 3 * nchunks and nchunks >= 3, (issued, nchunks)
+    assert worst < 2e-2, "parameters differ from the plain step by up to %.3e; losses / norms per step: %s" % (worst, outs)
+    for la, lb, ga, gb in outs:
+        assert abs(la - lb) < 2e-2 * max(1.0, abs(lb)) and abs(ga - gb) < 5e-2 * gb, outs
