@@ -190,6 +190,7 @@ struct C8ConvArgs {
     int yb_halo, yb_row;    // bytes per row
     int64_t yb_plane;       // bytes per plane
     int yb_cb;              // channel blocks per image
+    int dbg;                // experiments (VL_C8_DBG): 1 = no epilogue, 2 = no reduction loop
     const char* maskb;      // bf16 c8 ReluGrad mask (the producing layer's packed output), or null
     int mb_halo, mb_row;
     int64_t mb_plane;
@@ -212,7 +213,10 @@ struct C8Cfg {
     static_assert(P % 64 == 0, "whole 64-lane fetches");
 };
 
-template <int WP, int WQ, int TP, int TQ>
+// EPI: what the epilogue writes, at COMPILE time -- with run-time flags every one of a lane's 64-96 outputs paid five scalar branches
+// (conv1 forward: 12 us of epilogue per 10 us tile).  0 = by the arguments (any combination; tests), 1 = dense fp32 y, 16-byte
+// stores, 2 = packed yb, 3 = packed yb under the packed ReluGrad mask, 4 = fp32 y with a halo.  ReLU is a floor (0 or -inf): no branch.
+template <int WP, int WQ, int TP, int TQ, int EPI>
 __global__ __launch_bounds__(64 * WP * WQ, (C8Cfg<WP, WQ, TP, TQ>::WPS)) void conv_c8_kernel(const C8ConvArgs a, int tiles_q) {
     using C = C8Cfg<WP, WQ, TP, TQ>;
     constexpr int NW = C::NW, P = C::P, Q = C::Q, QF = C::QF, NBUF = C::NBUF, SLOT = C::SLOT, FP = C::FP, FW = C::FW, F = C::F;
@@ -223,7 +227,7 @@ __global__ __launch_bounds__(64 * WP * WQ, (C8Cfg<WP, WQ, TP, TQ>::WPS)) void co
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wp = wave % WP, wq = wave / WP;
-    const int nstages = a.nstages;
+    const int nstages = (a.dbg & 2) ? 0 : a.nstages;
 
     // ---- fetch plan ----
     const int n0 = (int)fd_div((uint32_t)p0, a.dOHW);
@@ -314,9 +318,15 @@ __global__ __launch_bounds__(64 * WP * WQ, (C8Cfg<WP, WQ, TP, TQ>::WPS)) void co
     }
 
     // ---- epilogue ----
+    if (a.dbg & 1) return;
     typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte access at 4-byte alignment
     typedef float f32x4 __attribute__((ext_vector_type(4)));
-    const bool wide = a.y_wide != 0;        // (uniform) dense unmasked fp32 output: staged through LDS, stored 16 bytes per lane
+    const bool wide = EPI == 0 ? a.y_wide != 0 : EPI == 1;   // dense unmasked fp32 output: staged through LDS, stored 16 bytes per lane
+    const bool has_y = EPI == 0 ? a.y != nullptr : (EPI == 1 || EPI == 4);
+    const bool has_yb = EPI == 0 ? a.yb != nullptr : (EPI == 2 || EPI == 3);
+    const bool has_maskb = EPI == 0 ? a.maskb != nullptr : EPI == 3;
+    const bool has_mask = EPI == 0 && a.mask != nullptr;
+    const float floor_v = a.relu ? 0.f : -INFINITY;
     float* stg = reinterpret_cast<float*>(lds) + wave * C::STG;             // this wave's [32 TQ channels][32 pixels + 4]
     if (wide) __syncthreads();                                              // every wave is done with the ring
     // Outputs and masks go through buffer instructions: per-lane 32-bit offset (pixel within the tile's first image n0, + this lane
@@ -355,7 +365,7 @@ __global__ __launch_bounds__(64 * WP * WQ, (C8Cfg<WP, WQ, TP, TQ>::WPS)) void co
             for (int qg = 0; qg < 4; ++qg) {
                 const int cog0 = q0 + (wq * TQ + j) * 32 + 8 * qg;
                 mkn[qg] = u32x2{0x3f803f80u, 0x3f803f80u};
-                if (a.maskb && cog0 < a.Cog)
+                if (has_maskb && cog0 < a.Cog)
                     mkn[qg] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_mb, (int)voff_mb, (int)(((g * a.Cog + cog0) >> 3) * a.mb_plane), 0));
             }
         };
@@ -376,15 +386,14 @@ __global__ __launch_bounds__(64 * WP * WQ, (C8Cfg<WP, WQ, TP, TQ>::WPS)) void co
                 const u32x2 mk = mkc[qg];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    v[e] = acc[j][i][qg * 4 + e] + bq[e];
-                    if (a.relu) v[e] = fmaxf(v[e], 0.f);
-                    if (a.mask && valid) v[e] = a.mask[((int64_t)n * a.Ctot + cu + 4 * (lane >> 5) + e) * a.y_plane + ypix] > 0.f ? v[e] : 0.f;
+                    v[e] = fmaxf(acc[j][i][qg * 4 + e] + bq[e], floor_v);
+                    if (has_mask && valid) v[e] = a.mask[((int64_t)n * a.Ctot + cu + 4 * (lane >> 5) + e) * a.y_plane + ypix] > 0.f ? v[e] : 0.f;
                     const uint32_t mw = e < 2 ? mk[0] : mk[1];
-                    if (a.maskb) v[e] = (int16_t)((e & 1) ? (mw >> 16) : (mw & 0xffffu)) > 0 ? v[e] : 0.f;   // bf16 > 0
-                    if (a.y && !wide) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v[e]), rs_y, (int)voff_y, (int)((cu + e) * a.y_plane * 4), 0);
+                    if (has_maskb) v[e] = (int16_t)((e & 1) ? (mw >> 16) : (mw & 0xffffu)) > 0 ? v[e] : 0.f;   // bf16 > 0
+                    if (has_y && !wide) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v[e]), rs_y, (int)voff_y, (int)((cu + e) * a.y_plane * 4), 0);
                     if (wide) stg[(j * 32 + qg * 8 + 4 * (lane >> 5) + e) * 36 + (lane & 31)] = v[e];
                 }
-                if (a.yb) __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])}, rs_yb, (int)voff_yb, (int)((cu >> 3) * a.yb_plane), 0);
+                if (has_yb) __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])}, rs_yb, (int)voff_yb, (int)((cu >> 3) * a.yb_plane), 0);
             }
         }
         if (wide) {
@@ -456,10 +465,10 @@ static int c8_tables(vl_conv_desc* d) {
     return 0;
 }
 
-template <int WP, int WQ, int TP, int TQ>
-static int launch_c8(const C8ConvArgs& a, int groups, hipStream_t stream) {
+template <int WP, int WQ, int TP, int TQ, int EPI>
+static int launch_c8e(const C8ConvArgs& a, int groups, hipStream_t stream) {
     using C = C8Cfg<WP, WQ, TP, TQ>;
-    auto kern = conv_c8_kernel<WP, WQ, TP, TQ>;
+    auto kern = conv_c8_kernel<WP, WQ, TP, TQ, EPI>;
     static bool attr = false;
     if (!attr) {
         VL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
@@ -472,8 +481,23 @@ static int launch_c8(const C8ConvArgs& a, int groups, hipStream_t stream) {
     return 0;
 }
 
+template <int WP, int WQ, int TP, int TQ>
+static int launch_c8(const C8ConvArgs& a, int groups, hipStream_t stream) {
+    static const bool generic = getenv("VL_C8_GENERIC_EPILOGUE") != nullptr;      // A/B: the run-time-flag epilogue everywhere
+    const bool y = a.y != nullptr, yb = a.yb != nullptr, mb = a.maskb != nullptr, mf = a.mask != nullptr;
+    if (!generic && !mf) {
+        if (y && !yb && !mb && a.y_wide) return launch_c8e<WP, WQ, TP, TQ, 1>(a, groups, stream);
+        if (!y && yb && !mb) return launch_c8e<WP, WQ, TP, TQ, 2>(a, groups, stream);
+        if (!y && yb && mb) return launch_c8e<WP, WQ, TP, TQ, 3>(a, groups, stream);
+        if (y && !yb && !mb && !a.y_wide) return launch_c8e<WP, WQ, TP, TQ, 4>(a, groups, stream);
+    }
+    return launch_c8e<WP, WQ, TP, TQ, 0>(a, groups, stream);
+}
+
 // channel tile by the group's channel count: 128-wide tiles, 192 as one tile of 192 (conv4 / conv5 dgrad), 64 for narrow groups
-static int dispatch_c8(const C8ConvArgs& a, int groups, hipStream_t stream) {
+static int dispatch_c8(C8ConvArgs& a, int groups, hipStream_t stream) {
+    static const int dbg = getenv("VL_C8_DBG") ? atoi(getenv("VL_C8_DBG")) : 0;
+    a.dbg = dbg;
     if (a.Cog <= 64) return launch_c8<4, 1, 2, 2>(a, groups, stream);          // 256 pixels x 64 channels, 4 waves
     if (a.Cog <= 96) return launch_c8<4, 1, 2, 3>(a, groups, stream);          // 256 x 96 (conv1 as a 3x3 conv over 48 channels)
     if (a.Cog % 128 != 0 && a.Cog % 192 == 0) return launch_c8<4, 2, 2, 3>(a, groups, stream);   // 256 x 192
