@@ -190,7 +190,6 @@ struct C8ConvArgs {
     int yb_halo, yb_row;    // bytes per row
     int64_t yb_plane;       // bytes per plane
     int yb_cb;              // channel blocks per image
-    int dbg;                // experiments (VL_C8_DBG): 1 = no epilogue, 2 = no reduction loop
     const char* maskb;      // bf16 c8 ReluGrad mask (the producing layer's packed output), or null
     int mb_halo, mb_row;
     int64_t mb_plane;
@@ -227,7 +226,7 @@ __global__ __launch_bounds__(64 * WP * WQ, (C8Cfg<WP, WQ, TP, TQ>::WPS)) void co
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wp = wave % WP, wq = wave / WP;
-    const int nstages = (a.dbg & 2) ? 0 : a.nstages;
+    const int nstages = a.nstages;
 
     // ---- fetch plan ----
     const int n0 = (int)fd_div((uint32_t)p0, a.dOHW);
@@ -318,7 +317,6 @@ __global__ __launch_bounds__(64 * WP * WQ, (C8Cfg<WP, WQ, TP, TQ>::WPS)) void co
     }
 
     // ---- epilogue ----
-    if (a.dbg & 1) return;
     typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte access at 4-byte alignment
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     const bool wide = EPI == 0 ? a.y_wide != 0 : EPI == 1;   // dense unmasked fp32 output: staged through LDS, stored 16 bytes per lane
@@ -496,8 +494,6 @@ static int launch_c8(const C8ConvArgs& a, int groups, hipStream_t stream) {
 
 // channel tile by the group's channel count: 128-wide tiles, 192 as one tile of 192 (conv4 / conv5 dgrad), 64 for narrow groups
 static int dispatch_c8(C8ConvArgs& a, int groups, hipStream_t stream) {
-    static const int dbg = getenv("VL_C8_DBG") ? atoi(getenv("VL_C8_DBG")) : 0;
-    a.dbg = dbg;
     if (a.Cog <= 64) return launch_c8<4, 1, 2, 2>(a, groups, stream);          // 256 pixels x 64 channels, 4 waves
     if (a.Cog <= 96) return launch_c8<4, 1, 2, 3>(a, groups, stream);          // 256 x 96 (conv1 as a 3x3 conv over 48 channels)
     if (a.Cog % 128 != 0 && a.Cog % 192 == 0) return launch_c8<4, 2, 2, 3>(a, groups, stream);   // 256 x 192
@@ -1108,12 +1104,77 @@ __global__ void input_prep_u8_s2d_kernel(const uint8_t* __restrict__ src, uint4*
     xb[idx] = o;
 }
 
+// The AlexNet case (3 channels, stride 4): one thread = 2 source rows x 4 pixels x 3 channels = 2 x 12 contiguous source bytes (three
+// unaligned dword loads per row away from the borders; the generic kernel issues 8 byte loads per chunk and reads every source byte
+// from three threads) -> the three chunks (one per channel) of its (row pair, column quad): 0.38 -> 0.2 ms per 1024 frames.
+__global__ void input_prep_u8_s2d_c3s4_kernel(const uint8_t* __restrict__ src, uint4* __restrict__ xb, int H, int W, int rh, int rw,
+                                              const int32_t* __restrict__ cy, const int32_t* __restrict__ cx, const uint8_t* __restrict__ mir,
+                                              const float* __restrict__ mean, int pt, int pl, int OHp, int OWp, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int S = (int)(idx % OWp), hp = (int)((idx / OWp) & 1), R = (int)((idx / (2 * OWp)) % OHp);
+    const int n = (int)(idx / ((int64_t)2 * OWp * OHp));
+    const int oy = cy ? cy[n] : 0, ox = cx ? cx[n] : 0;
+    const bool flip = mir && mir[n];
+    const float m0 = mean ? mean[0] : 0.f, m1 = mean ? mean[1] : 0.f, m2 = mean ? mean[2] : 0.f;
+    const int iw0 = 4 * S - pl;
+    const bool interior = iw0 >= 0 && iw0 + 3 < W;
+    float v[3][8];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int ih = 4 * R + 2 * hp + r - pt;
+        const bool rowok = ih >= 0 && ih < H;
+        const uint8_t* row = src + ((int64_t)n * rh + (rowok ? ih : 0) + oy) * rw * 3;
+        uint8_t b[12];
+        if (rowok && interior) {
+            const uint8_t* q = row + (int64_t)((flip ? W - 1 - (iw0 + 3) : iw0) + ox) * 3;
+            uint32_t w3[3];
+            __builtin_memcpy(w3, q, 12);
+#pragma unroll
+            for (int k = 0; k < 12; ++k) b[k] = (uint8_t)(w3[k >> 2] >> (8 * (k & 3)));
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int sk = flip ? 3 - k : k;
+                v[0][4 * r + k] = (float)b[3 * sk] - m0;
+                v[1][4 * r + k] = (float)b[3 * sk + 1] - m1;
+                v[2][4 * r + k] = (float)b[3 * sk + 2] - m2;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int iw = iw0 + k;
+                const bool ok = rowok && iw >= 0 && iw < W;
+                const uint8_t* q = row + (int64_t)((flip ? W - 1 - iw : iw) + ox) * 3;
+                v[0][4 * r + k] = ok ? (float)q[0] - m0 : 0.f;
+                v[1][4 * r + k] = ok ? (float)q[1] - m1 : 0.f;
+                v[2][4 * r + k] = ok ? (float)q[2] - m2 : 0.f;
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        uint4 o;
+        o.x = pack_bf16(v[c][0], v[c][1]);
+        o.y = pack_bf16(v[c][2], v[c][3]);
+        o.z = pack_bf16(v[c][4], v[c][5]);
+        o.w = pack_bf16(v[c][6], v[c][7]);
+        xb[(((int64_t)n * 6 + 2 * c + hp) * OHp + R) * OWp + S] = o;
+    }
+}
+
 extern "C" int vl_input_prep_u8_s2d(const vl_conv_desc* d, const uint8_t* src, void* xb, int n, int raw_h, int raw_w, const int32_t* crop_y,
                                     const int32_t* crop_x, const uint8_t* mirror, const float* mean_bgr, vl_stream_t stream) {
     VL_CHECK(src && xb && n > 0, "vl_input_prep_u8_s2d: bad argument");
     if (int rc = s2d_check(d, "vl_input_prep_u8_s2d")) return rc;
     VL_CHECK(d->h <= raw_h && d->w <= raw_w, "vl_input_prep_u8_s2d: bad shape");
     const int s = d->stride, ka = (d->kh - 1) / s + 1, OHp = d->oh + ka - 1, OWp = d->ow + ka - 1, CB = (d->cin * s * s + 7) / 8;
+    if (d->cin == 3 && s == 4) {
+        const int64_t t2 = (int64_t)n * 2 * OHp * OWp;
+        hipLaunchKernelGGL(input_prep_u8_s2d_c3s4_kernel, dim3((unsigned)((t2 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, (uint4*)xb, d->h,
+                           d->w, raw_h, raw_w, crop_y, crop_x, mirror, mean_bgr, d->pt, d->pl, OHp, OWp, t2);
+        VL_LAUNCH_CHECK();
+        return 0;
+    }
     const int64_t total = (int64_t)n * CB * OHp * OWp;
     hipLaunchKernelGGL(input_prep_u8_s2d_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, (uint4*)xb, d->cin,
                        s, d->h, d->w, raw_h, raw_w, crop_y, crop_x, mirror, mean_bgr, d->pt, d->pl, OHp, OWp, CB, total);
