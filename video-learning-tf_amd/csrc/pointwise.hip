@@ -313,7 +313,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t pw_rsrc(const void* base, int6
 // then 8 channels starting at a multiple of 8: its outputs are channels c0 - 4 .. c0 + 3, i.e. the upper half of one 16-byte chunk and
 // the lower half of the next, each stored as ONE 8-byte word per pixel (4 bf16, rounded to nearest even).
 template <int CHK, int NST, bool RELU, bool C8 = false>
-__global__ __launch_bounds__(256) void pool_lrn_bwd_stream_kernel(const float* __restrict__ x, const float* __restrict__ dp,
+__global__ __launch_bounds__(256, (C8 ? 3 : 1)) void pool_lrn_bwd_stream_kernel(const float* __restrict__ x, const float* __restrict__ dp,
                                                                   const uint8_t* __restrict__ arg, float* __restrict__ dx, int C,
                                                                   int H, int W, int OH, int OW, int64_t ps_n, int ps_c, int ps_h,
                                                                   int64_t pooled_bytes_f, float alpha, float bias, int halo) {
