@@ -170,9 +170,10 @@ int vl_pool_lrn_bwd(const float* x, const float* dp, const uint8_t* argmax, floa
                     vl_stream_t stream);
 
 /* vl_pool_lrn_bwd with the gradient written as packed bf16 (dxb: "c8" layout of the bf16 conv path, dxb_halo; rounded to nearest
- * even) instead of fp32 dx -- the only form that path's wgrad / dgrad / bias gradient read. */
-int vl_pool_lrn_bwd_c8(const float* x, const float* dp, const uint8_t* argmax, void* dxb, int n, int c, int h, int w, int p_halo,
-                       int radius, float alpha, float beta, float bias, int relu_fused, int dxb_halo, vl_stream_t stream);
+ * even) instead of fp32 dx -- the only form that path's wgrad / dgrad / bias gradient read.  x_packed != 0: x (the LRN input) is packed
+ * as well, c8 without a halo, as the producing conv's epilogue writes it. */
+int vl_pool_lrn_bwd_c8(const void* x, int x_packed, const float* dp, const uint8_t* argmax, void* dxb, int n, int c, int h, int w,
+                       int p_halo, int radius, float alpha, float beta, float bias, int relu_fused, int dxb_halo, vl_stream_t stream);
 
 /* Fused forward of [LRN -> max_pool 3x3/2 VALID] (alexnet.py:79-98,120-139): p = max_pool(lrn(x)), argmax = window-local
  * index (0..8) of the first maximum in scan order; the LRN output is never written (vl_pool_lrn_bwd needs only x).
@@ -181,9 +182,9 @@ int vl_lrn_pool_fwd(const float* x, float* p, uint8_t* argmax, int n, int c, int
                     float alpha, float beta, float bias, vl_stream_t stream);
 
 /* vl_lrn_pool_fwd with the pooled output written as packed bf16 (pb: "c8" layout of the bf16 conv path, p_halo) instead of fp32 p:
- * the next conv's operand.  argmax as vl_lrn_pool_fwd. */
-int vl_lrn_pool_fwd_c8(const float* x, void* pb, uint8_t* argmax, int n, int c, int h, int w, int p_halo, int radius, float alpha,
-                       float beta, float bias, vl_stream_t stream);
+ * the next conv's operand.  argmax as vl_lrn_pool_fwd.  x_packed != 0: x is packed as well (c8 without a halo). */
+int vl_lrn_pool_fwd_c8(const void* x, int x_packed, void* pb, uint8_t* argmax, int n, int c, int h, int w, int p_halo, int radius,
+                       float alpha, float beta, float bias, vl_stream_t stream);
 
 /* ---- tf.nn.max_pool k x k, stride s, VALID (alexnet.py:91-98,132-139,204-211) ------------------
  * x NCHW [n][c][h][w]; y element (n,c,oh,ow) is stored at y[n*ys_n + c*ys_c + oh*ys_h + ow*ys_w]

@@ -281,3 +281,27 @@ def test_lrn_pool_fwd_packed_output(ops, n, h, w, c, halo):
     ops.pack_c8(p, want, halo, halo)
     torch.cuda.synchronize()
     assert torch.equal(pb, want) and torch.equal(arg, arg2) and float(pb.float().abs().max()) > 0
+
+
+@pytest.mark.parametrize("n,h,w,c", [(2, 9, 7, 96), (3, 28, 28, 256), (1, 57, 57, 96), (2, 13, 11, 20)])
+def test_pool_kernels_read_the_packed_conv_output(ops, n, h, w, c):
+    """x_packed: the LRN input handed over as the conv epilogue wrote it (bf16 c8, no halo).  Same results, bit for bit, as the fp32
+    input holding the same (bf16-representable) values."""
+    rng = np.random.default_rng(c * h)
+    x = bf16_round(np.maximum(rng.standard_normal((n, h, w, c)) * 30, 0))
+    xf = torch.from_numpy(nchw(x)).to(DEV)
+    xp = to_c8(x, 0)
+    oh, ow = ops.pool_out(h), ops.pool_out(w)
+    shape = (n, c, oh + 2, ow + 2)
+    pb1, pb2 = (torch.zeros(ops.c8_shape(n, c, oh, ow, 1), dtype=torch.bfloat16, device=DEV) for _ in range(2))
+    a1, a2 = (torch.zeros(shape, dtype=torch.uint8, device=DEV) for _ in range(2))
+    ops.lrn_pool_fwd_c8(xf, pb1, a1, p_halo=1)
+    ops.lrn_pool_fwd_c8(xp, pb2, a2, p_halo=1, channels=c)
+    dp = torch.zeros(shape, device=DEV)
+    dp[:, :, 1:-1, 1:-1] = torch.from_numpy(rng.standard_normal((n, c, oh, ow)).astype(np.float32)).to(DEV)
+    d1, d2 = (torch.zeros(ops.c8_shape(n, c, h, w, 2), dtype=torch.bfloat16, device=DEV) for _ in range(2))
+    ops.pool_lrn_bwd_c8(xf, dp, a1, d1, p_halo=1, dxb_halo=2)
+    ops.pool_lrn_bwd_c8(xp, dp, a1, d2, p_halo=1, dxb_halo=2)
+    torch.cuda.synchronize()
+    assert torch.equal(pb1, pb2) and torch.equal(a1, a2) and torch.equal(d1, d2)
+    assert float(pb1.float().abs().max()) > 0 and float(d1.float().abs().max()) > 0

@@ -312,7 +312,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t pw_rsrc(const void* base, int6
 // C8: dx is the packed-bf16 "c8" gradient [image][C / 8][H + 2 halo][W + 2 halo][8] (conv_c8.hip) instead of fp32 NCHW.  The chunk is
 // then 8 channels starting at a multiple of 8: its outputs are channels c0 - 4 .. c0 + 3, i.e. the upper half of one 16-byte chunk and
 // the lower half of the next, each stored as ONE 8-byte word per pixel (4 bf16, rounded to nearest even).
-template <int CHK, int NST, bool RELU, bool C8 = false>
+// C8 == 2: x (the LRN input = the conv's ReLU output) is packed too, [image][C / 8][H][W][8] bf16 without a halo: one 16-byte load
+// per pixel brings a chunk's 8 channels.
+template <int CHK, int NST, bool RELU, int C8 = 0>
 __global__ __launch_bounds__(256, (C8 ? 3 : 1)) void pool_lrn_bwd_stream_kernel(const float* __restrict__ x, const float* __restrict__ dp,
                                                                   const uint8_t* __restrict__ arg, float* __restrict__ dx, int C,
                                                                   int H, int W, int OH, int OW, int64_t ps_n, int ps_c, int ps_h,
@@ -360,16 +362,18 @@ __global__ __launch_bounds__(256, (C8 ? 3 : 1)) void pool_lrn_bwd_stream_kernel(
     }
     const uint32_t slab_bytes = (uint32_t)rowlen * 8u;
 
-    const __amdgpu_buffer_rsrc_t rs_x = pw_rsrc(x + (int64_t)img * C * HW, (int64_t)C * HW * 4);
+    const __amdgpu_buffer_rsrc_t rs_x = C8 == 2 ? pw_rsrc(reinterpret_cast<const char*>(x) + (int64_t)img * ((C + 7) / 8) * HW * 16,
+                                                          (int64_t)((C + 7) / 8) * HW * 16)
+                                                : pw_rsrc(x + (int64_t)img * C * HW, (int64_t)C * HW * 4);
     const int wp = W + 2 * halo;
     const int dplane = (H + 2 * halo) * wp;
-    static_assert(!C8 || CHK == 8, "packed output: 8-channel chunks");
+    static_assert(C8 == 0 || CHK == 8, "packed output: 8-channel chunks");
     const int CB = (C + 7) / 8;
     const __amdgpu_buffer_rsrc_t rs_dx = C8 ? pw_rsrc(reinterpret_cast<const char*>(dx) + (int64_t)img * CB * dplane * 16, (int64_t)CB * dplane * 16)
                                             : pw_rsrc(dx + (int64_t)img * C * dplane, (int64_t)C * dplane * 4);
     const __amdgpu_buffer_rsrc_t rs_dp = pw_rsrc(dp + (int64_t)img * ps_n, pooled_bytes_f);
     const __amdgpu_buffer_rsrc_t rs_arg = pw_rsrc(arg + (int64_t)img * ps_n, pooled_bytes_f / 4);
-    const uint32_t voff_x = valid ? (uint32_t)p * 4u : PW_OOB;
+    const uint32_t voff_x = valid ? (uint32_t)p * (C8 == 2 ? 16u : 4u) : PW_OOB;
     const uint32_t voff_dx = valid ? (uint32_t)((py + halo) * wp + px + halo) * (C8 ? 16u : 4u) : PW_OOB;
     const int x_cs = HW * 4, dx_cs = dplane * 4;                      // channel strides in bytes
 
@@ -391,10 +395,20 @@ __global__ __launch_bounds__(256, (C8 ? 3 : 1)) void pool_lrn_bwd_stream_kernel(
     };
     float xa[CHK], xb[CHK];
     auto x_load = [&](int c0, float (&v)[CHK]) {
+        if constexpr (C8 == 2) {                                      // c0 is a multiple of 8: one chunk; blocks past C answer 0
+            typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+            const u4 w = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)(c0 < C ? voff_x : PW_OOB), (c0 >> 3) * HW * 16, 0));
 #pragma unroll
-        for (int i = 0; i < CHK; ++i) {
-            const int cc = c0 + i;                                    // uniform; channels past C: the range check answers 0
-            v[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, (int)(cc < C ? voff_x : PW_OOB), cc * x_cs, 0));
+            for (int i = 0; i < 4; ++i) {
+                v[2 * i] = __uint_as_float(w[i] << 16);
+                v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < CHK; ++i) {
+                const int cc = c0 + i;                                    // uniform; channels past C: the range check answers 0
+                v[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, (int)(cc < C ? voff_x : PW_OOB), cc * x_cs, 0));
+            }
         }
     };
 
@@ -436,7 +450,7 @@ __global__ __launch_bounds__(256, (C8 ? 3 : 1)) void pool_lrn_bwd_stream_kernel(
             a += tw0; a += tw1; a += tw2; a += tw3; a += tw4;
             float r = uw0 - k2ab * xw0 * a;
             if (RELU) r = xw0 > 0.f ? r : 0.f;
-            if constexpr (C8) {
+            if constexpr (C8 != 0) {
                 rr[i & 3] = r;
                 if ((i & 3) == 3) {                                   // channels oc - 3 .. oc: half a chunk of block (oc - 3) >> 3
                     typedef float f2 __attribute__((ext_vector_type(2)));
@@ -497,10 +511,10 @@ extern "C" int vl_pool_lrn_bwd(const float* x, const float* dp, const uint8_t* a
 #define VL_PLB_LAUNCH(CHK, NST)                                                                                                     \
     do {                                                                                                                            \
         if (relu_fused)                                                                                                             \
-            hipLaunchKernelGGL((pool_lrn_bwd_stream_kernel<CHK, NST, true>), grid, dim3(256), 0, (hipStream_t)stream, x, dp + origin, \
+            hipLaunchKernelGGL((pool_lrn_bwd_stream_kernel<CHK, NST, true, 0>), grid, dim3(256), 0, (hipStream_t)stream, x, dp + origin, \
                                argmax + origin, dx, c, h, w, oh, ow, psn, (int)pplane, owp, pooled_f, alpha, bias, dx_halo);        \
         else                                                                                                                        \
-            hipLaunchKernelGGL((pool_lrn_bwd_stream_kernel<CHK, NST, false>), grid, dim3(256), 0, (hipStream_t)stream, x, dp + origin, \
+            hipLaunchKernelGGL((pool_lrn_bwd_stream_kernel<CHK, NST, false, 0>), grid, dim3(256), 0, (hipStream_t)stream, x, dp + origin, \
                                argmax + origin, dx, c, h, w, oh, ow, psn, (int)pplane, owp, pooled_f, alpha, bias, dx_halo);        \
         VL_LAUNCH_CHECK();                                                                                                          \
         return 0;                                                                                                                   \
@@ -528,8 +542,8 @@ extern "C" int vl_pool_lrn_bwd(const float* x, const float* dp, const uint8_t* a
 
 /* vl_pool_lrn_bwd writing the packed-bf16 gradient dxb ("c8" layout of conv_c8.hip, dxb_halo) instead of fp32 dx: what the bf16 conv
  * path's wgrad / dgrad / bias gradient read.  Channel-stream form only (beta 0.75, planes that fit its staging). */
-extern "C" int vl_pool_lrn_bwd_c8(const float* x, const float* dp, const uint8_t* argmax, void* dxb, int n, int c, int h, int w, int p_halo,
-                                  int radius, float alpha, float beta, float bias, int relu_fused, int dxb_halo, vl_stream_t stream) {
+extern "C" int vl_pool_lrn_bwd_c8(const void* x, int x_packed, const float* dp, const uint8_t* argmax, void* dxb, int n, int c, int h, int w,
+                                  int p_halo, int radius, float alpha, float beta, float bias, int relu_fused, int dxb_halo, vl_stream_t stream) {
     VL_CHECK(x && dp && argmax && dxb && n > 0 && c > 0 && h >= 3 && w >= 3 && p_halo >= 0 && dxb_halo >= 0, "vl_pool_lrn_bwd_c8: bad argument");
     VL_CHECK(radius == 2 && beta == 0.75f, "vl_pool_lrn_bwd_c8: only depth_radius 2, beta 0.75 are built (alexnet.py:81-84)");
     VL_CHECK(n <= 65535, "vl_pool_lrn_bwd_c8: batch %d exceeds the grid limit", n);
@@ -544,12 +558,15 @@ extern "C" int vl_pool_lrn_bwd_c8(const float* x, const float* dp, const uint8_t
              "vl_pool_lrn_bwd_c8: plane too large for the channel-stream form");
     const dim3 grid(ceil_div((int64_t)h * w, 256), n);
     const int64_t psn = (int64_t)c * pplane;
-    if (relu_fused)
-        hipLaunchKernelGGL((pool_lrn_bwd_stream_kernel<8, 5, true, true>), grid, dim3(256), 0, (hipStream_t)stream, x, dp + origin, argmax + origin,
-                           (float*)dxb, c, h, w, oh, ow, psn, (int)pplane, owp, pooled_f, alpha, bias, dxb_halo);
-    else
-        hipLaunchKernelGGL((pool_lrn_bwd_stream_kernel<8, 5, false, true>), grid, dim3(256), 0, (hipStream_t)stream, x, dp + origin, argmax + origin,
-                           (float*)dxb, c, h, w, oh, ow, psn, (int)pplane, owp, pooled_f, alpha, bias, dxb_halo);
+    const float* xf = (const float*)x;
+#define VL_PLBC(RELU, MODE)                                                                                                             \
+    hipLaunchKernelGGL((pool_lrn_bwd_stream_kernel<8, 5, RELU, MODE>), grid, dim3(256), 0, (hipStream_t)stream, xf, dp + origin, argmax + origin, \
+                       (float*)dxb, c, h, w, oh, ow, psn, (int)pplane, owp, pooled_f, alpha, bias, dxb_halo)
+    if (relu_fused && x_packed) VL_PLBC(true, 2);
+    else if (relu_fused) VL_PLBC(true, 1);
+    else if (x_packed) VL_PLBC(false, 2);
+    else VL_PLBC(false, 1);
+#undef VL_PLBC
     VL_LAUNCH_CHECK();
     return 0;
 }
@@ -588,7 +605,8 @@ extern "C" int vl_lrn_bwd(const float* x, const float* dy, float* dx, int n, int
 // strict-> first maximum of 9 LDS reads, exactly vl_maxpool_fwd's scan order, and are stored in the pool-output halo layout.
 // C8: pout is the packed-bf16 "c8" tensor [image][C / 8][pooled plane][8] (conv_c8.hip) instead of fp32 NCHW: each pooled output is
 // stored as one bf16 (nearest even) at its channel's slot of the pixel's chunk; the arg-max map is unchanged.
-template <int CHK, int PPT, int NSL, bool C8 = false>
+// C8 == 2: x is packed too ([image][C / 8][H][W][8] bf16, no halo): a 16-byte load per pixel brings 8 channels = four 2-channel chunks.
+template <int CHK, int PPT, int NSL, int C8 = 0>
 __global__ __launch_bounds__(512) void lrn_pool_fwd_kernel(const float* __restrict__ x, float* __restrict__ pout,
                                                            uint8_t* __restrict__ argout, int C, int H, int W, int OH, int OW, int prb,
                                                            int pplane, int owp, int p_halo, float alpha, float bias) {
@@ -600,9 +618,10 @@ __global__ __launch_bounds__(512) void lrn_pool_fwd_kernel(const float* __restri
     const int npix = (2 * nprow + 1) * W;                             // input pixels of this band
     const int p_base = 2 * oh_a * W;
     const int HW = H * W;
-    const __amdgpu_buffer_rsrc_t rs_x = pw_rsrc(x + (int64_t)img * C * HW, (int64_t)C * HW * 4);
     const int CB = (C + 7) / 8;
-    const __amdgpu_buffer_rsrc_t rs_p = C8 ? pw_rsrc(reinterpret_cast<const char*>(pout) + (int64_t)img * CB * pplane * 16, (int64_t)CB * pplane * 16)
+    const __amdgpu_buffer_rsrc_t rs_x = C8 == 2 ? pw_rsrc(reinterpret_cast<const char*>(x) + (int64_t)img * CB * HW * 16, (int64_t)CB * HW * 16)
+                                                : pw_rsrc(x + (int64_t)img * C * HW, (int64_t)C * HW * 4);
+    const __amdgpu_buffer_rsrc_t rs_p = C8 != 0 ? pw_rsrc(reinterpret_cast<const char*>(pout) + (int64_t)img * CB * pplane * 16, (int64_t)CB * pplane * 16)
                                            : pw_rsrc(pout + (int64_t)img * C * pplane, (int64_t)C * pplane * 4);
     const __amdgpu_buffer_rsrc_t rs_a = pw_rsrc(argout + (int64_t)img * C * pplane, (int64_t)C * pplane);
     uint32_t voff_x[PPT];
@@ -611,7 +630,7 @@ __global__ __launch_bounds__(512) void lrn_pool_fwd_kernel(const float* __restri
     for (int q = 0; q < PPT; ++q) {
         const int pix = threadIdx.x + q * T;
         lpix[q] = pix < npix ? pix : -1;
-        voff_x[q] = pix < npix ? (uint32_t)(p_base + pix) * 4u : PW_OOB;
+        voff_x[q] = pix < npix ? (uint32_t)(p_base + pix) * (C8 == 2 ? 16u : 4u) : PW_OOB;
     }
     // pooled outputs of a chunk: o = tid + s T  <->  (slab ci, pooled row, pooled column)
     int s_lds[NSL], s_out[NSL];                                       // LDS float offset of the window origin | ci << 24 | output element offset
@@ -678,7 +697,7 @@ __global__ __launch_bounds__(512) void lrn_pool_fwd_kernel(const float* __restri
                         }
                     }
                 const int off = c * pplane + (s_out[sl] & 0xffffff);
-                if constexpr (C8) {
+                if constexpr (C8 != 0) {
                     const __bf16 hb = (__bf16)best;
                     __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(uint16_t, hb), rs_p,
                                                           ((c >> 3) * pplane + (s_out[sl] & 0xffffff)) * 16 + (c & 7) * 2, 0, 0);
@@ -690,6 +709,34 @@ __global__ __launch_bounds__(512) void lrn_pool_fwd_kernel(const float* __restri
         }
     };
     const int nchunks = (C + 2 + CHK - 1) / CHK;
+    if constexpr (C8 == 2) {
+        static_assert(C8 != 2 || CHK == 2, "packed input: 2-channel chunks (one dword of a pixel's 16-byte block)");
+        typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+        u4 cur[PPT], nxt[PPT];
+        auto blk_load = [&](int kb, u4 (&v)[PPT]) {                   // channels 8 kb .. 8 kb + 7; blocks past C answer 0
+#pragma unroll
+            for (int q = 0; q < PPT; ++q)
+                v[q] = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)(kb < CB ? voff_x[q] : PW_OOB), kb * HW * 16, 0));
+        };
+        blk_load(0, cur);
+        for (int kb = 0; kb * 4 < nchunks; ++kb) {
+            blk_load(kb + 1, nxt);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (kb * 4 + j >= nchunks) break;
+                float xin[PPT][CHK];
+#pragma unroll
+                for (int q = 0; q < PPT; ++q) {
+                    xin[q][0] = __uint_as_float(cur[q][j] << 16);
+                    xin[q][1] = __uint_as_float(cur[q][j] & 0xffff0000u);
+                }
+                chunk((kb * 4 + j) * CHK, j & 1, xin);
+            }
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) cur[q] = nxt[q];
+        }
+        return;
+    }
     x_load(0, xa);
     for (int k = 0; k < nchunks; k += 2) {                            // unrolled by two: the x registers alternate without copies
         x_load((k + 1) * CHK, xb);
@@ -700,7 +747,7 @@ __global__ __launch_bounds__(512) void lrn_pool_fwd_kernel(const float* __restri
     }
 }
 
-template <int CHK, int PPT, int NSL, bool C8 = false>
+template <int CHK, int PPT, int NSL, int C8 = 0>
 static int launch_lrn_pool_fwd(const float* x, float* p, uint8_t* argmax, int n, int c, int h, int w, int p_halo, float alpha, float bias,
                                hipStream_t stream) {
     const int oh = (h - 3) / 2 + 1, ow = (w - 3) / 2 + 1;
@@ -756,8 +803,8 @@ extern "C" int vl_lrn_pool_fwd(const float* x, float* p, uint8_t* argmax, int n,
 
 /* vl_lrn_pool_fwd with the pooled output written as packed bf16 (pb: "c8" layout of the bf16 conv path, p_halo; nearest even) instead of
  * fp32 p -- the next conv's operand; argmax keeps the fp32 form's NCHW layout with p_halo. */
-extern "C" int vl_lrn_pool_fwd_c8(const float* x, void* pb, uint8_t* argmax, int n, int c, int h, int w, int p_halo, int radius, float alpha,
-                                  float beta, float bias, vl_stream_t stream) {
+extern "C" int vl_lrn_pool_fwd_c8(const void* x, int x_packed, void* pb, uint8_t* argmax, int n, int c, int h, int w, int p_halo, int radius,
+                                  float alpha, float beta, float bias, vl_stream_t stream) {
     VL_CHECK(x && pb && argmax && n > 0 && c > 0 && h >= 3 && w >= 3 && p_halo >= 0, "vl_lrn_pool_fwd_c8: bad argument");
     VL_CHECK(radius == 2 && beta == 0.75f, "vl_lrn_pool_fwd_c8: only depth_radius 2, beta 0.75 are built (alexnet.py:81-84)");
     VL_CHECK(n <= 65535, "vl_lrn_pool_fwd_c8: batch %d exceeds the grid limit", n);
@@ -765,7 +812,8 @@ extern "C" int vl_lrn_pool_fwd_c8(const float* x, void* pb, uint8_t* argmax, int
     const int64_t pplane = (int64_t)(oh + 2 * p_halo) * (ow + 2 * p_halo);
     VL_CHECK((int64_t)(c + 16) * h * w * 4 < (1ll << 31) && (int64_t)((c + 7) / 8) * pplane * 16 < (1ll << 31) && pplane < (1 << 24),
              "vl_lrn_pool_fwd_c8: image too large for 32-bit buffer offsets");
-    return launch_lrn_pool_fwd<2, 2, 1, true>(x, (float*)pb, argmax, n, c, h, w, p_halo, alpha, bias, (hipStream_t)stream);
+    if (x_packed) return launch_lrn_pool_fwd<2, 2, 1, 2>((const float*)x, (float*)pb, argmax, n, c, h, w, p_halo, alpha, bias, (hipStream_t)stream);
+    return launch_lrn_pool_fwd<2, 2, 1, 1>((const float*)x, (float*)pb, argmax, n, c, h, w, p_halo, alpha, bias, (hipStream_t)stream);
 }
 
 // ---- max-pool VALID (alexnet.py:91-98) --------------------------------------------------------

@@ -252,6 +252,10 @@ class LRCNEngine:
                     L["dyb"] = cbuf(conv.cout, conv.oh, conv.ow, L["dy_halo"])
                     L["wbt"] = torch.zeros(conv.c8_w_bytes(True), dtype=torch.uint8, device=dev)
                     ws_bytes = max(ws_bytes, conv.c8_wgrad_ws_bytes(N))
+            # the LRN layers' conv outputs are written packed only (no halo): lrn_pool_fwd_c8 / pool_lrn_bwd_c8 read them packed
+            for L in self.layers:
+                if L["lrn"] and L["pool"]:
+                    L["yb"] = cbuf(L["conv"].cout, L["conv"].oh, L["conv"].ow, 0)
             # conv1 (strided, 3 channels) runs the same kernels as the equivalent stride-1 layer over its space-to-depth input
             L0 = self.layers[0]
             eq = L0["eq"] = L0["conv"].s2d_layer()
@@ -462,19 +466,19 @@ class LRCNEngine:
                     conv.s2d_c8_from_x0(x, L["xb"][:n])
                 conv.s2d_weights(P["dcnn/%sW" % name], L["ws2d"])
                 L["eq"].c8_pack_w(L["ws2d"], L["wb"], False)
-                self._run(name + ".fwd", L["eq"].c8_fwd, L["xb"][:n], L["wb"], P["dcnn/%sb" % name], y=L["y"][:n], relu=True)
+                self._run(name + ".fwd", L["eq"].c8_fwd, L["xb"][:n], L["wb"], P["dcnn/%sb" % name], yb=L["yb"][:n], relu=True)
             elif self.c8:
                 # bf16 path: packed operands; a conv that feeds the next conv directly also writes that conv's packed input
                 L["conv"].c8_pack_w(P["dcnn/%sW" % name], L["wb"], False)
-                yb = nxt["xb"][:n] if (nxt is not None and not L["pool"]) else None
-                y = L["y"][:n] if yb is None else None       # fp32 output only where a pool / LRN kernel reads it
+                yb = nxt["xb"][:n] if (nxt is not None and not L["pool"]) else (L["yb"][:n] if "yb" in L else None)
+                y = L["y"][:n] if yb is None else None       # fp32 output only where the plain max-pool reads it (conv5)
                 self._run(name + ".fwd", L["conv"].c8_fwd, L["xb"][:n], L["wb"], P["dcnn/%sb" % name], y=y, yb=yb, relu=True)
             else:
                 self._run(name + ".fwd", L["conv"].fwd, x, P["dcnn/%sW" % name], P["dcnn/%sb" % name], L["y"][:n], relu=True)
             x = L["y"][:n]
             if L["lrn"] and L["pool"] and self.c8:
                 # bf16 path: the pooled output is only ever the next conv's packed operand -- written packed, fp32 p stays unused
-                ops.lrn_pool_fwd_c8(x, nxt["xb"][:n], L["arg"][:n], p_halo=L["p_halo"], **LRN)
+                ops.lrn_pool_fwd_c8(L["yb"][:n], nxt["xb"][:n], L["arg"][:n], p_halo=L["p_halo"], channels=L["conv"].cout, **LRN)
                 x = None
             elif L["lrn"] and L["pool"]:
                 # LRN + pool in one pass: the LRN output is only ever the pool's input and is never stored
@@ -644,7 +648,7 @@ class LRCNEngine:
             dy = L["dy"][:n]
             if L["pool"] and L["lrn"] and self.c8:
                 # bf16 path: the gradient is only ever read packed (wgrad, dgrad, bias gradient) -- written packed, fp32 dy stays unused
-                ops.pool_lrn_bwd_c8(L["y"][:n], L["dp"][:n], L["arg"][:n], L["dyb"][:n], p_halo=L["p_halo"],
+                ops.pool_lrn_bwd_c8(L["yb"][:n], L["dp"][:n], L["arg"][:n], L["dyb"][:n], p_halo=L["p_halo"],
                                     dxb_halo=(L["eq"].dy_halo if li == 0 else L["dy_halo"]), relu_fused=True, **LRN)
             elif L["pool"] and L["lrn"]:
                 # pool -> LRN -> ReLU backward in one pass: d(lrn out) is never written

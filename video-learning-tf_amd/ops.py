@@ -337,15 +337,27 @@ def lrn_pool_fwd(x, p, argmax, p_halo=0, radius=2, alpha=2e-5, beta=0.75, bias=1
     _ffi.call("vl_lrn_pool_fwd", _p(x), _p(p), _p(argmax), n, c, h, w, p_halo, radius, alpha, beta, bias, stream())
 
 
-def lrn_pool_fwd_c8(x, pb, argmax, p_halo=0, radius=2, alpha=2e-5, beta=0.75, bias=1.0):
-    """lrn_pool_fwd with the pooled output written as packed bf16 (c8 layout, p_halo): the next conv's operand on the bf16 path."""
-    _f32(x); _dense(x, pb, argmax)
-    n, c, h, w = x.shape
+def _x_or_packed(x, c):
+    """(packed?, n, h, w) of a pool / LRN input: fp32 NCHW, or bf16 c8 without a halo ([n][c/8][h][w][8]) of c channels."""
+    if x.dtype == torch.bfloat16:
+        if x.dim() != 5 or x.shape[4] != 8 or c is None or x.shape[1] != (c + 7) // 8 or not x.is_contiguous():
+            raise _ffi.VltfError("packed pool input must be a contiguous bf16 [n][c/8][h][w][8] tensor and needs channels=")
+        return 1, x.shape[0], x.shape[2], x.shape[3]
+    _f32(x)
+    return 0, x.shape[0], x.shape[2], x.shape[3]
+
+
+def lrn_pool_fwd_c8(x, pb, argmax, p_halo=0, radius=2, alpha=2e-5, beta=0.75, bias=1.0, channels=None):
+    """lrn_pool_fwd with the pooled output written as packed bf16 (c8 layout, p_halo): the next conv's operand on the bf16 path.
+    x: fp32 NCHW, or the packed conv output (bf16 c8, no halo; pass channels=)."""
+    _dense(x, pb, argmax)
+    c = channels if channels is not None else x.shape[1]
+    packed, n, h, w = _x_or_packed(x, c)
     oh, ow = pool_out(h), pool_out(w)
     if pb.dtype != torch.bfloat16 or tuple(pb.shape) != c8_shape(n, c, oh, ow, p_halo) or \
             tuple(argmax.shape) != (n, c, oh + 2 * p_halo, ow + 2 * p_halo):
         raise _ffi.VltfError("lrn_pool_fwd_c8: shape mismatch x=%s pb=%s argmax=%s" % (tuple(x.shape), tuple(pb.shape), tuple(argmax.shape)))
-    _ffi.call("vl_lrn_pool_fwd_c8", _p(x), _p(pb), _p(argmax), n, c, h, w, p_halo, radius, alpha, beta, bias, stream())
+    _ffi.call("vl_lrn_pool_fwd_c8", _p(x), packed, _p(pb), _p(argmax), n, c, h, w, p_halo, radius, alpha, beta, bias, stream())
 
 
 def pool_lrn_bwd(x, dp, argmax, dx, p_halo=0, dx_halo=0, radius=2, alpha=2e-5, beta=0.75, bias=1.0, relu_fused=True):
@@ -361,14 +373,16 @@ def pool_lrn_bwd(x, dp, argmax, dx, p_halo=0, dx_halo=0, radius=2, alpha=2e-5, b
 
 
 def pool_lrn_bwd_c8(x, dp, argmax, dxb, p_halo=0, dxb_halo=0, radius=2, alpha=2e-5, beta=0.75, bias=1.0, relu_fused=True):
-    """pool_lrn_bwd with the gradient written as packed bf16 (c8 layout, dxb_halo): the bf16 conv path's operand."""
-    _f32(x, dp); _dense(x, dp, argmax, dxb)
-    n, c, h, w = x.shape
+    """pool_lrn_bwd with the gradient written as packed bf16 (c8 layout, dxb_halo): the bf16 conv path's operand.
+    x: fp32 NCHW, or the packed conv output (bf16 c8, no halo)."""
+    _f32(dp); _dense(x, dp, argmax, dxb)
+    c = dp.shape[1]
+    packed, n, h, w = _x_or_packed(x, c)
     oh, ow = pool_out(h), pool_out(w)
     if tuple(dp.shape) != (n, c, oh + 2 * p_halo, ow + 2 * p_halo) or tuple(argmax.shape) != tuple(dp.shape) or \
             dxb.dtype != torch.bfloat16 or tuple(dxb.shape) != c8_shape(n, c, h, w, dxb_halo):
         raise _ffi.VltfError("pool_lrn_bwd_c8: shape mismatch x=%s dp=%s dxb=%s" % (tuple(x.shape), tuple(dp.shape), tuple(dxb.shape)))
-    _ffi.call("vl_pool_lrn_bwd_c8", _p(x), _p(dp), _p(argmax), _p(dxb), n, c, h, w, p_halo, radius, alpha, beta, bias, int(relu_fused),
+    _ffi.call("vl_pool_lrn_bwd_c8", _p(x), packed, _p(dp), _p(argmax), _p(dxb), n, c, h, w, p_halo, radius, alpha, beta, bias, int(relu_fused),
               dxb_halo, stream())
 
 
