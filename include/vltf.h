@@ -135,6 +135,14 @@ size_t vl_conv_c8_wgrad_ws_bytes(const vl_conv_desc* d, int n);
 int vl_conv_c8_wgrad(vl_conv_desc* d, const void* xb, const void* dyb, float* dw, void* ws, size_t ws_bytes, int n,
                      vl_stream_t stream);
 int vl_bias_grad_c8(const void* dyb, float* db, float* ws, int n, int c, int h, int w, int halo, vl_stream_t stream);
+/* Dense products on the same pipeline (fc6 of the bf16 path): c[m][n] = sum_k a[k][m] b[k][n] (+ bias[n]) (ReLU) with both operands
+ * reduction-major in 8-channel blocks, "kc8" = [ceil(channels / 8)][k][8] bf16 -- what the wgrad kernel consumes.
+ *   vl_pack_kc8   dst = src[position * pos_stride + channel * ch_stride] (fp32, any strides: a matrix or its transpose) in kc8
+ *   vl_gemm_kc8   the product (fp32 out, row-major; m, n multiples of 8); ws: vl_gemm_kc8_ws_bytes (split-k slabs, fixed order) */
+int vl_pack_kc8(const float* src, void* dst, int64_t positions, int channels, int64_t pos_stride, int64_t ch_stride, vl_stream_t stream);
+size_t vl_gemm_kc8_ws_bytes(int m, int n, int k);
+int vl_gemm_kc8(const void* a_kc8, const void* b_kc8, float* c, int m, int n, int k, const float* bias, int relu, void* ws,
+                size_t ws_bytes, vl_stream_t stream);
 /* A strided first layer (conv1: 11 x 11 / 4 over 3 channels) on the same kernels: with kh = s a + py, kw = s b + px it is a ka x ka
  * (ka = ceil(k / s), odd) STRIDE-1 layer over the cin s^2 channels (c, py, px) of the space-to-depth input -- identical products and
  * sums, plus multiplies by zero where s a + py >= k.  The caller creates that layer's descriptor (cin s^2, oh, ow, cout, ka, ka, 1, 1;

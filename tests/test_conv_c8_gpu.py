@@ -305,3 +305,32 @@ def test_pool_kernels_read_the_packed_conv_output(ops, n, h, w, c):
     torch.cuda.synchronize()
     assert torch.equal(pb1, pb2) and torch.equal(a1, a2) and torch.equal(d1, d2)
     assert float(pb1.float().abs().max()) > 0 and float(d1.float().abs().max()) > 0
+
+
+@pytest.mark.parametrize("m,n,k,bias,relu", [(256, 128, 64, False, False), (256, 256, 1000, False, False), (64, 72, 333, True, True),
+                                              (1024, 512, 2304, True, False), (8, 8, 5, False, True)])
+def test_dense_product_on_the_wgrad_kernel(ops, m, n, k, bias, relu):
+    """vl_pack_kc8 + vl_gemm_kc8: c = a^T b (+ bias) (ReLU) with bf16 products, against fp64 on the bf16-rounded operands; operands
+    packed from a matrix and from a transposed view (strides); split-k slabs, the direct (one slab) form and ragged k."""
+    rng = np.random.default_rng(m + n + k)
+    a = rng.standard_normal((k, m)).astype(np.float32)           # [k][m]
+    bt = rng.standard_normal((n, k)).astype(np.float32)          # b stored TRANSPOSED [n][k]: packed through strides
+    bv = rng.standard_normal(n).astype(np.float32) if bias else None
+    ad, btd = torch.from_numpy(a).to(DEV), torch.from_numpy(bt).to(DEV)
+    ak = torch.zeros(ops.kc8_shape(k, m), dtype=torch.bfloat16, device=DEV)
+    bk = torch.zeros(ops.kc8_shape(k, n), dtype=torch.bfloat16, device=DEV)
+    ops.pack_kc8(ad, ak, k, m, m, 1)                              # element (position kk, channel i) = a[kk][i]
+    ops.pack_kc8(btd, bk, k, n, 1, k)                             # element (position kk, channel j) = bt[j][kk]
+    c = torch.full((m, n), 7.0, device=DEV)
+    ws = torch.empty(max(ops.gemm_kc8_ws_bytes(m, n, k) // 4, 1), device=DEV)
+    ops.gemm_kc8(ak, bk, c, m, n, k, bias=None if bv is None else torch.from_numpy(bv).to(DEV), relu=relu, ws=ws)
+    want = bf16_round(a).astype(np.float64).T @ bf16_round(bt).astype(np.float64).T
+    if bv is not None:
+        want = want + bv
+    if relu:
+        want = np.maximum(want, 0)
+    torch.cuda.synchronize()
+    close(c.cpu().numpy(), want, msg="gemm_kc8")
+    c2 = torch.empty_like(c)
+    ops.gemm_kc8(ak, bk, c2, m, n, k, bias=None if bv is None else torch.from_numpy(bv).to(DEV), relu=relu, ws=ws)
+    assert torch.equal(c, c2)

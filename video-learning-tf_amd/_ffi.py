@@ -38,6 +38,9 @@ SIGNATURES = {
     "vl_conv_c8_pack_w": (i32, [p, p, p, i32, p]),
     "vl_conv_c8_fwd": (i32, [p, p, p, p, p, p, i32, i32, p]),
     "vl_conv_c8_dgrad": (i32, [p, p, p, p, p, p, p, i32, p]),
+    "vl_pack_kc8": (i32, [p, p, i64, i32, i64, i64, p]),
+    "vl_gemm_kc8_ws_bytes": (sz, [i32, i32, i32]),
+    "vl_gemm_kc8": (i32, [p, p, p, i32, i32, i32, p, i32, p, sz, p]),
     "vl_s2d_c8_from_x0": (i32, [p, p, p, i32, p]),
     "vl_input_prep_u8_s2d": (i32, [p, p, p, i32, i32, i32, p, p, p, p, p]),
     "vl_s2d_weights": (i32, [p, p, p, i32, p]),

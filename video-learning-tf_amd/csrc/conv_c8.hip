@@ -606,7 +606,8 @@ struct C8WgradArgs {
     const char* dy;       // c8 output gradient
     int64_t x_img, dy_img, x_grp, dy_grp, x_total, dy_total;   // bytes
     int64_t dy_plane;     // bytes per channel-block plane of dy
-    const int* toff;      // forward tap offsets (c8_toff_fwd)
+    const int* toff;      // forward tap offsets (c8_toff_fwd); null: tap t at t * tap_stride (dense products, vl_gemm_kc8)
+    int64_t tap_stride;
     int ntaps;            // real taps per group
     int Cog;              // output channels per group
     int L;                // positions swept per image
@@ -670,7 +671,7 @@ __global__ __launch_bounds__(64 * WA * WB) void wgrad_c8_kernel(const C8WgradArg
         const int id = (wave + j * NW) % C::NAI, sub = id / (KP / 4), pg = id % (KP / 4);
         int t = tap0 + sub * 16 + ch;
         t = t < a.ntaps ? t : 0;                                   // rows past the last tap: any valid address, discarded by the epilogue
-        voff_a[j] = (uint32_t)a.toff[t] + (uint32_t)(q4 * 16);
+        voff_a[j] = (a.toff ? (uint32_t)a.toff[t] : (uint32_t)(t * a.tap_stride)) + (uint32_t)(q4 * 16);
         grp_a[j] = pg;
         lds_a[j] = sub * KP * 256 + pg * 1024;
     }
@@ -1179,5 +1180,120 @@ extern "C" int vl_input_prep_u8_s2d(const vl_conv_desc* d, const uint8_t* src, v
     hipLaunchKernelGGL(input_prep_u8_s2d_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, (uint4*)xb, d->cin,
                        s, d->h, d->w, raw_h, raw_w, crop_y, crop_x, mirror, mean_bgr, d->pt, d->pl, OHp, OWp, CB, total);
     VL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- dense products on the wgrad kernel --------------------------------------------------------------------------------------------
+// C[m][n] = sum_k A[k][m] B[k][n] is what wgrad_c8_kernel computes when "positions" are k and both operands are stored position-major
+// in 8-channel blocks: "kc8" = [channel block][k][8] bf16 (one image, no halo, one tap per block of A).  fc6's three products are
+// this with (A, B) = (pool5^T, W), (dfc6^T, W^T), (pool5, dfc6): vl_pack_kc8 writes the operands from fp32 matrices with any strides.
+__global__ void pack_kc8_kernel(const float* __restrict__ src, uint4* __restrict__ dst, int64_t P, int C, int64_t ps, int64_t cs, int CB,
+                                int cb_fastest, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    // thread order follows the SOURCE's contiguous index: positions when cs != 1 (8 strided reads, coalesced over threads; one
+    // position per thread), channel blocks when cs == 1 (32 contiguous bytes per read, coalesced over threads; FOUR positions per
+    // thread so that its stores are 64 contiguous bytes: the chunks of one position are a whole plane apart)
+    const int PP = cb_fastest ? 4 : 1;
+    const int64_t pos0 = cb_fastest ? (idx / CB) * 4 : idx % P;
+    const int cb = cb_fastest ? (int)(idx % CB) : (int)(idx / P);
+    for (int q = 0; q < PP; ++q) {
+        const int64_t pos = pos0 + q;
+        if (pos >= P) break;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = cb * 8 + j;
+            v[j] = c < C ? src[pos * ps + (int64_t)c * cs] : 0.f;
+        }
+        uint4 o;
+        o.x = pack_bf16(v[0], v[1]);
+        o.y = pack_bf16(v[2], v[3]);
+        o.z = pack_bf16(v[4], v[5]);
+        o.w = pack_bf16(v[6], v[7]);
+        dst[(int64_t)cb * P + pos] = o;
+    }
+}
+
+/* dst (kc8: [ceil(channels / 8)][positions][8] bf16) = src[position * pos_stride + channel * ch_stride] rounded to bf16. */
+extern "C" int vl_pack_kc8(const float* src, void* dst, int64_t positions, int channels, int64_t pos_stride, int64_t ch_stride, vl_stream_t stream) {
+    VL_CHECK(src && dst && positions > 0 && channels > 0, "vl_pack_kc8: bad argument");
+    const int CB = (channels + 7) / 8;
+    const int64_t total = ch_stride == 1 ? ((positions + 3) / 4) * CB : positions * CB;
+    hipLaunchKernelGGL(pack_kc8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, (uint4*)dst, positions, channels,
+                       pos_stride, ch_stride, CB, ch_stride == 1 ? 1 : 0, total);
+    VL_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void gemm_kc8_reduce_kernel(const float* __restrict__ ws, float* __restrict__ c, int M, int N, int rowsP, int CoP, int slabs,
+                                       const float* __restrict__ bias, int relu) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)M * N) return;
+    const int col = (int)(idx % N), row = (int)(idx / N);
+    const float* p = ws + (int64_t)row * CoP + col;
+    float s = bias ? bias[col] : 0.f;
+    for (int z = 0; z < slabs; ++z) s += p[(int64_t)z * rowsP * CoP];
+    c[idx] = relu ? fmaxf(s, 0.f) : s;
+}
+
+static void gemm_kc8_plan(int m, int n, int k, int* tiles_a, int* tiles_b, int* slabs, int* slab_len) {
+    *tiles_a = (m / 8 + 31) / 32;            // 32 taps = 256 rows of C per tile
+    *tiles_b = (n + 127) / 128;
+    const int tiles = *tiles_a * *tiles_b;
+    const int64_t stages = ((int64_t)k + 31) / 32;
+    int s = (2 * 256) / tiles;
+    if (s > stages / 8) s = (int)(stages / 8);
+    if (s < 1) s = 1;
+    const int64_t per = (stages + s - 1) / s;
+    *slab_len = (int)(per * 32);
+    *slabs = (int)(((int64_t)k + *slab_len - 1) / *slab_len);
+}
+
+extern "C" size_t vl_gemm_kc8_ws_bytes(int m, int n, int k) {
+    if (m <= 0 || n <= 0 || k <= 0) return 0;
+    int ta, tb, slabs, sl;
+    gemm_kc8_plan(m, n, k, &ta, &tb, &slabs, &sl);
+    return (size_t)slabs * ta * 256 * tb * 128 * sizeof(float);
+}
+
+/* c[m][n] (fp32, row-major) = sum_k a[k][m] * b[k][n] (+ bias[n]) (ReLU), a and b in the kc8 layout of vl_pack_kc8 (bf16 products,
+ * fp32 accumulation); m, n multiples of 8.  ws: vl_gemm_kc8_ws_bytes (split-k slabs, summed in slab order). */
+extern "C" int vl_gemm_kc8(const void* a_kc8, const void* b_kc8, float* c, int m, int n, int k, const float* bias, int relu, void* ws,
+                           size_t ws_bytes, vl_stream_t stream) {
+    VL_CHECK(a_kc8 && b_kc8 && c && m > 0 && n > 0 && k > 0 && m % 8 == 0 && n % 8 == 0, "vl_gemm_kc8: bad argument (m, n multiples of 8)");
+    VL_CHECK((int64_t)k * 16 * ((m > n ? m : n) / 8) < MAX_BUF_BYTES, "vl_gemm_kc8: operand too large for 32-bit offsets");
+    C8WgPlan p;
+    memset(&p, 0, sizeof(p));
+    p.wa = 4; p.wb = 2; p.tb = 2;
+    gemm_kc8_plan(m, n, k, &p.tiles_a, &p.tiles_b, &p.slabs, &p.slab_len);
+    const bool direct = p.slabs == 1 && !bias && !relu && m % 256 == 0 && n % 128 == 0;   // one slab, nothing to add: straight into c
+    C8WgradArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = (const char*)a_kc8;
+    a.dy = (const char*)b_kc8;
+    a.dy_plane = (int64_t)k * 16;
+    a.tap_stride = a.dy_plane;
+    a.x_img = a.x_total = (int64_t)(m / 8) * a.dy_plane;
+    a.dy_img = a.dy_total = (int64_t)(n / 8) * a.dy_plane;
+    a.ntaps = m / 8;
+    a.Cog = n;
+    a.L = k;
+    a.qstart = 0;
+    a.nimg = 1;
+    a.Rtot = k;
+    a.slab_len = p.slab_len;
+    a.rowsP = direct ? m : p.tiles_a * 256;
+    a.CoP = direct ? n : p.tiles_b * 128;
+    a.ws = direct ? c : (float*)ws;
+    a.dL = make_fastdiv(k);
+    VL_CHECK(direct || (ws && ws_bytes >= (size_t)p.slabs * a.rowsP * a.CoP * sizeof(float)), "vl_gemm_kc8: workspace too small");
+    if (int rc = launch_c8_wgrad<4, 2, 2>(a, p, 1, (hipStream_t)stream)) return rc;
+    if (!direct) {
+        const int64_t total = (int64_t)m * n;
+        hipLaunchKernelGGL(gemm_kc8_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)ws, c, m, n,
+                           a.rowsP, a.CoP, p.slabs, bias, relu);
+        VL_LAUNCH_CHECK();
+    }
     return 0;
 }

@@ -267,6 +267,16 @@ class LRCNEngine:
                 L0["dws2d"] = torch.zeros(eq.w_shape, device=dev)
                 ws_bytes = max(ws_bytes, eq.c8_wgrad_ws_bytes(N))
         self.flat_dim = h * w * c
+        if self.c8 and N % 8 == 0:
+            # fc6's three products on the wgrad kernel (ops.gemm_kc8: reduction-major packed operands), DESIGN 4.7
+            F = self.flat_dim
+            kb = lambda count: torch.zeros(count, dtype=torch.bfloat16, device=dev)
+            self.k_act = kb(N * max(F, FC_DIM))            # the activation operand of the forward / input-gradient product
+            self.k_w = kb(F * FC_DIM)                      # fc6W, reduction-major for the forward, then for the input gradient
+            if training:
+                self.k_p5, self.k_d6 = kb(N * F), kb(N * FC_DIM)
+            for (gm, gn, gk) in ((N, FC_DIM, F), (N, F, FC_DIM), (F, FC_DIM, N)):
+                ws_bytes = max(ws_bytes, ops.gemm_kc8_ws_bytes(gm, gn, gk))
         self.f6 = buf(N, FC_DIM)
         self.f7 = buf(N, FC_DIM) if cfg.frame_encoding_layer != "fc6" else None
         self.f8 = buf(N, cfg.num_classes) if cfg.frame_encoding_layer not in ("fc6", "fc7") else None
@@ -452,6 +462,10 @@ class LRCNEngine:
         self._xb_fed = False
         return n, b
 
+    def _fc6_kc8(self, n):
+        """fc6 runs on the packed-operand product kernel: bf16 path, whole 8-frame blocks."""
+        return self.c8 and hasattr(self, "k_w") and n % 8 == 0
+
     # ---- forward -------------------------------------------------------------------------------
     def _forward(self, n, b, train):
         P, cfg = self.P, self.cfg
@@ -489,7 +503,15 @@ class LRCNEngine:
                 x = L["p"][:n]
             if self.c8 and L["pool"] and not L["lrn"] and nxt is not None:
                 ops.pack_c8(x, nxt["xb"][:n], L["p_halo"], nxt["x_halo"])
-        ops.gemm(x, P["dcnn/fc6W"], self.f6, n, FC_DIM, self.flat_dim, bias=P["dcnn/fc6b"], relu=True, ws=self.ws)
+        if self._fc6_kc8(n):
+            F = self.flat_dim
+            a = self.k_act[:n * F].view(ops.kc8_shape(F, n))
+            w = self.k_w.view(ops.kc8_shape(F, FC_DIM))
+            ops.pack_kc8(x, a, F, n, 1, F)                                    # (position f, channel frame) = pool5[frame][f]
+            ops.pack_kc8(P["dcnn/fc6W"], w, F, FC_DIM, FC_DIM, 1)
+            ops.gemm_kc8(a, w, self.f6, n, FC_DIM, F, bias=P["dcnn/fc6b"], relu=True, ws=self.ws)
+        else:
+            ops.gemm(x, P["dcnn/fc6W"], self.f6, n, FC_DIM, self.flat_dim, bias=P["dcnn/fc6b"], relu=True, ws=self.ws)
         if self.f7 is not None:
             ops.gemm(self.f6, P["dcnn/fc7W"], self.f7, n, FC_DIM, FC_DIM, bias=P["dcnn/fc7b"], relu=True, ws=self.ws)
         if self.f8 is not None:
@@ -627,7 +649,22 @@ class LRCNEngine:
             d = self.df6
         L5 = self.layers[-1]
         ops.colsum(d, G["dcnn/fc6b"], sw, n, FC_DIM)
-        if self.dp is None:
+        kc8 = self._fc6_kc8(n)
+        if kc8:
+            # bf16 path: weight gradient in one pass on the packed-operand kernel (the exchange chunks follow it)
+            F = self.flat_dim
+            a = self.k_p5[:n * F].view(ops.kc8_shape(n, F))
+            b_ = self.k_d6[:n * FC_DIM].view(ops.kc8_shape(n, FC_DIM))
+            ops.pack_kc8(L5["p"], a, n, F, F, 1)                              # (position frame, channel f)
+            ops.pack_kc8(d, b_, n, FC_DIM, FC_DIM, 1)
+            ops.gemm_kc8(a, b_, G["dcnn/fc6W"], F, FC_DIM, n, ws=self.ws)
+            if self.dp is not None:
+                chunks = iter(self.grad_chunks)
+                if self.offsets["dcnn/fc6W"][0] > 0:
+                    self.dp.reduce_async(self.g, *next(chunks))
+                for _ in self.fc6_row_blocks:
+                    self.dp.reduce_async(self.g, *next(chunks))
+        elif self.dp is None:
             ops.gemm(L5["p"], d, G["dcnn/fc6W"], self.flat_dim, FC_DIM, n, transa=True, ws=self.ws)
         else:
             # the exchange starts here: everything produced so far, then fc6W block by block -- block i is on the wire
@@ -639,7 +676,15 @@ class LRCNEngine:
             for r0, r1 in self.fc6_row_blocks:
                 ops.gemm(flat_p[:, r0:], d, G["dcnn/fc6W"][r0:r1], r1 - r0, FC_DIM, n, transa=True, lda=self.flat_dim)
                 self.dp.reduce_async(self.g, *next(chunks))
-        ops.gemm(d, P["dcnn/fc6W"], L5["dp"], n, self.flat_dim, FC_DIM, transb=True, ws=self.ws)
+        if kc8:
+            F = self.flat_dim
+            a = self.k_act[:n * FC_DIM].view(ops.kc8_shape(FC_DIM, n))
+            w = self.k_w.view(ops.kc8_shape(FC_DIM, F))
+            ops.pack_kc8(d, a, FC_DIM, n, 1, FC_DIM)                          # (position j, channel frame) = dfc6[frame][j]
+            ops.pack_kc8(P["dcnn/fc6W"], w, FC_DIM, F, 1, FC_DIM)             # (position j, channel f) = W[f][j]
+            ops.gemm_kc8(a, w, L5["dp"], n, F, FC_DIM, ws=self.ws)
+        else:
+            ops.gemm(d, P["dcnn/fc6W"], L5["dp"], n, self.flat_dim, FC_DIM, transb=True, ws=self.ws)
         # ---- conv stack, last to first
         for li in reversed(range(len(self.layers))):
             L = self.layers[li]

@@ -257,6 +257,35 @@ def bias_grad_c8(dyb, db, ws, c, halo):
     _ffi.call("vl_bias_grad_c8", _p(dyb), _p(db), _p(ws), n, c, hp - 2 * halo, wp - 2 * halo, halo, stream())
 
 
+def kc8_shape(positions, channels):
+    """Reduction-major packed operand of gemm_kc8: [ceil(channels / 8)][positions][8] bf16."""
+    return ((channels + 7) // 8, positions, 8)
+
+
+def pack_kc8(src, dst, positions, channels, pos_stride, ch_stride):
+    """dst (kc8) = src[position * pos_stride + channel * ch_stride]: a row-major fp32 matrix (or its transpose, by the strides)."""
+    _f32(src); _dense(dst)
+    if dst.dtype != torch.bfloat16 or tuple(dst.shape) != kc8_shape(positions, channels):
+        raise _ffi.VltfError("pack_kc8: dst must be bf16 %s, got %s %s" % (kc8_shape(positions, channels), dst.dtype, tuple(dst.shape)))
+    if (positions - 1) * pos_stride + (channels - 1) * ch_stride >= src.numel():
+        raise _ffi.VltfError("pack_kc8: strides reach past the source")
+    _ffi.call("vl_pack_kc8", _p(src), _p(dst), positions, channels, pos_stride, ch_stride, stream())
+
+
+def gemm_kc8_ws_bytes(m, n, k):
+    return int(_ffi.lib().vl_gemm_kc8_ws_bytes(m, n, k))
+
+
+def gemm_kc8(a, b, c, m, n, k, bias=None, relu=False, ws=None):
+    """c[m][n] = sum_k a[k][m] b[k][n] (+bias) (relu): bf16 products of kc8 operands, fp32 accumulation and output."""
+    _f32(c, bias); _dense(a, b, c, bias, ws)
+    if a.dtype != torch.bfloat16 or b.dtype != torch.bfloat16 or tuple(a.shape) != kc8_shape(k, m) or tuple(b.shape) != kc8_shape(k, n) \
+            or c.numel() < m * n:
+        raise _ffi.VltfError("gemm_kc8: operand shapes a=%s b=%s for m=%d n=%d k=%d" % (tuple(a.shape), tuple(b.shape), m, n, k))
+    _ffi.call("vl_gemm_kc8", _p(a), _p(b), _p(c), m, n, k, _p(bias), int(relu), _p(ws), 0 if ws is None else ws.numel() * ws.element_size(),
+              stream())
+
+
 def c8_shape(n, c, h, w, halo):
     return (n, (c + 7) // 8, h + 2 * halo, w + 2 * halo, 8)
 
