@@ -848,11 +848,12 @@ struct C8WgPlan {
 
 static int c8_wgrad_plan(const vl_conv_desc* d, int n, C8WgPlan* p) {
     const int ntaps = c8_taps(d->cig, d->kh, d->kw);
-    // waves (taps x channels) and 32-channel blocks per wave: 32 taps x 128 channels; 192-channel groups: 16 taps x 192;
+    // waves (taps x channels) and 32-channel blocks per wave: 32 taps x 128 channels; 192-channel groups: 32 taps x 192 on 12 waves;
     // up to 96 channels (conv1 as a 3x3 conv over 48 channels): 32 taps x 96 with every wave on all 96
     p->tb = 2;
     p->wb = d->cog % 128 == 0 ? 2 : d->cog % 192 == 0 ? 3 : 2;
-    p->wa = p->wb == 3 ? 2 : 4;
+    static const bool narrow192 = getenv("VL_C8_WG192_NARROW") != nullptr;   // A/B: 16 taps x 192 channels on 6 waves (8 % slower)
+    p->wa = p->wb == 3 ? (narrow192 ? 2 : 4) : 4;
     if (d->cog <= 96 && d->cog > 64) p->wa = 4, p->wb = 1, p->tb = 3;
     const int taps_tile = p->wa * 8, cols_tile = p->wb * p->tb * 32;
     p->tiles_a = (ntaps + taps_tile - 1) / taps_tile;
@@ -931,7 +932,8 @@ extern "C" int vl_conv_c8_wgrad(vl_conv_desc* d, const void* xb, const void* dyb
     a.CoP = p.CoP;
     a.dL = make_fastdiv(p.L);
     int rc = p.tb == 3   ? launch_c8_wgrad<4, 1, 3>(a, p, d->groups, (hipStream_t)stream)
-             : p.wb == 3 ? launch_c8_wgrad<2, 3, 2>(a, p, d->groups, (hipStream_t)stream)
+             : p.wb == 3 ? (p.wa == 4 ? launch_c8_wgrad<4, 3, 2>(a, p, d->groups, (hipStream_t)stream)
+                                      : launch_c8_wgrad<2, 3, 2>(a, p, d->groups, (hipStream_t)stream))
                          : launch_c8_wgrad<4, 2, 2>(a, p, d->groups, (hipStream_t)stream);
     if (rc) return rc;
     const int64_t total = (int64_t)d->kh * d->kw * d->cig * d->cout;
