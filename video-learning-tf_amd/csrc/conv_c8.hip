@@ -114,7 +114,7 @@ static constexpr int KT = 4;   // taps (32 reduction positions = two MFMA steps)
 // taps of one group: t = (cb * kh + ky) * kw + kx over the group's cbg channel blocks, padded to a multiple of KT
 static int c8_taps(int cg, int kh, int kw) { return ((cg + 7) / 8) * kh * kw; }
 static int c8_taps_padded(int cg, int kh, int kw) { return (c8_taps(cg, kh, kw) + KT - 1) / KT * KT; }
-static int c8_cop(int cog) { return (cog + 63) / 64 * 64; }   // channel pitch of the packed weights: whole 64-channel fetches (96 -> 128)
+static int c8_cop(int cog) { return (cog + 127) / 128 * 128; }   // channel pitch of the packed weights: a 96-wide tile fetches 128 channels
 
 // out[g][t][co < CoP][8]: forward  (bwd = 0): W[ky][kx][cb * 8 + j][g * cog + co]              (reduce over input channels)
 //                         dgrad    (bwd = 1): W[kh-1-ky][kw-1-kx][co][g * cog + cb * 8 + j]     (reduce over output channels; "co" = ci)
@@ -496,6 +496,10 @@ static int launch_c8(const C8ConvArgs& a, int groups, hipStream_t stream) {
 static int dispatch_c8(C8ConvArgs& a, int groups, hipStream_t stream) {
     if (a.Cog <= 64) return launch_c8<4, 1, 2, 2>(a, groups, stream);          // 256 pixels x 64 channels, 4 waves
     if (a.Cog <= 96) return launch_c8<4, 1, 2, 3>(a, groups, stream);          // 256 x 96 (conv1 as a 3x3 conv over 48 channels)
+    // 192-channel groups (conv4 forward, conv4 / conv5 dgrad): two 96-wide tiles of 4 waves, two workgroups per CU (72 KB each), rather
+    // than one 192-wide tile of 8 waves that owns the CU (112 KB): 3-6 % faster (VL_C8_Q192=1 runs the wide tile)
+    static const bool q192 = getenv("VL_C8_Q192") != nullptr;
+    if (a.Cog % 128 != 0 && a.Cog % 192 == 0 && !q192) return launch_c8<4, 1, 2, 3>(a, groups, stream);
     if (a.Cog % 128 != 0 && a.Cog % 192 == 0) return launch_c8<4, 2, 2, 3>(a, groups, stream);   // 256 x 192
     return launch_c8<4, 2, 2, 2>(a, groups, stream);                           // 256 x 128
 }
