@@ -16,6 +16,8 @@ import math
 from dataclasses import dataclass, field
 from typing import Optional, Tuple
 
+import os
+
 import numpy as np
 import torch
 
@@ -267,7 +269,7 @@ class LRCNEngine:
                 L0["dws2d"] = torch.zeros(eq.w_shape, device=dev)
                 ws_bytes = max(ws_bytes, eq.c8_wgrad_ws_bytes(N))
         self.flat_dim = h * w * c
-        if self.c8 and N % 8 == 0:
+        if self.c8 and N % 8 == 0 and os.environ.get("VLTF_FC6_KC8", "1") != "0":      # (0: A/B against the split-product GEMM)
             # fc6's three products on the wgrad kernel (ops.gemm_kc8: reduction-major packed operands), DESIGN 4.7
             F = self.flat_dim
             kb = lambda count: torch.zeros(count, dtype=torch.bfloat16, device=dev)
