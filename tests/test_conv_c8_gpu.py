@@ -334,3 +334,40 @@ def test_dense_product_on_the_wgrad_kernel(ops, m, n, k, bias, relu):
     c2 = torch.empty_like(c)
     ops.gemm_kc8(ak, bk, c2, m, n, k, bias=None if bv is None else torch.from_numpy(bv).to(DEV), relu=relu, ws=ws)
     assert torch.equal(c, c2)
+
+
+def test_the_packed_path_refuses_what_it_cannot_run(ops):
+    """Fail-fast convention of the C-ABI (utils_.error in the reference: raise): every unsupported geometry is an error, not a fallback."""
+    from vltf_amd._ffi import VltfError
+    dev_u8 = lambda nbytes: torch.zeros(max(nbytes, 16), dtype=torch.uint8, device=DEV)
+    # channels per group not a multiple of 8
+    conv = ops.Conv(12, 9, 9, 16, 3, 3, 1, 1)
+    conv.set_halo(1, 0, 1, 0)
+    xb = torch.zeros(ops.c8_shape(2, 12, 9, 9, 1), dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(VltfError, match="multiple of 8"):
+        conv.c8_fwd(xb, dev_u8(conv.c8_w_bytes(False)), torch.zeros(16, device=DEV), y=torch.zeros((2, 16, 9, 9), device=DEV))
+    # input without the SAME halo: the gather would need bounds tests the packed kernels do not have
+    conv = ops.Conv(16, 9, 9, 16, 3, 3, 1, 1)
+    conv.set_halo(0, 0, 0, 0)
+    xb = torch.zeros(ops.c8_shape(2, 16, 9, 9, 0), dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(VltfError, match="padded layout"):
+        conv.c8_fwd(xb, dev_u8(conv.c8_w_bytes(False)), torch.zeros(16, device=DEV), y=torch.zeros((2, 16, 9, 9), device=DEV))
+    # wgrad needs x and dy in one plane geometry
+    conv.set_halo(1, 0, 2, 0)
+    xb = torch.zeros(ops.c8_shape(2, 16, 9, 9, 1), dtype=torch.bfloat16, device=DEV)
+    dyb = torch.zeros(ops.c8_shape(2, 16, 9, 9, 2), dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(VltfError, match="x_halo == dy_halo"):
+        conv.c8_wgrad(xb, dyb, torch.zeros(conv.w_shape, device=DEV), torch.zeros(1 << 20, device=DEV))
+    # strided layers have no packed dgrad / wgrad of their own (conv1 goes through s2d_layer())
+    conv = ops.Conv(16, 9, 9, 16, 3, 3, 2, 1)
+    conv.set_halo(1, 0, 1, 0)
+    with pytest.raises(VltfError):
+        conv.c8_dgrad(torch.zeros(ops.c8_shape(2, 16, 5, 5, 1), dtype=torch.bfloat16, device=DEV), dev_u8(conv.c8_w_bytes(True)),
+                      dx=torch.zeros((2, 16, 9, 9), device=DEV))
+    # wrong operand layout / dtype is caught before the call
+    with pytest.raises(VltfError):
+        conv.c8_fwd(torch.zeros((2, 16, 11, 11), device=DEV), dev_u8(64), torch.zeros(16, device=DEV), y=torch.zeros((2, 16, 5, 5), device=DEV))
+    # dense product: m, n in whole 8-channel blocks
+    with pytest.raises(VltfError):
+        ops.gemm_kc8(torch.zeros(ops.kc8_shape(16, 12), dtype=torch.bfloat16, device=DEV), torch.zeros(ops.kc8_shape(16, 8), dtype=torch.bfloat16, device=DEV),
+                     torch.zeros((12, 8), device=DEV), 12, 8, 16, ws=torch.zeros(1 << 16, device=DEV))
