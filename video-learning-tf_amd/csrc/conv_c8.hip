@@ -12,7 +12,10 @@
 //     once per step into [group][tap][cout][8] and fetched the same way.
 //   * wgrad reduces over PIXELS, the strided index of both operands; the LDS image [pixel][chunk] is read column-wise with
 //     ds_read_b64_tr_b16 (the hardware transpose read of gfx950), see wgrad_c8_kernel.
-// Producers write the c8 copies (vl_pack_c8 as a stand-alone producer; the fused forms live with the producers).
+//   * conv1 (11 x 11 / 4 over 3 channels) runs the same two kernels as the equivalent 3 x 3 stride-1 layer over its space-to-depth
+//     input (vl_s2d_*), dense products (fc6) run the wgrad kernel on reduction-major operands (vl_pack_kc8 / vl_gemm_kc8).
+// Producers write the c8 copies (vl_pack_c8 as a stand-alone producer; the fused forms live with the producers: the conv epilogues
+// here, vl_lrn_pool_fwd_c8 / vl_pool_lrn_bwd_c8 in pointwise.hip, vl_input_prep_u8_s2d below).  DESIGN.md 4.7 has the measurements.
 #include <stdlib.h>
 #include <string.h>
 
