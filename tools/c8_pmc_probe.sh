@@ -30,7 +30,9 @@ for key,r in sorted(res.items()):
         key[0], 'x'.join(str(int(k)) for k in key[1:]), r['dur_a']/1e6, 100*r['SQ_VALU_MFMA_BUSY_CYCLES']/1024/cyc,
         100*r['SQ_WAIT_INST_ANY']/r['SQ_WAVE_CYCLES'], 100*r['SQ_WAIT_ANY']/r['SQ_WAVE_CYCLES'])
     if 'SQ_INSTS_MFMA' in r:
-        line+='  VALU/MFMA %.2f  LDS/MFMA %.2f  bank-conflict cycles %.1f %% of LDS cycles' % (
-            r['SQ_INSTS_VALU']/max(r['SQ_INSTS_MFMA'],1), r['SQ_INSTS_LDS']/max(r['SQ_INSTS_MFMA'],1), 100*r['SQ_LDS_BANK_CONFLICT']/max(r['SQ_LDS_IDX_ACTIVE'],1))
+        # SQ_INSTS_VALU counts the MFMAs too (they are vector-ALU instructions): "other" = everything that is not an MFMA, whole kernel
+        line+='  SQ_INSTS_VALU/SQ_INSTS_MFMA %.2f (other VALU per MFMA %.2f)  LDS/MFMA %.2f  bank-conflict cycles %.1f %% of LDS cycles' % (
+            r['SQ_INSTS_VALU']/max(r['SQ_INSTS_MFMA'],1), r['SQ_INSTS_VALU']/max(r['SQ_INSTS_MFMA'],1)-1.0, r['SQ_INSTS_LDS']/max(r['SQ_INSTS_MFMA'],1),
+            100*r['SQ_LDS_BANK_CONFLICT']/max(r['SQ_LDS_IDX_ACTIVE'],1))
     print(line)
 P

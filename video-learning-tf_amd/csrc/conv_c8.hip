@@ -696,18 +696,24 @@ __global__ __launch_bounds__(64 * WA * WB) void wgrad_c8_kernel(const C8WgradArg
     constexpr uint32_t OOB = 0xF0000000u;
     auto issue = [&](int st) {
         const uint32_t slot = lds0 + (uint32_t)(st % NBUF) * SLOT;
-        const int64_t gp0 = gp_begin + (int64_t)st * KP;                       // first position of the stage
+        int gp0 = (int)(gp_begin + (int64_t)st * KP);                          // first position of the stage (Rtot < 2^31)
+        // opaque to the optimiser: otherwise the per-lane offsets of the rarely taken branches below become loop-carried vector
+        // induction variables, a dozen vector adds in EVERY stage
+        asm volatile("" : "+s"(gp0));
         const int n_s = (int)fd_div((uint32_t)gp0, a.dL);                      // its image; at most one image boundary inside (L >= KP)
-        const int r0 = (int)(gp0 - (int64_t)n_s * a.L);                        // position within the image's sweep
+        const int r0 = gp0 - n_s * a.L;                                        // position within the image's sweep
         const int to_next = a.L - r0;                                          // positions of the stage before the next image starts
         const int to_end = (int)((gp_end - gp0) < KP ? (gp_end - gp0) : KP);   // positions before the slab ends
         if (to_next >= KP && to_end >= KP) {                                   // the whole stage inside one image: no per-lane work at all
             const uint32_t sx = (uint32_t)((int64_t)(n_s - n_first) * a.x_img) + (uint32_t)r0 * 16;
             const uint32_t sdy = (uint32_t)((int64_t)(n_s - n_first) * a.dy_img) + (uint32_t)(a.qstart + r0) * 16;
+            // (readfirstlane: the offsets ARE uniform; it keeps hipcc from folding them into a per-stage vector add on the lane offsets)
 #pragma unroll
-            for (int j = 0; j < FA; ++j) lds_dma16(rs_x, slot + lds_a[j], voff_a[j], (int)(sx + (uint32_t)grp_a[j] * 64));
+            for (int j = 0; j < FA; ++j)
+                lds_dma16(rs_x, slot + lds_a[j], voff_a[j], __builtin_amdgcn_readfirstlane((int)(sx + (uint32_t)grp_a[j] * 64)));
 #pragma unroll
-            for (int j = 0; j < FB; ++j) lds_dma16(rs_dy, slot + lds_b[j], voff_b[j], (int)(sdy + (uint32_t)grp_b[j] * 64));
+            for (int j = 0; j < FB; ++j)
+                lds_dma16(rs_dy, slot + lds_b[j], voff_b[j], __builtin_amdgcn_readfirstlane((int)(sdy + (uint32_t)grp_b[j] * 64)));
         } else if (a.L >= KP) {                                                // at most one image boundary inside the stage
             const uint32_t sx = (uint32_t)((int64_t)(n_s - n_first) * a.x_img) + (uint32_t)r0 * 16;
             const uint32_t sdy = (uint32_t)((int64_t)(n_s - n_first) * a.dy_img) + (uint32_t)(a.qstart + r0) * 16;
