@@ -287,6 +287,10 @@ def main(init_file, seed=0, device=None):
     if settings.train:
         train = Train(settings, feeder, engine)
         do_train(settings, train, feeder, engine)
+        if world > 1:
+            # nobody leaves before rank 0 has written the last checkpoint: a phase that follows (validation with `resume: latest`)
+            # reads it on every rank
+            torch.distributed.barrier()
     elif settings.val:
         result = do_test(settings, Validation(settings) if rank == 0 else None, feeder, engine, rank, world)
         if world > 1:
