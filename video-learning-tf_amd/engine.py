@@ -16,6 +16,7 @@ import math
 from dataclasses import dataclass, field
 from typing import Optional, Tuple
 
+import contextlib
 import os
 
 import numpy as np
@@ -722,11 +723,18 @@ class LRCNEngine:
                 else:      # straight into the previous conv's packed gradient; its ReluGrad reads this layer's packed input
                     self._run(name + ".dgrad", conv.c8_dgrad, L["dyb"][:n], L["wbt"], dxb=prev["dyb"][:n], relu_mask_c8=L["xb"][:n])
                 continue
-            if conv.fuses_bias():      # bias gradient comes out of the same pass over dy
-                self._run(name + ".wgrad", conv.wgrad, x_in, dy, G["dcnn/%sW" % name], self.ws, db=G["dcnn/%sb" % name])
+            side = self._side_stream()
+            if side is not None:           # experiment (VLTF_WGRAD_STREAM=1): wgrad on a second stream beside this layer's dgrad
+                side.wait_stream(torch.cuda.current_stream(self.dev))
+                ctx = torch.cuda.stream(side)
             else:
-                self._run(name + ".wgrad", conv.wgrad, x_in, dy, G["dcnn/%sW" % name], self.ws)
-                ops.bias_grad_nchw(dy, G["dcnn/%sb" % name], sw)
+                ctx = contextlib.nullcontext()
+            with ctx:
+                if conv.fuses_bias():      # bias gradient comes out of the same pass over dy
+                    self._run(name + ".wgrad", conv.wgrad, x_in, dy, G["dcnn/%sW" % name], self.ws, db=G["dcnn/%sb" % name])
+                else:
+                    self._run(name + ".wgrad", conv.wgrad, x_in, dy, G["dcnn/%sW" % name], self.ws)
+                    ops.bias_grad_nchw(dy, G["dcnn/%sb" % name], sw)
             if li > 0:
                 prev = self.layers[li - 1]
                 conv.wt_transpose(P["dcnn/%sW" % name], self.wt)
@@ -734,8 +742,17 @@ class LRCNEngine:
                     self._run(name + ".dgrad", conv.dgrad, dy, self.wt, prev["dp"][:n])     # into the pool output gradient
                 else:
                     self._run(name + ".dgrad", conv.dgrad, dy, self.wt, prev["dy"][:n], relu_mask=prev["y"][:n])
+        if self._side_stream() is not None:
+            torch.cuda.current_stream(self.dev).wait_stream(self._side_stream())
         if self.dp is not None:
             self.dp.reduce_async(self.g, *self.grad_chunks[-1])
+
+    def _side_stream(self):
+        if os.environ.get("VLTF_WGRAD_STREAM", "0") != "1":
+            return None
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.dev)
+        return self._side
 
     def _pool_bwd(self, L, n, dx, relu_mask, dx_halo):
         ops.maxpool_bwd(L["dp"][:n], L["arg"][:n], dx, relu_mask=relu_mask, hwc=L["hwc"], dy_halo=L["p_halo"], dx_halo=dx_halo)
