@@ -581,6 +581,7 @@ class LRCNEngine:
     def _backward(self, n, b):
         P, G, cfg = self.P, self.G, self.cfg
         ops.set_conv_math(cfg.conv_math)             # process-wide switch (see _forward): another engine may have run in between
+        self._frames_now = n
         D, C, H, T = cfg.encode_dim(), cfg.num_classes, cfg.lstm_hidden, self.T
         sw = self.small_ws
         if cfg.classifier == "lstm":
@@ -653,6 +654,11 @@ class LRCNEngine:
         L5 = self.layers[-1]
         ops.colsum(d, G["dcnn/fc6b"], sw, n, FC_DIM)
         kc8 = self._fc6_kc8(n)
+        side = self._side_stream()
+        if side is not None and not kc8:           # fc6's input gradient on the second stream, beside the weight-gradient blocks
+            side.wait_stream(torch.cuda.current_stream(self.dev))
+            with torch.cuda.stream(side):
+                ops.gemm(d, P["dcnn/fc6W"], L5["dp"], n, self.flat_dim, FC_DIM, transb=True, ws=self.ws_side)
         if kc8:
             # bf16 path: weight gradient in one pass on the packed-operand kernel (the exchange chunks follow it)
             F = self.flat_dim
@@ -686,6 +692,8 @@ class LRCNEngine:
             ops.pack_kc8(d, a, FC_DIM, n, 1, FC_DIM)                          # (position j, channel frame) = dfc6[frame][j]
             ops.pack_kc8(P["dcnn/fc6W"], w, FC_DIM, F, 1, FC_DIM)             # (position j, channel f) = W[f][j]
             ops.gemm_kc8(a, w, L5["dp"], n, F, FC_DIM, ws=self.ws)
+        elif side is not None:
+            torch.cuda.current_stream(self.dev).wait_stream(side)             # pool5's backward reads what the side stream wrote
         else:
             ops.gemm(d, P["dcnn/fc6W"], L5["dp"], n, self.flat_dim, FC_DIM, transb=True, ws=self.ws)
         # ---- conv stack, last to first
@@ -748,10 +756,18 @@ class LRCNEngine:
             self.dp.reduce_async(self.g, *self.grad_chunks[-1])
 
     def _side_stream(self):
-        if os.environ.get("VLTF_WGRAD_STREAM", "0") != "1":
+        """Second HIP stream of the backward pass, or None.  Independent launches (a layer's weight gradient beside its input
+        gradient and the next pool / LRN backward; fc6's input gradient beside its weight-gradient blocks) fill the CUs a small
+        launch leaves idle: an 8-clip shard steps 4 % faster, 16 / 32 clips 2 %, 64 clips 1.5 %.  VLTF_WGRAD_STREAM=1 / 0 forces it;
+        unset = on for shards of at most 512 frames (where launches underfill the chip), off for the full batch, whose per-kernel timings
+        (bench.py's roofline) need launches that run alone.  The fp32 path only."""
+        mode = os.environ.get("VLTF_WGRAD_STREAM", "")
+        on = mode == "1" or (mode == "" and getattr(self, "_frames_now", 1 << 30) <= 512)
+        if not on or self.cfg.conv_math != "f32":
             return None
         if getattr(self, "_side", None) is None:
             self._side = torch.cuda.Stream(device=self.dev)
+            self.ws_side = torch.empty((64 << 20) // 4, device=self.dev)        # split-k slabs of a GEMM that runs on the side stream
         return self._side
 
     def _pool_bwd(self, L, n, dx, relu_mask, dx_halo):
