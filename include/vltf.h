@@ -122,8 +122,7 @@ int vl_conv_wgrad(const vl_conv_desc* d, const float* x, const float* dy, float*
  *   vl_conv_c8_dgrad       dx (fp32 NCHW, dx_halo) and / or dxb (c8, dx_halo) from dyb (c8, dy_halo); ReluGrad of the producing layer
  *                          from relu_mask (fp32, as vl_conv_dgrad) or relu_mask_c8 (the layer's own packed input xb, x_halo)
  *   vl_bias_grad_c8        db[c] = sum_{n,h,w} dy from the packed gradient (c8, halo); ws: float[64 * 8 * ceil(c/8)]
- *   vl_conv_c8_wgrad       dw (HWIO fp32) from xb and dyb, and optionally db ([cout]: the bias gradient, summed from the dy tiles of
- *                          the same pass); deterministic slab reduction through ws (vl_conv_c8_wgrad_ws_bytes) */
+ *   vl_conv_c8_wgrad       dw (HWIO fp32) from xb and dyb; deterministic slab reduction through ws (vl_conv_c8_wgrad_ws_bytes) */
 size_t vl_c8_bytes(int n, int c, int h, int w, int halo);
 int vl_pack_c8(const float* x, void* xb, int n, int c, int h, int w, int x_halo, int xb_halo, vl_stream_t stream);
 size_t vl_conv_c8_w_bytes(const vl_conv_desc* d, int bwd);
@@ -133,7 +132,7 @@ int vl_conv_c8_fwd(vl_conv_desc* d, const void* xb, const void* wb, const float*
 int vl_conv_c8_dgrad(vl_conv_desc* d, const void* dyb, const void* wbt, float* dx, void* dxb, const float* relu_mask,
                      const void* relu_mask_c8, int n, vl_stream_t stream);
 size_t vl_conv_c8_wgrad_ws_bytes(const vl_conv_desc* d, int n);
-int vl_conv_c8_wgrad(vl_conv_desc* d, const void* xb, const void* dyb, float* dw, float* db, void* ws, size_t ws_bytes, int n,
+int vl_conv_c8_wgrad(vl_conv_desc* d, const void* xb, const void* dyb, float* dw, void* ws, size_t ws_bytes, int n,
                      vl_stream_t stream);
 int vl_bias_grad_c8(const void* dyb, float* db, float* ws, int n, int c, int h, int w, int halo, vl_stream_t stream);
 /* Dense products on the same pipeline (fc6 of the bf16 path): c[m][n] = sum_k a[k][m] b[k][n] (+ bias[n]) (ReLU) with both operands

@@ -46,7 +46,7 @@ SIGNATURES = {
     "vl_s2d_weights": (i32, [p, p, p, i32, p]),
     "vl_bias_grad_c8": (i32, [p, p, p, i32, i32, i32, i32, i32, p]),
     "vl_conv_c8_wgrad_ws_bytes": (sz, [p, i32]),
-    "vl_conv_c8_wgrad": (i32, [p, p, p, p, p, p, sz, i32, p]),
+    "vl_conv_c8_wgrad": (i32, [p, p, p, p, p, sz, i32, p]),
     "vl_bias_grad_nchw": (i32, [p, p, p, i32, i32, i32, p]),
     "vl_lrn_fwd": (i32, [p, p, i32, i32, i32, i32, f32, f32, f32, p]),
     "vl_lrn_bwd": (i32, [p, p, p, i32, i32, i32, i32, f32, f32, f32, i32, i32, i32, p]),

@@ -623,8 +623,6 @@ struct C8WgradArgs {
     int64_t Rtot;         // nimg * L
     int slab_len;         // positions per slab (multiple of 32)
     float* ws;            // [slab][group][rowsP][CoP]
-    float* dbws;          // bias-gradient partials [slab][group][CoP], or null: db[co] = sum over positions of dy rides along as ONE more
-                          // operand block of ones in the workgroups of the first tap tile (halo positions of dy are zeros)
     int rowsP, CoP;       // rows (taps * 8) / columns of a slab image, padded to the tiling
     FastDiv dL;
 };
@@ -761,14 +759,6 @@ __global__ __launch_bounds__(64 * WA * WB) void wgrad_c8_kernel(const C8WgradArg
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
-    const bool do_bias = a.dbws != nullptr && ta == 0 && wa == 0;      // (wave-uniform) these waves also sum dy over the positions
-    const i32x4 ones = {0x3f803f80, 0x3f803f80, 0x3f803f80, 0x3f803f80};  // eight bf16 1.0
-    f32x16 accb[TB];
-#pragma unroll
-    for (int j = 0; j < TB; ++j)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) accb[j][q] = 0.f;
-
     for (int st = 0; st < NBUF - 1 && st < nstages; ++st) issue(st);
     // transposed operand reads: 16-lane group g16 -> (columns 16 (g16 & 1) .. + 15 of the 32-wide block, positions 8 (g16 >> 1) .. + 7);
     // lane 4 q + p of the group addresses row q, columns 4 p .. 4 p + 3 = chunk 2 (g16 & 1) + (p >> 1), byte 8 (p & 1)
@@ -827,10 +817,6 @@ __global__ __launch_bounds__(64 * WA * WB) void wgrad_c8_kernel(const C8WgradArg
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < TB; ++j) acc[i][j] = mfma_bf16(av[i], bv[j], acc[i][j]);
-            if (do_bias) {
-#pragma unroll
-                for (int j = 0; j < TB; ++j) accb[j] = mfma_bf16(ones, bv[j], accb[j]);      // every row = the column sums of dy
-            }
         });
     }
 
@@ -847,24 +833,6 @@ __global__ __launch_bounds__(64 * WA * WB) void wgrad_c8_kernel(const C8WgradArg
                 if (row < a.rowsP && col < a.CoP) out[(int64_t)row * a.CoP + col] = acc[i][j][q];
             }
         }
-    if (do_bias && lane < 32) {                                        // row 0 of the ones-block: register 0 of lanes 0 .. 31
-        float* ob = a.dbws + ((int64_t)zs * gridDim.y + g) * a.CoP;
-#pragma unroll
-        for (int j = 0; j < TB; ++j) {
-            const int col = co0 + (wb * TB + j) * 32 + lane;
-            if (col < a.CoP) ob[col] = accb[j][0];
-        }
-    }
-}
-
-// db[g * cog + co] = sum over slabs of dbws[slab][g][co], in slab order
-__global__ void wgrad_c8_bias_reduce_kernel(const float* __restrict__ dbws, float* __restrict__ db, int cog, int groups, int CoP, int slabs) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= cog * groups) return;
-    const int g = c / cog, co = c % cog;
-    float s = 0.f;
-    for (int z = 0; z < slabs; ++z) s += dbws[((int64_t)z * groups + g) * CoP + co];
-    db[c] = s;
 }
 
 // dw[ky][kx][c][g * cog + co] = sum over slabs of ws[slab][g][((c / 8 * kh + ky) * kw + kx) * 8 + c % 8][co], in slab order
@@ -923,7 +891,7 @@ extern "C" size_t vl_conv_c8_wgrad_ws_bytes(const vl_conv_desc* d, int n) {
     if (!d || n <= 0) return 0;
     C8WgPlan p;
     c8_wgrad_plan(d, n, &p);
-    return (size_t)p.slabs * d->groups * ((size_t)p.rowsP + 1) * p.CoP * sizeof(float);      // weight slabs + one row of bias partials each
+    return (size_t)p.slabs * d->groups * p.rowsP * p.CoP * sizeof(float);
 }
 
 template <int WA, int WB, int TB>
@@ -941,9 +909,8 @@ static int launch_c8_wgrad(const C8WgradArgs& a, const C8WgPlan& p, int groups, 
 }
 
 /* dw (HWIO fp32) = d(loss)/dw from the c8 operands xb (x_halo) and dyb (dy_halo == x_halo), stride-1 layers; deterministic slab
- * reduction through ws (>= vl_conv_c8_wgrad_ws_bytes).  db (optional, [cout]): the bias gradient sum of dy over images and pixels,
- * from the dy tiles the kernel streams anyway (one more MFMA operand block of ones in the first tap tile's workgroups). */
-extern "C" int vl_conv_c8_wgrad(vl_conv_desc* d, const void* xb, const void* dyb, float* dw, float* db, void* ws, size_t ws_bytes, int n,
+ * reduction through ws (>= vl_conv_c8_wgrad_ws_bytes). */
+extern "C" int vl_conv_c8_wgrad(vl_conv_desc* d, const void* xb, const void* dyb, float* dw, void* ws, size_t ws_bytes, int n,
                                 vl_stream_t stream) {
     VL_CHECK(d && xb && dyb && dw && ws && n > 0, "vl_conv_c8_wgrad: bad argument");
     VL_CHECK(d->stride == 1 && d->x_halo == d->dy_halo && d->oh == d->h && d->ow == d->w, "vl_conv_c8_wgrad: stride-1 SAME layers with x_halo == dy_halo");
@@ -951,7 +918,7 @@ extern "C" int vl_conv_c8_wgrad(vl_conv_desc* d, const void* xb, const void* dyb
     if (int rc = c8_tables(d)) return rc;
     C8WgPlan p;
     c8_wgrad_plan(d, n, &p);
-    VL_CHECK(ws_bytes >= (size_t)p.slabs * d->groups * ((size_t)p.rowsP + 1) * p.CoP * sizeof(float), "vl_conv_c8_wgrad: workspace too small");
+    VL_CHECK(ws_bytes >= (size_t)p.slabs * d->groups * p.rowsP * p.CoP * sizeof(float), "vl_conv_c8_wgrad: workspace too small");
     VL_CHECK(p.Rtot < (1ll << 31), "vl_conv_c8_wgrad: too many positions");
     const int Hp = d->h + 2 * d->x_halo, Wp = d->w + 2 * d->x_halo;
     C8WgradArgs a;
@@ -974,7 +941,6 @@ extern "C" int vl_conv_c8_wgrad(vl_conv_desc* d, const void* xb, const void* dyb
     a.Rtot = p.Rtot;
     a.slab_len = p.slab_len;
     a.ws = (float*)ws;
-    a.dbws = db ? (float*)ws + (size_t)p.slabs * d->groups * p.rowsP * p.CoP : nullptr;
     a.rowsP = p.rowsP;
     a.CoP = p.CoP;
     a.dL = make_fastdiv(p.L);
@@ -987,11 +953,6 @@ extern "C" int vl_conv_c8_wgrad(vl_conv_desc* d, const void* xb, const void* dyb
     hipLaunchKernelGGL(wgrad_c8_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)ws, dw,
                        d->kh, d->kw, d->cig, d->cog, d->groups, p.rowsP, p.CoP, p.slabs, total);
     VL_LAUNCH_CHECK();
-    if (db) {
-        hipLaunchKernelGGL(wgrad_c8_bias_reduce_kernel, dim3((d->cout + 255) / 256), dim3(256), 0, (hipStream_t)stream, a.dbws, db, d->cog, d->groups,
-                           p.CoP, p.slabs);
-        VL_LAUNCH_CHECK();
-    }
     return 0;
 }
 

@@ -715,14 +715,15 @@ class LRCNEngine:
             # else: dy was written (ReluGrad fused) by the next layer's dgrad epilogue
             if self.c8 and li == 0:
                 eq = L["eq"]
-                self._run(name + ".wgrad", eq.c8_wgrad, L["xb"][:n], L["dyb"][:n], L["dws2d"], self.ws, db=G["dcnn/%sb" % name])
+                self._run(name + ".wgrad", eq.c8_wgrad, L["xb"][:n], L["dyb"][:n], L["dws2d"], self.ws)
                 conv.s2d_weights(L["dws2d"], G["dcnn/%sW" % name], grad=True)
+                ops.bias_grad_c8(L["dyb"][:n], G["dcnn/%sb" % name], sw, conv.cout, eq.dy_halo)
                 continue
             if self.c8:
                 if L["pool"] and not L["lrn"]:
                     ops.pack_c8(dy, L["dyb"][:n], L["dy_halo"], L["dy_halo"])
-                # (the bias gradient rides in the same pass: one more operand block of ones over the dy tiles)
-                self._run(name + ".wgrad", conv.c8_wgrad, L["xb"][:n], L["dyb"][:n], G["dcnn/%sW" % name], self.ws, db=G["dcnn/%sb" % name])
+                self._run(name + ".wgrad", conv.c8_wgrad, L["xb"][:n], L["dyb"][:n], G["dcnn/%sW" % name], self.ws)
+                ops.bias_grad_c8(L["dyb"][:n], G["dcnn/%sb" % name], sw, conv.cout, L["dy_halo"])
                 prev = self.layers[li - 1]
                 conv.c8_pack_w(P["dcnn/%sW" % name], L["wbt"], True)
                 if prev["pool"]:

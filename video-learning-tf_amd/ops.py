@@ -238,17 +238,14 @@ class Conv:
     def c8_wgrad_ws_bytes(self, n):
         return int(_ffi.lib().vl_conv_c8_wgrad_ws_bytes(self._d, n))
 
-    def c8_wgrad(self, xb, dyb, dw, ws, db=None):
-        """dw, and with db ([cout]) also the bias gradient sum of dy, from the same pass."""
+    def c8_wgrad(self, xb, dyb, dw, ws):
         n = xb.shape[0]
-        _f32(dw, db); _dense(dw, ws, db)
-        if db is not None and db.numel() != self.cout:
-            raise _ffi.VltfError("conv.c8_wgrad: db must have %d elements" % self.cout)
+        _f32(dw); _dense(dw, ws)
         self._c8_check(xb, n, self.cin, self.h, self.w, self.x_halo, "xb")
         self._c8_check(dyb, n, self.cout, self.oh, self.ow, self.dy_halo, "dyb")
         if tuple(dw.shape) != self.w_shape:
             raise _ffi.VltfError("conv.c8_wgrad: dw shape %s" % (tuple(dw.shape),))
-        _ffi.call("vl_conv_c8_wgrad", self._d, _p(xb), _p(dyb), _p(dw), _p(db), _p(ws), ws.numel() * ws.element_size(), n, stream())
+        _ffi.call("vl_conv_c8_wgrad", self._d, _p(xb), _p(dyb), _p(dw), _p(ws), ws.numel() * ws.element_size(), n, stream())
 
 
 def bias_grad_c8(dyb, db, ws, c, halo):
