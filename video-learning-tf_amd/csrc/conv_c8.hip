@@ -451,18 +451,27 @@ void conv_c8_free_tables(vl_conv_desc* d) {
     d->c8_toff_fwd = d->c8_toff_bwd = nullptr;
 }
 
-static int c8_tables(vl_conv_desc* d) {
-    if (!d->c8_toff_fwd) {
-        VL_CHECK(d->fwd_padded && d->x_phase <= 1, "conv c8: x needs the padded layout (halo >= SAME padding), not phase split");
+// Built at vl_conv_create / vl_conv_set_halo (rebuild_tables in mfma_gemm.hip): nothing is allocated inside the compute calls.
+// A layer the packed kernels cannot run (no SAME halo, phase-split input, channels not in whole 8-blocks) simply has no tables.
+int conv_c8_build_tables(vl_conv_desc* d) {
+    conv_c8_free_tables(d);
+    if (d->cig % 8 != 0 || d->cog % 8 != 0) return 0;
+    if (d->fwd_padded && d->x_phase <= 1) {
         d->c8_toff_fwd = upload_taps(d->cig, d->kh, d->kw, d->h + 2 * d->x_halo, d->w + 2 * d->x_halo, d->x_halo - d->pt, d->x_halo - d->pl);
-        VL_CHECK(d->c8_toff_fwd, "conv c8: tap table allocation failed");
+        if (!d->c8_toff_fwd) return 2;
     }
-    if (!d->c8_toff_bwd && d->stride == 1 && d->bwd_padded) {
+    if (d->stride == 1 && d->bwd_padded) {
         // dgrad: dx[h][w] = sum dy[h + ky' - (kh-1-pt)][..] Wflip[ky'][kx'] over dy with halo dy_halo
         d->c8_toff_bwd = upload_taps(d->cog, d->kh, d->kw, d->oh + 2 * d->dy_halo, d->ow + 2 * d->dy_halo, d->dy_halo - (d->kh - 1 - d->pt),
                                      d->dy_halo - (d->kw - 1 - d->pl));
-        VL_CHECK(d->c8_toff_bwd, "conv c8: tap table allocation failed");
+        if (!d->c8_toff_bwd) return 2;
     }
+    return 0;
+}
+
+static int c8_tables(vl_conv_desc* d) {
+    VL_CHECK(d->fwd_padded && d->x_phase <= 1, "conv c8: x needs the padded layout (halo >= SAME padding), not phase split");
+    VL_CHECK(d->c8_toff_fwd, "conv c8: no tap tables for this layer (vl_conv_set_halo builds them)");
     return 0;
 }
 
@@ -556,7 +565,7 @@ extern "C" int vl_conv_c8_fwd(vl_conv_desc* d, const void* xb, const void* wb, c
 extern "C" int vl_conv_c8_dgrad(vl_conv_desc* d, const void* dyb, const void* wbt, float* dx, void* dxb, const float* relu_mask,
                                 const void* relu_mask_c8, int n, vl_stream_t stream) {
     VL_CHECK(d && dyb && wbt && (dx || dxb) && n > 0, "vl_conv_c8_dgrad: bad argument");
-    VL_CHECK(d->stride == 1 && d->bwd_padded, "vl_conv_c8_dgrad: stride-1 layers in the padded layout only");
+    VL_CHECK(d->stride == 1 && d->bwd_padded && d->c8_toff_bwd, "vl_conv_c8_dgrad: stride-1 layers in the padded layout only");
     VL_CHECK(d->cig % 8 == 0 && d->cog % 8 == 0, "vl_conv_c8_dgrad: channels per group must be a multiple of 8");
     if (int rc = c8_tables(d)) return rc;
     const int Hp = d->oh + 2 * d->dy_halo, Wp = d->ow + 2 * d->dy_halo, CB = d->cout / 8;

@@ -29,4 +29,5 @@ struct vl_conv_desc {
     int* c8_toff_bwd;
 };
 
-void conv_c8_free_tables(vl_conv_desc* d);   // conv_c8.hip; called when the halos change and at destroy
+void conv_c8_free_tables(vl_conv_desc* d);   // conv_c8.hip; at destroy
+int conv_c8_build_tables(vl_conv_desc* d);    // conv_c8.hip; from rebuild_tables (create, set_halo, phase split): 0, or 2 on allocation failure

@@ -1988,6 +1988,7 @@ static int rebuild_tables(vl_conv_desc* d) {
         const int needw = (d->kw - 1 - d->pl > d->pl ? d->kw - 1 - d->pl : d->pl);
         d->bwd_padded = d->dy_halo >= need && d->dy_halo >= needw;
     }
+    if (rc == 0) rc = conv_c8_build_tables(d);     // the packed-bf16 path's tap tables (conv_c8.hip) follow the same halos
     return rc;
 }
 
@@ -2025,7 +2026,6 @@ extern "C" int vl_conv_set_halo(vl_conv_desc* d, int x_halo, int y_halo, int dy_
     VL_CHECK(x_halo >= 0 && y_halo >= 0 && dy_halo >= 0 && dx_halo >= 0 && x_halo < 64 && y_halo < 64 && dy_halo < 64 && dx_halo < 64,
              "vl_conv_set_halo: bad halo");
     d->x_halo = x_halo; d->y_halo = y_halo; d->dy_halo = dy_halo; d->dx_halo = dx_halo;
-    conv_c8_free_tables(d);            // conv_c8.hip rebuilds its tap tables for the new halos on first use
     VL_CHECK(rebuild_tables(d) == 0, "vl_conv_set_halo: device table allocation failed");
     return 0;
 }
