@@ -234,3 +234,24 @@ def test_adam_and_dropout_run():
     onehot = torch.tensor(O.labels_to_one_hot([[0], [1]], ncls), device=DEV)
     losses = [eng.train_step_u8(frames, onehot, lr=1e-3, clip_norm=10.0, mean_bgr=MEAN)["loss"] for _ in range(8)]
     assert all(np.isfinite(losses)) and min(losses[4:]) < losses[0]
+
+
+def test_two_stream_backward_equals_one_stream(monkeypatch):
+    """engine._side_stream: weight gradients (and fc6's input gradient) on a second HIP stream beside the input gradients.  Same kernels
+    on the same buffers, so three steps must leave exactly the parameters of the one-stream schedule -- a missing wait would not."""
+    rng = np.random.default_rng(9)
+    shape, ncls, fpc, b = (99, 83, 3), 6, 4, 3
+    frames = torch.tensor(rng.integers(0, 256, (b * fpc,) + shape, dtype=np.uint8), device=DEV)
+    onehot = torch.tensor(O.labels_to_one_hot([[l] for l in rng.integers(0, ncls, b)], ncls), device=DEV)
+    results = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("VLTF_WGRAD_STREAM", mode)
+        cfg, eng = make(dict(num_classes=ncls, fpc=fpc, lstm_hidden=16), shape, b)
+        eng.load_params(oracle_params(np.random.default_rng(4), cfg, shape))
+        outs = [eng.train_step_u8(frames, onehot, lr=0.01, clip_norm=1.0, mean_bgr=MEAN) for _ in range(3)]
+        assert (eng._side_stream() is not None) == (mode == "1")
+        results.append((eng.get_params(), [(o["loss"], o["grad_norm"]) for o in outs]))
+    (p0, o0), (p1, o1) = results
+    assert o0 == o1
+    for k in p0:
+        assert np.array_equal(p0[k], p1[k]), k
