@@ -629,7 +629,7 @@ __global__ __launch_bounds__(512) void lrn_pool_fwd_kernel(const float* __restri
 #pragma unroll
     for (int q = 0; q < PPT; ++q) {
         const int pix = threadIdx.x + q * T;
-        lpix[q] = pix < npix ? pix : -1;
+        lpix[q] = pix < npix ? pix : -1;                              // (-1: its LRN values go to the buffer's spare slot)
         voff_x[q] = pix < npix ? (uint32_t)(p_base + pix) * (C8 == 2 ? 16u : 4u) : PW_OOB;
     }
     // pooled outputs of a chunk: o = tid + s T  <->  (slab ci, pooled row, pooled column)
@@ -662,7 +662,7 @@ __global__ __launch_bounds__(512) void lrn_pool_fwd_kernel(const float* __restri
         for (int d = 0; d < 5; ++d) xw[q][d] = 0.f;
 
     auto chunk = [&](int c0, int buf, const float (&xin)[PPT][CHK]) {
-        float* lb = lbuf + buf * CHK * npix;
+        float* lb = lbuf + buf * (CHK * npix + 1);                    // + 1: the spare slot idle lanes write to (no exec-mask branch)
         // LRN outputs of channels c0 - 2 .. c0 + CHK - 3 -> slabs 0 .. CHK - 1
 #pragma unroll
         for (int i = 0; i < CHK; ++i) {
@@ -675,14 +675,15 @@ __global__ __launch_bounds__(512) void lrn_pool_fwd_kernel(const float* __restri
                 const float sc = bias + alpha * sq;
                 const float rq = __builtin_amdgcn_rsqf(sc);
                 const float l = xw[q][2] * (rq * __builtin_amdgcn_sqrtf(rq));   // x * sc^-0.75 (pow_neg's beta = 0.75 form)
-                if (lpix[q] >= 0) lb[i * npix + lpix[q]] = l;
+                lb[lpix[q] >= 0 ? i * npix + lpix[q] : CHK * npix] = l;
             }
         }
         __syncthreads();
 #pragma unroll
         for (int sl = 0; sl < NSL; ++sl) {
             const int c = c0 - 2 + (s_out[sl] >> 24);
-            if (s_out[sl] >= 0 && c >= 0 && c < C) {
+            const bool live = s_out[sl] >= 0 && c >= 0 && c < C;      // dead lanes scan slab 0's first window and store out of range
+            {
                 const float* wp = lb + s_lds[sl];
                 float best = -INFINITY;
                 int bi = 0;
@@ -700,11 +701,11 @@ __global__ __launch_bounds__(512) void lrn_pool_fwd_kernel(const float* __restri
                 if constexpr (C8 != 0) {
                     const __bf16 hb = (__bf16)best;
                     __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(uint16_t, hb), rs_p,
-                                                          ((c >> 3) * pplane + (s_out[sl] & 0xffffff)) * 16 + (c & 7) * 2, 0, 0);
+                                                          live ? ((c >> 3) * pplane + (s_out[sl] & 0xffffff)) * 16 + (c & 7) * 2 : (int)PW_OOB, 0, 0);
                 } else {
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, best), rs_p, off * 4, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, best), rs_p, live ? off * 4 : (int)PW_OOB, 0, 0);
                 }
-                __builtin_amdgcn_raw_buffer_store_b8((uint8_t)bi, rs_a, off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b8((uint8_t)bi, rs_a, live ? off : (int)PW_OOB, 0, 0);
             }
         }
     };
@@ -760,7 +761,7 @@ static int launch_lrn_pool_fwd(const float* x, float* p, uint8_t* argmax, int n,
         const int npix = (2 * cand + 1) * w;
         const int need_px = ceil_div(npix, PPT), need_out = ceil_div((int64_t)CHK * cand * ow, NSL);
         int t = ceil_div(need_px > need_out ? need_px : need_out, 64) * 64;
-        if (t <= 512 && (size_t)2 * CHK * npix * sizeof(float) <= 64 * 1024) {
+        if (t <= 512 && (size_t)2 * (CHK * npix + 1) * sizeof(float) <= 64 * 1024) {
             prb = cand;
             threads = t < 64 ? 64 : t;
         }
@@ -773,7 +774,7 @@ static int launch_lrn_pool_fwd(const float* x, float* p, uint8_t* argmax, int n,
         const int need_px = ceil_div((2 * prb + 1) * w, PPT), need_out = ceil_div((int64_t)CHK * prb * ow, NSL);
         threads = ceil_div(need_px > need_out ? need_px : need_out, 64) * 64;
     }
-    const size_t lds = (size_t)2 * CHK * (2 * prb + 1) * w * sizeof(float);
+    const size_t lds = (size_t)2 * (CHK * (2 * prb + 1) * w + 1) * sizeof(float);       // two buffers, each with a spare slot
     if (getenv("VL_LRN_POOL_VERBOSE")) fprintf(stderr, "lrn_pool_fwd<%d,%d,%d>: bands %d prb %d threads %d lds %zu\n", CHK, PPT, NSL, bands, prb, threads, lds);
     hipLaunchKernelGGL((lrn_pool_fwd_kernel<CHK, PPT, NSL, C8>), dim3(bands, n), dim3(threads), lds, stream, x, p, argmax, c, h,
                        w, oh, ow, prb, (int)pplane, owp, p_halo, alpha, bias);
