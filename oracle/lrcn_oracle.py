@@ -694,7 +694,8 @@ def tensor_list_fusion(inputs, method, dims, fpcs, cpvs):
         return np.mean(np.stack(inputs), axis=0), dims[0], fpcs[0], cpvs[0], ("avg", len(inputs))
     if method == "maximum":
         st = np.stack(inputs)
-        return st.max(axis=0), dims[0], fpcs[0], cpvs[0], ("maximum", st.argmax(axis=0), len(inputs))
+        mx = st.max(axis=0)
+        return mx, dims[0], fpcs[0], cpvs[0], ("maximum", st == mx, len(inputs))
     if method == "concat":
         if cpv_ratio == 1:
             return np.concatenate(inputs, axis=1), sum(dims), fpcs[0], cpvs[0], ("concat", list(dims))
@@ -718,7 +719,9 @@ def tensor_list_fusion_grad(cache, d):
     if kind == "avg":
         return [d / cache[1]] * cache[1]
     if kind == "maximum":
-        return [d * (cache[1] == i) for i in range(cache[2])]
+        # tf.reduce_max's registered gradient (_MinOrMaxGrad): the inputs equal to the maximum share it evenly
+        hit = cache[1]
+        return [d * hit[i] / hit.sum(axis=0) for i in range(cache[2])]
     if kind == "concat":
         out, pos = [], 0
         for dim in cache[1]:
@@ -833,6 +836,177 @@ def encdec_backward(p, cache, dlogits, fpc_frames, enc, dtype=F64):
     g, _, dstate = lstm_classifier_backward(p, cache["dec"], dlogits, dtype)
     ge = lrcn_backward(pe, cache["enc"], dstate, fpc_frames, enc["layer"], enc["layers"], "state", dtype, "lstm", None)
     g.update({"enc/" + k: v for k, v in ge.items()})
+    return g
+
+
+# ----------------------------------------------------------------------------------------------
+# The general pipeline graph -- Model.__init__ / Model.build_pipeline (models/model.py:18-162)
+# ----------------------------------------------------------------------------------------------
+def convert_dim_fc(p, name, x, out_dim, dtype=F64):
+    """tf_util.py:32-60: identity when the width already matches, else x @ <name>_w + <name>_b."""
+    if x.shape[-1] == out_dim:
+        return x, False
+    return xw_plus_b(x, p[name + "_w"], p[name + "_b"], dtype), True
+
+
+def _sub(p, scope):
+    return {k[len(scope):]: v for k, v in p.items() if k.startswith(scope)} if scope else p
+
+
+def pipeline_forward(p, scope, spec, ins, num_classes, dtype=F64, chunk=32):
+    """Model.build_pipeline (model.py:18-155) for one pipeline.
+    spec: the YAML keys of settings_.py:167-208 -- input, input_fusion, representation (dcnn | nop | fc), frame_encoding_layer,
+    fc_output_dim, classifier (None | fc | lstm), lstm_params [hidden, layers, fusion], frame_fusion (type, method).
+    ins: [(tensor, cpv, fpc)] per input, in order.  Variables are named `scope` + the TF names.
+    -> (output, cpv, fpc of the output, cache)."""
+    tensors = [t for t, _, _ in ins]
+    cpvs, fpcs = [c for _, c, _ in ins], [f for _, _, f in ins]
+    dims = [int(t.shape[-1]) for t in tensors]
+    cpv = cpvs[-1]                        # model.py:44-59: `cpv` is the loop variable, i.e. the LAST input's, whatever the fusion does
+    c = {"spec": spec, "scope": scope}
+    ftype, fmethod = spec.get("frame_fusion") or (None, None)
+    classif = spec.get("classifier")
+    if classif is None and ftype == "late":
+        raise ValueError("Specified late fusion with no classifier selected")                          # model.py:36-37
+    if spec.get("input_fusion") is not None:                                                           # model.py:69-73
+        x, dim, fpc, cpv0, fcache = tensor_list_fusion([t.astype(dtype) for t in tensors], spec["input_fusion"], dims, fpcs, cpvs)
+        tensors, dims, fpcs, cpvs = [x], [dim], [fpc], [cpv0]
+        c["in_fusion"] = fcache
+    x, fpc = tensors[0], fpcs[0]
+    out_fpc = fpc
+    rep = spec["representation"]
+    if rep == "dcnn":                                                                                  # model.py:81-84
+        layer = spec["frame_encoding_layer"]
+        pd = _sub(p, scope)
+        feats, cc = [], []
+        for s0 in range(0, x.shape[0], chunk):
+            f, ch = alexnet_forward(pd, x[s0:s0 + chunk], layer, dtype, True)
+            feats.append(f)
+            cc.append(ch)
+        feat = np.concatenate(feats, axis=0)
+        c.update(cnn=cc, chunk=chunk, layer=layer)
+    elif rep == "nop":
+        feat = x.astype(dtype)
+    elif rep == "fc":                                                                                  # vectorizer.py:77-78
+        c["rep_in"] = x.astype(dtype)
+        feat, c["rep_fc"] = convert_dim_fc(p, scope + "fc_convert", c["rep_in"], spec["fc_output_dim"], dtype)
+    else:
+        raise ValueError("Undefined representation [%s]" % rep)
+    dim = feat.shape[-1]
+    c["feat_shape"] = feat.shape
+    if ftype == "early" and fpc > 1:                                                                   # model.py:103-106
+        feat = temporal_fusion(feat.reshape(-1, fpc, dim), fmethod)
+        c["early"] = (fpc, fmethod)
+        out_fpc = 1
+    if classif is None:                                                                                # model.py:110-112
+        return feat, cpv, out_fpc, c
+    if classif == "fc":                                                                                # model.py:115-119
+        if rep == "fc" and c["rep_fc"] and dim != num_classes:
+            raise ValueError("Variable %sfc_convert_w already exists" % scope)                         # tf.get_variable, tf_util.py:48
+        c["cls_in"] = feat
+        logits, c["cls_fc"] = convert_dim_fc(p, scope + "fc_convert", feat, num_classes, dtype)
+    elif classif == "lstm":                                                                            # model.py:120-141
+        if fpc == 1:
+            raise ValueError("The LSTM classifier requires an fpc greater than 1")
+        if ftype not in (None, "none"):
+            raise ValueError("The LSTM classifier should be used only with [none] fusion, but it's [%s]" % ftype)
+        hidden, layers, lfusion = spec["lstm_params"][:3]
+        state = None
+        if len(tensors) > 1:                                                                           # the 2nd input is the state vector
+            if len(tensors) != 2:
+                raise ValueError("too many values to unpack (expected 2)")                             # tf_util.py:184
+            ratio = int(cpvs[0] / cpvs[1])
+            state = replicate_auxilliary_tensor(tensors[1].astype(dtype), ratio)
+            c["state_rep"] = (ratio, tensors[1].shape[0])
+        logits, c["lstm"] = lstm_classifier_forward(p, scope, feat, fpc, layers, lfusion, num_classes, state=state, dtype=dtype)
+    else:
+        raise ValueError("Undefined classifier [%s]" % classif)
+    if ftype == "late" and fpc > 1:                                                                    # model.py:149-151
+        c["late"] = (logits.shape, fpc, fmethod)
+        logits = temporal_fusion(logits.reshape(-1, fpc, num_classes), fmethod)
+    return logits, cpv, 1, c
+
+
+def pipeline_backward(p, c, dout, num_inputs, dtype=F64):
+    """-> (gradients of the pipeline's variables, [d/d(input i)], None for an input no gradient flows to: raw frames)."""
+    spec, scope = c["spec"], c["scope"]
+    g = {}
+    d = dout.astype(dtype)
+    dstate = None
+    classif = spec.get("classifier")
+    if "late" in c:
+        shape, fpc, fmethod = c["late"]
+        d = temporal_fusion_grad((shape[0] // fpc, fpc, shape[1]), fmethod, d).reshape(shape)
+    if classif == "fc":
+        if c["cls_fc"]:
+            g[scope + "fc_convert_w"] = c["cls_in"].T @ d
+            g[scope + "fc_convert_b"] = d.sum(0)
+            d = d @ p[scope + "fc_convert_w"].astype(dtype).T
+    elif classif == "lstm":
+        gl, d, dstate = lstm_classifier_backward(p, c["lstm"], d, dtype)
+        g.update(gl)
+        if dstate is not None:
+            ratio, rows = c["state_rep"]
+            dstate = replicate_auxilliary_tensor_grad(dstate, ratio, rows)
+    if "early" in c:
+        fpc, fmethod = c["early"]
+        fs = c["feat_shape"]
+        d = temporal_fusion_grad((fs[0] // fpc, fpc, fs[1]), fmethod, d).reshape(fs)
+    rep = spec["representation"]
+    if rep == "dcnn":
+        pd = _sub(p, scope)
+        for ci, cc in enumerate(c["cnn"]):
+            gc = alexnet_backward(pd, cc, d[ci * c["chunk"]:(ci + 1) * c["chunk"]], c["layer"], dtype)
+            for k, v in gc.items():
+                g[scope + k] = g[scope + k] + v if scope + k in g else v
+        d = None                                            # the input is a dataset placeholder
+    elif rep == "fc" and c["rep_fc"]:
+        g[scope + "fc_convert_w"] = c["rep_in"].T @ d
+        g[scope + "fc_convert_b"] = d.sum(0)
+        d = d @ p[scope + "fc_convert_w"].astype(dtype).T
+    if "in_fusion" in c:
+        return g, (tensor_list_fusion_grad(c["in_fusion"], d) if d is not None else [None] * num_inputs)
+    return g, [d] + ([dstate] if num_inputs > 1 else [])
+
+
+def model_forward(p, pipelines, datasets, feeds, num_classes, dtype=F64, chunk=32):
+    """Model.__init__ (model.py:157-162): the pipelines are built in order, an input is a dataset tag (a placeholder: feeds[tag],
+    with datasets[tag] = {"cpv", "fpc"}) or the output of an earlier pipeline; the LAST pipeline's output is the logits.
+    pipelines: [(name, spec)].  With more than one pipeline every variable is scoped "<pipeline>/<tf name>" (in the reference a
+    second dcnn gets TF's automatic "dcnn_1/" name scope and a second LSTM / fc_convert cannot be created at all).
+    -> (logits, cache)."""
+    scoped = len(pipelines) > 1
+    outs, shapes, cache = {}, {}, {"order": [n for n, _ in pipelines], "pipes": {}, "sources": {}}
+    for name, spec in pipelines:
+        ins = []
+        for src in spec["input"]:
+            if src in outs:
+                ins.append((outs[src],) + shapes[src])
+            else:
+                ins.append((feeds[src], datasets[src]["cpv"], datasets[src]["fpc"]))
+        out, cpv, fpc, c = pipeline_forward(p, name + "/" if scoped else "", spec, ins, num_classes, dtype, chunk)
+        outs[name], shapes[name] = out, (cpv, fpc)
+        cache["pipes"][name], cache["sources"][name] = c, list(spec["input"])
+    cache["outputs"] = outs
+    return outs[pipelines[-1][0]], cache
+
+
+def model_backward(p, cache, dlogits, dtype=F64):
+    """Gradients of model_forward's logits wrt every variable in p (zeros for a pipeline nothing downstream consumes)."""
+    order = cache["order"]
+    dout = {order[-1]: dlogits.astype(dtype)}
+    g = {}
+    for name in reversed(order):
+        if name not in dout:
+            continue
+        gp, dins = pipeline_backward(p, cache["pipes"][name], dout[name], len(cache["sources"][name]), dtype)
+        g.update(gp)
+        for src, d in zip(cache["sources"][name], dins):
+            if src in cache["pipes"] and d is not None:
+                dout[src] = dout[src] + d if src in dout else d
+    for k, v in p.items():
+        if k not in g:
+            g[k] = np.zeros(v.shape, dtype)
     return g
 
 
