@@ -241,7 +241,8 @@ int vl_lstm_step_bwd(const float* dout, const float* dh_next, const float* act, 
  * H <= 512: weight-stationary cluster form -- ceil(H/16) workgroups per group of <= 8 clips keep their 64 gate columns of kh in
  * LDS for the whole sequence and exchange h_t (forward) / partial dh_{t-1} (backward) through tagged 8-byte words in `ws`
  * (agent-scope atomics, bounded spins); larger H: one workgroup per clip streaming kh every step.
- * ws: device scratch of vl_lstm_seq_ws_bytes(batch, T, H) bytes, contents irrelevant before and after the call. */
+ * ws: device scratch of vl_lstm_seq_ws_bytes(batch, T, H) bytes, ZEROED ONCE by the caller when it is allocated: its first word is
+ * the sticky time-out flag of vl_lstm_seq_status, which no launch clears; the rest is scratch. */
 size_t vl_lstm_seq_ws_bytes(int batch, int T, int H);
 int vl_lstm_seq_fwd(const float* gx, const float* kh, const float* h0, const float* c0, float* act, float* cseq, float* hseq,
                     float* hprev, int batch, int T, int H, float forget_bias, void* ws, size_t ws_bytes, vl_stream_t stream);
@@ -249,9 +250,14 @@ int vl_lstm_seq_fwd(const float* gx, const float* kh, const float* h0, const flo
  * dh0 / dc0 (nullable, [batch][H]) receive the gradients w.r.t. the initial output / cell state. */
 int vl_lstm_seq_bwd(const float* dout, const float* kh, const float* act, const float* cseq, const float* c0, float* dz,
                     float* dh0, float* dc0, int batch, int T, int H, void* ws, size_t ws_bytes, vl_stream_t stream);
-/* Synchronous check of the last vl_lstm_seq_* call on `ws`: *timed_out = 1 if a workgroup of the cluster form gave up
- * waiting for its peers (results are then invalid; it never hangs). */
-int vl_lstm_seq_status(const void* ws, int* timed_out);
+/* Synchronous read-and-reset of the time-out flag in `ws`: *timed_out = 1 if a workgroup of ANY cluster-form launch on `ws` since
+ * the last call of this function gave up waiting for its peers (the cluster form needs all its workgroups resident at once: one
+ * per CU; a launch that shares the device with another kernel holding CUs can starve).  Results are then invalid -- it never
+ * hangs -- and the caller must discard the step (LRCNEngine / GraphEngine raise). */
+int vl_lstm_seq_status(void* ws, int* timed_out);
+/* Test hooks of the cluster form, process-wide: spin_limit polls before a gather gives up (0 = the default 2^18);
+ * mute_workgroup >= 0: that workgroup of every launch publishes nothing, so its peers time out (-1 = off). */
+int vl_lstm_seq_test_hooks(unsigned spin_limit, int mute_workgroup);
 /* dst[cols][rows] = src[rows][cols]^T (src row stride ld). */
 int vl_transpose(const float* src, int64_t ld, float* dst, int rows, int cols, vl_stream_t stream);
 

@@ -6,6 +6,10 @@ Cases (full AlexNet geometry, 227x227x3, fc6 encode -> LSTM(256, 1 layer, avg) -
   cfg2_ref   the same job with the reference initialiser (sigma 0.05, alexnet.py:40-46) -- exactly bench.py's inputs:
              frames default_rng(0), labels default_rng(1000), parameters engine.init_params(cfg, seed=2)
   t32_ws     BASELINE config 5's clip length: 4 clips x 32 frames, well-scaled weights
+  c3shard_ref  BASELINE config 3: rank 0's shard of bench.py's strong-scaling job at 8 GPUs -- clips 0..7 of the 64 (8 clips x 16
+             frames, the first 128 frames / 8 labels of cfg2_ref's streams), reference initialiser; a plain 8-clip step (the
+             shard's 1/64 loss scaling is a constant factor 8/64 on every gradient, applied by the test)
+  c3pair_ws  the same 8 clips as ONE global batch with well-scaled weights: the answer a 2-rank run (4 + 4 clips) must reproduce
 
 Inputs are regenerated from these seeds by the tests (tests/test_full_workload_gpu.py) and by bench.py's first-step check;
 only the oracle's outputs are stored: logits, loss, global gradient norm, accuracy, per-tensor gradient norms, 16-element heads
@@ -33,6 +37,8 @@ CASES = {
     "cfg2_ws": (64, 16, True),
     "cfg2_ref": (64, 16, False),
     "t32_ws": (4, 32, True),
+    "c3shard_ref": (8, 16, False),
+    "c3pair_ws": (8, 16, True),
 }
 ACT_LAYERS = ("conv1", "lrn1", "pool1", "conv2", "lrn2", "pool2", "conv3", "conv4", "conv5", "pool5", "fc6")
 

@@ -123,8 +123,9 @@ def test_one_rank_rccl_step_equals_plain_step():
 
 def test_one_rank_rccl_step_on_the_bf16_path():
     """BASELINE config 5 is the bf16 conv path under data parallelism: the same one-rank RCCL step with conv_math="bf16" (packed
-    operands, csrc/conv_c8.hip).  The data-parallel form computes fc6's weight gradient in row blocks with fp32 products where the
-    plain step uses one split-bf16 GEMM, so the two runs agree to bf16 level, not bitwise."""
+    operands, csrc/conv_c8.hip).  The data-parallel form computes fc6's weight gradient in four row blocks on the packed-operand
+    kernel (engine._backward: one vl_gemm_kc8 per block, its all-reduce issued right behind it) where the plain step runs one
+    product over all rows; the split-k slab count may differ between the two, so the runs are held to bf16 level, not bitwise."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     pr = ctx.Process(target=nccl_worker, args=(free_port(), q, "bf16"))

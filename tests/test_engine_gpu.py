@@ -255,3 +255,30 @@ def test_two_stream_backward_equals_one_stream(monkeypatch):
     assert o0 == o1
     for k in p0:
         assert np.array_equal(p0[k], p1[k]), k
+
+
+def test_engine_reports_an_lstm_cluster_timeout():
+    """The product path reads the cluster LSTM's sticky time-out word wherever it fetches results: a step whose recurrence gave up
+    on a peer workgroup raises instead of returning wrong numbers (forced with the library's test hooks), and the engine is
+    usable again afterwards."""
+    from vltf_amd import ops
+    from vltf_amd._ffi import VltfError
+    rng = np.random.default_rng(6)
+    shape, ncls, fpc, b = (67, 67, 3), 7, 4, 2
+    cfg, eng = make(dict(num_classes=ncls, fpc=fpc, frame_encoding_layer="fc6", lstm_hidden=32, lstm_layers=1, fusion="avg"), shape, b)
+    p = oracle_params(rng, cfg, shape)
+    eng.load_params(p)
+    frames = torch.tensor(rng.integers(0, 256, (b * fpc,) + shape, dtype=np.uint8), device=DEV)
+    onehot = torch.tensor(O.labels_to_one_hot([[l] for l in rng.integers(0, ncls, b)], ncls), device=DEV)
+    try:
+        ops.lstm_seq_test_hooks(spin_limit=64, mute_workgroup=1)
+        with pytest.raises(VltfError, match="timed out"):
+            eng.train_step_u8(frames, onehot, lr=0.0, clip_norm=0.0, mean_bgr=MEAN)
+        eng.forward_u8(frames, MEAN)
+        with pytest.raises(VltfError, match="timed out"):
+            eng.logits_host()
+    finally:
+        ops.lstm_seq_test_hooks()
+    eng.load_params(p)
+    out = eng.train_step_u8(frames, onehot, lr=0.0, clip_norm=0.0, mean_bgr=MEAN)
+    assert np.isfinite(out["loss"])

@@ -20,7 +20,8 @@ DEV = "cuda:0"
 MEAN = np.array([99.197148, 105.293620, 109.503945], np.float32)
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lrcn_full.npz")
 SHAPE, NCLS, HID, LR, CLIP = (227, 227, 3), 101, 256, 1e-3, 10.0
-CASES = {"cfg2_ws": (64, 16, True), "cfg2_ref": (64, 16, False), "t32_ws": (4, 32, True)}     # = make_golden_full.CASES
+CASES = {"cfg2_ws": (64, 16, True), "cfg2_ref": (64, 16, False), "t32_ws": (4, 32, True),       # = make_golden_full.CASES
+         "c3shard_ref": (8, 16, False), "c3pair_ws": (8, 16, True)}
 
 
 def case_inputs(name):
@@ -93,17 +94,22 @@ def test_benchmark_job_matches_oracle_fixture(name):
     want = gold[name + "/logits"]
     assert np.abs(fwd - want).max() <= 1e-3, "forward logits: max |d| %.3e" % np.abs(fwd - want).max()
     out = eng.train_step_u8(fd, od, lr=LR, clip_norm=CLIP, mean_bgr=MEAN)
-    got_logits = eng.logits_host()
-    assert np.abs(got_logits - want).max() <= 1e-3
+    check_step_against_fixture(gold, name, p, clips, out, eng.logits_host(), eng.get_grads(), eng.get_params())
+
+
+def check_step_against_fixture(gold, name, p, clips, out, got_logits, g, newp, grad_scale=1.0):
+    """One train step's outputs against the fixture case `name`.  grad_scale: constant factor between the step's gradients and
+    the fixture's (a rank's shard of a larger global batch scales its loss by local / global rows); with it != 1 the update heads
+    are skipped (the clip threshold does not scale along)."""
+    assert np.abs(got_logits - gold[name + "/logits"]).max() <= 1e-3
     loss, gn, acc = gold[name + "/loss_gn_acc"]
+    gn = gn * grad_scale
     assert abs(out["loss"] - loss) <= 1e-4 * max(1.0, abs(loss)), (out["loss"], loss)
     assert abs(out["grad_norm"] - gn) <= 2e-3 * gn, (out["grad_norm"], gn)
     assert abs(out["accuracy"] - acc) <= 1.0 / clips + 1e-9
-    g = eng.get_grads()
-    newp = eng.get_params()
     clip_scale = CLIP / max(gn, CLIP)
     for k in p:
-        gk = g[k].astype(np.float64).ravel()
+        gk = g[k].astype(np.float64).ravel() / grad_scale
         wn = float(gold["%s/gradnorm/%s" % (name, k)][0])
         assert abs(np.linalg.norm(gk) - wn) <= 2e-3 * wn + 1e-12, "grad norm of %s: %.6e vs %.6e" % (k, np.linalg.norm(gk), wn)
         # a 64-element strided sample + the 16-element head: direction of the gradient, not only its length
@@ -111,10 +117,91 @@ def test_benchmark_job_matches_oracle_fixture(name):
         for tag, gv in (("gradsample", gk[idx]), ("gradhead", gk[:16])):
             ws = gold["%s/%s/%s" % (name, tag, k)]
             assert np.linalg.norm(gv - ws) <= 2e-2 * np.linalg.norm(ws) + 2e-3 * wn / np.sqrt(gk.size) * np.sqrt(ws.size), (tag, k)
-        # the update actually applied: w - lr * clip_scale * g
-        wh = gold["%s/newhead/%s" % (name, k)]
-        np.testing.assert_allclose(newp[k].ravel()[:16], wh, rtol=1e-5, atol=LR * clip_scale * 2e-2 * np.abs(gk[:16]).max() + 1e-7,
-                                   err_msg="updated " + k)
+        if grad_scale == 1.0:       # the update actually applied: w - lr * clip_scale * g
+            wh = gold["%s/newhead/%s" % (name, k)]
+            np.testing.assert_allclose(newp[k].ravel()[:16], wh, rtol=1e-5, atol=LR * clip_scale * 2e-2 * np.abs(gk[:16]).max() + 1e-7,
+                                       err_msg="updated " + k)
+
+
+def test_config3_shard_on_two_streams_matches_fixture_and_the_one_stream_schedule(monkeypatch):
+    """BASELINE config 3's per-rank work: rank 0's shard of bench.py's 8-GPU strong-scaling job (clips 0..7 of the 64, 128 frames
+    of 227x227, reference initialiser, loss scaled by 1/64 as engine._train does under data parallelism).  At this size the
+    backward runs its independent launches on TWO streams by default (engine._side_stream): (a) the step equals the fp64 oracle's
+    fixture case c3shard_ref at the benchmark tolerances, (b) every gradient is BITWISE equal to the one-stream schedule's
+    (VLTF_WGRAD_STREAM=0) at this full geometry, where the overlapped kernels run for hundreds of microseconds."""
+    from vltf_amd.engine import LRCNEngine
+    gold = np.load(GOLD)
+    if "c3shard_ref/logits" not in gold.files:
+        pytest.fail("fixture case c3shard_ref missing from lrcn_full.npz (run tests/golden/make_golden_full.py)")
+    cfg, p, frames, onehot = case_inputs("c3shard_ref")
+    clips = CASES["c3shard_ref"][0]
+    eng = LRCNEngine(cfg, max_clips=clips, device=DEV)
+    fd, od = torch.from_numpy(frames).to(DEV), torch.from_numpy(onehot).to(DEV)
+    runs = {}
+    for mode in ("", "0", "1"):                       # default (ON at 128 frames), forced off, forced on
+        monkeypatch.setenv("VLTF_WGRAD_STREAM", mode) if mode else monkeypatch.delenv("VLTF_WGRAD_STREAM", raising=False)
+        eng.load_params(p)
+        out = eng.train_step_u8(fd, od, lr=LR, clip_norm=CLIP, mean_bgr=MEAN, global_rows=64)
+        assert (eng._side_stream() is not None) == (mode != "0")
+        runs[mode] = (out, eng.logits_host(), eng.get_grads(), eng.get_params())
+    out, logits, g, newp = runs[""]
+    check_step_against_fixture(gold, "c3shard_ref", p, clips, out, logits, g, newp, grad_scale=clips / 64.0)
+    for k in p:
+        assert np.array_equal(runs[""][2][k], runs["0"][2][k]), "two-stream gradient of %s differs from the one-stream schedule" % k
+        assert np.array_equal(runs["1"][3][k], runs["0"][3][k]), "updated %s differs" % k
+
+
+def _pair_worker(rank, world, port, q):
+    """One rank of the 2-rank full-geometry run: 4 of the 8 clips of fixture case c3pair_ws, gloo backend (two ranks on one GPU)."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from vltf_amd import dp
+    from vltf_amd.engine import LRCNEngine
+    dp.init_from_env(backend="gloo")
+    cfg, p, frames, onehot = case_inputs("c3pair_ws")
+    clips, fpc = CASES["c3pair_ws"][:2]
+    lo, hi = dp.shard_range(clips, rank, world)
+    gar = dp.GradAllReduce()
+    eng = LRCNEngine(cfg, max_clips=hi - lo, device=DEV, dp=gar)
+    eng.load_params(p)
+    gar.broadcast_params(eng.w)
+    out = eng.train_step_u8(torch.from_numpy(frames[lo * fpc:hi * fpc]).to(DEV), torch.from_numpy(onehot[lo:hi]).to(DEV), lr=LR,
+                            clip_norm=CLIP, mean_bgr=MEAN, global_rows=clips)
+    tot = gar.sum_scalars(torch.tensor([out["loss_sum"], out["correct"], float(out["rows"])], device=DEV, dtype=torch.float64)).cpu().numpy()
+    logits = [None] * world
+    torch.distributed.all_gather_object(logits, eng.logits_host())
+    if rank == 0:
+        out = dict(out, loss=float(tot[0] / tot[2]), accuracy=float(tot[1] / tot[2]))
+        q.put((out, np.concatenate(logits), eng.get_grads(), eng.get_params(), gar.issued, len(eng.grad_chunks)))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_config3_two_rank_full_geometry_step_equals_oracle_fixture():
+    """Multi-rank correctness at the benchmark's geometry: 2 ranks x 4 clips x 16 frames of 227x227 (gloo: both ranks share the one
+    GPU), chunked all-reduce inside the two-stream backward; the reduced gradients, their global norm, the loss and the applied
+    update must equal the fp64 oracle's answer for the 8-clip batch (fixture c3pair_ws) at the single-rank tolerances."""
+    import socket
+    import torch.multiprocessing as mp
+    gold = np.load(GOLD)
+    if "c3pair_ws/logits" not in gold.files:
+        pytest.fail("fixture case c3pair_ws missing from lrcn_full.npz (run tests/golden/make_golden_full.py)")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_pair_worker, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    res = q.get(timeout=600)
+    for pr in procs:
+        pr.join(300)
+        assert pr.exitcode == 0, "rank exited with %s" % pr.exitcode
+    out, logits, g, newp, issued, nchunks = res
+    assert issued == nchunks >= 7          # [classifier + LSTM], 4 fc6W row blocks, conv5..3, conv2..1
+    _, p, _, _ = case_inputs("c3pair_ws")
+    check_step_against_fixture(gold, "c3pair_ws", p, CASES["c3pair_ws"][0], out, logits, g, newp)
 
 
 @pytest.mark.parametrize("ws", [True, False])

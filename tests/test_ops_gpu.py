@@ -502,7 +502,8 @@ def test_lstm_persistent_kernels(ops, b, T, d, H, init):
     act, cseq = torch.empty((b * T, 4 * H), device=DEV), torch.empty((b * T, H), device=DEV)
     hseq, hprev = torch.empty((b * T, H), device=DEV), torch.empty((b * T, H), device=DEV)
     ws = ops.lstm_seq_ws(b, T, H, DEV)
-    ws.fill_(float("nan"))                                       # contents before the call are irrelevant
+    ws[64:].fill_(float("nan"))                                  # scratch contents before the call are irrelevant (the first 256 bytes
+                                                                 # hold the sticky status word: zeroed once at allocation)
     ops.lstm_seq_fwd(gx, kd[d:], act, cseq, hseq, hprev, b, T, H, ws=ws, h0=s0d, c0=s0d)
     assert not ops.lstm_seq_timed_out(ws)
     # a 4096-term fp32 pre-activation of size ~2 carries ~5e-6 of rounding (measured 5.5e-6 .. 8.1e-6 on |h| <= 1): the per-op
@@ -549,6 +550,40 @@ def test_lstm_cluster_is_deterministic_and_reentrant(ops):
         res.append((host(hseq), host(dz)))
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
     assert np.abs(res[0][1]).max() > 0
+
+
+def test_lstm_cluster_timeout_is_sticky_until_read(ops):
+    """A workgroup that never hears from a peer gives up after the spin limit and raises the status word (wrong results, no
+    hang).  The word is sticky: a later healthy launch on the same workspace does not clear it; reading it does.
+    Forced with the library's test hooks: workgroup 0 publishes nothing, 64 polls instead of 2^18."""
+    rng = np.random.default_rng(4)
+    b, T, H = 8, 6, 256
+    gx = dev((rng.standard_normal((b * T, 4 * H)) * 1.5).astype(np.float32))
+    kh = dev((rng.standard_normal((H, 4 * H)) * 0.05).astype(np.float32))
+    dout = dev(rng.standard_normal((b * T, H)).astype(np.float32))
+    ws = ops.lstm_seq_ws(b, T, H, DEV)
+    act, cseq = torch.zeros((b * T, 4 * H), device=DEV), torch.zeros((b * T, H), device=DEV)
+    hseq, hprev, dz = torch.zeros((b * T, H), device=DEV), torch.zeros((b * T, H), device=DEV), torch.zeros((b * T, 4 * H), device=DEV)
+    try:
+        ops.lstm_seq_test_hooks(spin_limit=64, mute_workgroup=0)
+        ops.lstm_seq_fwd(gx, kh, act, cseq, hseq, hprev, b, T, H, ws=ws)
+        torch.cuda.synchronize()
+    finally:
+        ops.lstm_seq_test_hooks()
+    ops.lstm_seq_bwd(dout, kh, act, cseq, dz, b, T, H, ws=ws)        # healthy launch: must not erase the forward's flag
+    assert ops.lstm_seq_timed_out(ws)
+    assert not ops.lstm_seq_timed_out(ws)                            # the read reset it
+    ops.lstm_seq_fwd(gx, kh, act, cseq, hseq, hprev, b, T, H, ws=ws)
+    ops.lstm_seq_bwd(dout, kh, act, cseq, dz, b, T, H, ws=ws)
+    assert not ops.lstm_seq_timed_out(ws)
+    try:
+        ops.lstm_seq_test_hooks(spin_limit=64, mute_workgroup=3)
+        ops.lstm_seq_bwd(dout, kh, act, cseq, dz, b, T, H, ws=ws)
+        torch.cuda.synchronize()
+    finally:
+        ops.lstm_seq_test_hooks()
+    with pytest.raises(Exception, match="timed out"):
+        ops.lstm_seq_check(ws)
 
 
 @pytest.mark.parametrize("method", ["avg", "last"])

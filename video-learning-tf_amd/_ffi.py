@@ -64,6 +64,7 @@ SIGNATURES = {
     "vl_lstm_seq_fwd": (i32, [p, p, p, p, p, p, p, p, i32, i32, i32, f32, p, sz, p]),
     "vl_lstm_seq_bwd": (i32, [p, p, p, p, p, p, p, p, i32, i32, i32, p, sz, p]),
     "vl_lstm_seq_status": (i32, [p, C.POINTER(i32)]),
+    "vl_lstm_seq_test_hooks": (i32, [C.c_uint, i32]),
     "vl_transpose": (i32, [p, i64, p, i32, i32, p]),
     "vl_temporal_fusion_fwd": (i32, [p, p, i32, i32, i32, i32, p]),
     "vl_temporal_fusion_bwd": (i32, [p, p, i32, i32, i32, i32, p]),

@@ -199,8 +199,13 @@ class ComposedEngine:
         torch.cuda.synchronize(self.dev)
         return {n: self.G[n].detach().cpu().numpy().copy() for n, _ in self.specs}
 
+    def check_status(self):
+        """LRCNEngine.check_status over both pipelines' LSTM workspaces."""
+        ops.lstm_seq_check(self.lstm_ws, getattr(self.enc, "lstm_ws", None))
+
     def logits_host(self):
         torch.cuda.synchronize(self.dev)
+        self.check_status()
         return self.logits[:self._rows].detach().cpu().numpy().copy()
 
     # checkpoints (feeder.py): same reserved keys as LRCNEngine
@@ -372,9 +377,10 @@ class ComposedEngine:
         ops.fill(self.stats, 0.0)
         ops.softmax_xent(self.logits[:rows], onehot, self.dlogits, self.stats, 1.0 / (global_rows or rows * world), self.loss_rows)
         self._head_backward(b1)
-        if self.dp is not None and self.grad_chunks:
-            self.dp.reduce_async(self.g, *self.grad_chunks[0])
-        self.enc.dp = _OffsetReduce(self.dp, self.g, self.enc.g) if self.dp is not None else None
+        # the decoder's chunk is issued by _OffsetReduce together with the encoder's first one, i.e. AFTER the encoder's LSTM
+        # backward: the cluster-form recurrence needs every CU and must not spin under an RCCL kernel that holds some
+        self.enc.dp = _OffsetReduce(self.dp, self.g, self.enc.g, first=self.grad_chunks[0] if self.specs2 else None) \
+            if self.dp is not None else None
         self.enc._backward(n, b1)
         self.enc.dp = None
         return self._finish_step(rows, lr, clip_norm, fetch)
@@ -402,6 +408,7 @@ class ComposedEngine:
         if not fetch:
             return None
         torch.cuda.synchronize(self.dev)
+        self.check_status()
         st = self.stats.cpu().numpy()
         return {"loss": float(st[0]) / max(rows, 1), "accuracy": float(st[1]) / max(rows, 1),
                 "grad_norm": math.sqrt(float(self.ss.item())), "rows": rows, "loss_sum": float(st[0]), "correct": float(st[1])}
@@ -410,11 +417,15 @@ class ComposedEngine:
 class _OffsetReduce:
     """Lets pipeline 1's backward issue its gradient chunks on the shared flat buffer (its own `g` is a slice of it)."""
 
-    def __init__(self, dp, whole, part):
+    def __init__(self, dp, whole, part, first=None):
         self.dp, self.world = dp, dp.world
         self.whole, self.base = whole, (part.data_ptr() - whole.data_ptr()) // 4
+        self.first = first                      # (offset, count) of a chunk of `whole` to send ahead of the first chunk of `part`
 
     def reduce_async(self, flat, offset, count):
+        if self.first is not None:
+            self.dp.reduce_async(self.whole, *self.first)
+            self.first = None
         self.dp.reduce_async(self.whole, self.base + offset, count)
 
     def wait(self):

@@ -21,7 +21,9 @@
 // by relaxed agent-scope atomic loads (bypass L1) until the tag matches; no flag, no fence, placement independent.
 // Epochs count steps within the call (1..T, never 0); buffers alternate by epoch parity (a workgroup can be at most one step
 // ahead of another, see below); the launcher zeroes the granules before every call.  Spins are bounded: a workgroup that never
-// sees its granules sets the status word and goes on (wrong results, no hang) -- vl_lstm_seq_status reports it.
+// sees its granules sets the status word and goes on (wrong results, no hang).  The status word is STICKY: no launch clears it,
+// vl_lstm_seq_status reads AND resets it, so a forward call's time-out is still there after the backward call and the engine's
+// one check per step (engine._finish_step) sees every launch of that step.
 //
 //   why two buffers suffice: a workgroup publishes epoch e+1 only after it has gathered ALL of epoch e, which includes the
 //   slowest workgroup's epoch-e values; the slowest one publishes those only after it finished reading epoch e-1.  So while
@@ -44,6 +46,10 @@ static constexpr int CPG = 8;        // clips per group (at most)
 static constexpr int LNT = 256;      // threads per workgroup
 static constexpr int LH_MAX = 512;   // largest hidden size of this form (LDS: H x 64 floats + 8 x H floats)
 static constexpr unsigned SPIN_LIMIT = 1u << 18;   // polls before giving up (~tens of ms; a healthy hop takes microseconds)
+// test hooks (vl_lstm_seq_test_hooks): a shorter spin limit, and one workgroup index whose granules are never published, so that
+// tests/ can see the time-out path end to end; defaults = production behaviour
+static unsigned g_spin_limit = SPIN_LIMIT;
+static int g_mute_workgroup = -1;
 static constexpr size_t STATUS_BYTES = 256;        // status block at the start of the workspace (word 0: timed-out flag)
 
 template <int I> struct IntK { static constexpr int value = I; };
@@ -59,7 +65,8 @@ __device__ __forceinline__ void store_granule(u64* g, unsigned epoch, float v) {
 // (per-slot branches made hipcc wait for every load separately: n dependent L2 round trips per pass).
 // Returns false (and raises the status word) when the bounded spin runs out.
 template <int MAXN, class IDX>
-__device__ __forceinline__ bool gather_granules(const u64* g, int n, IDX idx, unsigned epoch, float (&v)[MAXN], unsigned* status) {
+__device__ __forceinline__ bool gather_granules(const u64* g, int n, IDX idx, unsigned epoch, float (&v)[MAXN], unsigned* status,
+                                                unsigned spin_limit) {
     if (n <= 0) return true;
     const gu64* a[MAXN];
 #pragma unroll
@@ -75,7 +82,7 @@ __device__ __forceinline__ bool gather_granules(const u64* g, int n, IDX idx, un
             ok &= (unsigned)(x[m] >> 32) == epoch;
         }
         if (ok) return true;
-        if (spins >= SPIN_LIMIT) {
+        if (spins >= spin_limit) {
             __hip_atomic_store((gu32*)status, 1u, RLX_AGENT);
             return false;
         }
@@ -100,6 +107,8 @@ struct LstmClusterArgs {
     unsigned* status;
     int B, T, H, Hp, G, W, cpg;
     float forget_bias;
+    unsigned spin_limit;
+    int mute;             // test hook: this workgroup (blockIdx.x) publishes nothing; -1 = none
 };
 
 // ---- forward ------------------------------------------------------------------------------------------------------------
@@ -154,7 +163,7 @@ __global__ __launch_bounds__(LNT) void lstm_cluster_fwd_kernel(const LstmCluster
                 constexpr int N = decltype(tag)::value;
                 float v[N];
                 gather_granules<N>(src, myn, [&](int m) { const int i = tid + LNT * m; const int c = i / H; return c * Hp + (i - c * H); },
-                                   (unsigned)t, v, p.status);
+                                   (unsigned)t, v, p.status, p.spin_limit);
 #pragma unroll
                 for (int m = 0; m < N; ++m)
                     if (m < myn) {
@@ -197,7 +206,7 @@ __global__ __launch_bounds__(LNT) void lstm_cluster_fwd_kernel(const LstmCluster
             const float gi = sigm(zi), gj = tanhf(zj), gf = sigm(zf + p.forget_bias), go = sigm(zo);
             cst = cst * gf + gi * gj;
             const float h = tanhf(cst) * go;
-            if (t + 1 < T) store_granule(xg + (t & 1) * xpar + gc * Hp + gu, (unsigned)(t + 1), h);
+            if (t + 1 < T && (int)blockIdx.x != p.mute) store_granule(xg + (t & 1) * xpar + gc * Hp + gu, (unsigned)(t + 1), h);
             float* a = p.act + r * H4 + gu;
             a[0] = gi; a[H] = gj; a[2 * H] = gf; a[3 * H] = go;
             p.cseq[r * H + gu] = cst;
@@ -256,7 +265,7 @@ __global__ __launch_bounds__(LNT) void lstm_cluster_bwd_kernel(const LstmCluster
         auto run = [&](auto tag) {
             constexpr int N = decltype(tag)::value;
             float v[N];
-            gather_granules<N>(src, glive ? W : 0, [&](int m) { return (size_t)m * wstride; }, epoch, v, p.status);
+            gather_granules<N>(src, glive ? W : 0, [&](int m) { return (size_t)m * wstride; }, epoch, v, p.status, p.spin_limit);
             float s = 0.f;
 #pragma unroll
             for (int m = 0; m < N; ++m)
@@ -295,7 +304,7 @@ __global__ __launch_bounds__(LNT) void lstm_cluster_bwd_kernel(const LstmCluster
             zz[0] = zi; zz[LU] = zj; zz[2 * LU] = zf; zz[3 * LU] = zo;
         }
         __syncthreads();                                        // own dz_t in LDS
-        if (t > 0 || p.dh0) {
+        if ((t > 0 || p.dh0) && (int)blockIdx.x != p.mute) {
             u64* dst = pg + (epoch & 1) * ppar + (size_t)w * CPG * Hp;
             if (nclips > 4) publish_partials<8>(KsT, zl, dst, H, Hp, nclips, epoch, tid);
             else if (nclips > 2) publish_partials<4>(KsT, zl, dst, H, Hp, nclips, epoch, tid);
@@ -364,7 +373,8 @@ int vl_lstm_cluster_run(bool bwd, LstmClusterArgs a, int batch, void* ws, size_t
         VL_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         attr_set[bwd] = true;
     }
-    VL_HIP(hipMemsetAsync(ws, 0, STATUS_BYTES, s));
+    a.spin_limit = g_spin_limit;
+    a.mute = g_mute_workgroup;
     const float *gx = a.gx, *h0 = a.h0, *c0 = a.c0, *dout = a.dout;
     float *act = a.act, *cseq = a.cseq, *hseq = a.hseq, *hprev = a.hprev, *dz = a.dz, *dh0 = a.dh0, *dc0 = a.dc0;
     for (int b0 = 0; b0 < batch; b0 += c.chunk) {
@@ -419,7 +429,6 @@ extern "C" int vl_lstm_seq_fwd(const float* gx, const float* kh, const float* h0
         a.T = T; a.H = H; a.forget_bias = forget_bias;
         return vl_lstm_cluster_run(false, a, batch, ws, ws_bytes, (hipStream_t)stream);
     }
-    VL_HIP(hipMemsetAsync(ws, 0, STATUS_BYTES, (hipStream_t)stream));
     return vl_lstm_perclip_fwd(gx, kh, h0, c0, act, cseq, hseq, hprev, batch, T, H, forget_bias, (hipStream_t)stream);
 }
 
@@ -434,16 +443,22 @@ extern "C" int vl_lstm_seq_bwd(const float* dout, const float* kh, const float* 
         a.dh0 = dh0; a.dc0 = dc0; a.T = T; a.H = H;
         return vl_lstm_cluster_run(true, a, batch, ws, ws_bytes, (hipStream_t)stream);
     }
-    VL_HIP(hipMemsetAsync(ws, 0, STATUS_BYTES, (hipStream_t)stream));
     float* kh_t = (float*)((char*)ws + STATUS_BYTES);
     if (vl_transpose(kh, (int64_t)4 * H, kh_t, H, 4 * H, stream)) return 1;
     return vl_lstm_perclip_bwd(dout, kh_t, act, cseq, c0, dz, dh0, dc0, batch, T, H, (hipStream_t)stream);
 }
 
-extern "C" int vl_lstm_seq_status(const void* ws, int* timed_out) {
+extern "C" int vl_lstm_seq_status(void* ws, int* timed_out) {
     VL_CHECK(ws && timed_out, "vl_lstm_seq_status: null argument");
     unsigned v = 0;
-    VL_HIP(hipMemcpy(&v, ws, sizeof(v), hipMemcpyDeviceToHost));
+    VL_HIP(hipMemcpy(&v, ws, sizeof(v), hipMemcpyDeviceToHost));       // synchronises with the launches that may have raised it
+    if (v) VL_HIP(hipMemset(ws, 0, sizeof(v)));
     *timed_out = (int)v;
+    return 0;
+}
+
+extern "C" int vl_lstm_seq_test_hooks(unsigned spin_limit, int mute_workgroup) {
+    g_spin_limit = spin_limit ? spin_limit : SPIN_LIMIT;
+    g_mute_workgroup = mute_workgroup;
     return 0;
 }

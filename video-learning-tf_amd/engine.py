@@ -176,7 +176,11 @@ class LRCNEngine:
             if bi == len(self.fc6_row_blocks) - 1:
                 hi = first_conv                                   # fc6b rides with the last block
             self.grad_chunks.append((lo, hi - lo))
-        self.grad_chunks.append((first_conv, total - first_conv))   # conv5..conv1, at the end of backward
+        # conv5..conv3 (8.0 of the 9.3 MB of conv gradients) go out as soon as conv3's weight gradient is queued, while conv2 / conv1
+        # backward (40 % of the conv backward) still runs; only conv2 + conv1 (1.4 MB) are left for the end of the step
+        conv_lo = self.offsets["dcnn/conv2W"][0]
+        self.grad_chunks.append((first_conv, conv_lo - first_conv))
+        self.grad_chunks.append((conv_lo, total - conv_lo))
         assert sum(c for _, c in self.grad_chunks) == total and all(
             self.grad_chunks[i][0] + self.grad_chunks[i][1] == self.grad_chunks[i + 1][0] for i in range(len(self.grad_chunks) - 1))
         if cfg.optimizer == "adam" and training:
@@ -425,8 +429,15 @@ class LRCNEngine:
                 t.copy_(torch.from_numpy(np.ascontiguousarray(a)))
         return missing
 
+    def check_status(self):
+        """Raises when a cluster-form LSTM launch since the last check timed out (ops.lstm_seq_check: the flag is sticky over the
+        launches of a step and reset here).  Synchronises; called wherever results are fetched to the host."""
+        if getattr(self, "lstm_ws", None) is not None:
+            ops.lstm_seq_check(self.lstm_ws)
+
     def logits_host(self, rows=None):
         torch.cuda.synchronize(self.dev)
+        self.check_status()
         return self.logits[:rows if rows is not None else self._rows].detach().cpu().numpy().copy()
 
     # ---- input ---------------------------------------------------------------------------------
@@ -666,12 +677,16 @@ class LRCNEngine:
             b_ = self.k_d6[:n * FC_DIM].view(ops.kc8_shape(n, FC_DIM))
             ops.pack_kc8(L5["p"], a, n, F, F, 1)                              # (position frame, channel f)
             ops.pack_kc8(d, b_, n, FC_DIM, FC_DIM, 1)
-            ops.gemm_kc8(a, b_, G["dcnn/fc6W"], F, FC_DIM, n, ws=self.ws)
-            if self.dp is not None:
+            if self.dp is None:
+                ops.gemm_kc8(a, b_, G["dcnn/fc6W"], F, FC_DIM, n, ws=self.ws)
+            else:
+                # the exchange starts here, as on the fp32 path: a row block of fc6W = a range of the packed operand's 8-row
+                # blocks (block edges are multiples of 128), each block's all-reduce issued right behind its product
                 chunks = iter(self.grad_chunks)
                 if self.offsets["dcnn/fc6W"][0] > 0:
                     self.dp.reduce_async(self.g, *next(chunks))
-                for _ in self.fc6_row_blocks:
+                for r0, r1 in self.fc6_row_blocks:
+                    ops.gemm_kc8(a[r0 // 8:r1 // 8], b_, G["dcnn/fc6W"][r0:r1], r1 - r0, FC_DIM, n, ws=self.ws)
                     self.dp.reduce_async(self.g, *next(chunks))
         elif self.dp is None:
             ops.gemm(L5["p"], d, G["dcnn/fc6W"], self.flat_dim, FC_DIM, n, transa=True, ws=self.ws)
@@ -724,6 +739,8 @@ class LRCNEngine:
                     ops.pack_c8(dy, L["dyb"][:n], L["dy_halo"], L["dy_halo"])
                 self._run(name + ".wgrad", conv.c8_wgrad, L["xb"][:n], L["dyb"][:n], G["dcnn/%sW" % name], self.ws)
                 ops.bias_grad_c8(L["dyb"][:n], G["dcnn/%sb" % name], sw, conv.cout, L["dy_halo"])
+                if self.dp is not None and name == "conv3":
+                    self.dp.reduce_async(self.g, *self.grad_chunks[-2])
                 prev = self.layers[li - 1]
                 conv.c8_pack_w(P["dcnn/%sW" % name], L["wbt"], True)
                 if prev["pool"]:
@@ -743,6 +760,9 @@ class LRCNEngine:
                 else:
                     self._run(name + ".wgrad", conv.wgrad, x_in, dy, G["dcnn/%sW" % name], self.ws)
                     ops.bias_grad_nchw(dy, G["dcnn/%sb" % name], sw)
+                if self.dp is not None and name == "conv3":
+                    # issued from the stream the weight gradients ran on: RCCL's stream waits for that stream only
+                    self.dp.reduce_async(self.g, *self.grad_chunks[-2])
             if li > 0:
                 prev = self.layers[li - 1]
                 conv.wt_transpose(P["dcnn/%sW" % name], self.wt)
@@ -811,6 +831,7 @@ class LRCNEngine:
         if not fetch:
             return None
         torch.cuda.synchronize(self.dev)
+        self.check_status()
         st = self.stats.cpu().numpy()
         return {"loss": float(st[0]) / max(rows, 1), "accuracy": float(st[1]) / max(rows, 1), "grad_norm": math.sqrt(float(self.ss.item())),
                 "rows": rows, "loss_sum": float(st[0]), "correct": float(st[1])}

@@ -477,10 +477,25 @@ def lstm_seq_bwd(dout, kh, act, cseq, dz, batch, T, H, ws=None, c0=None, dh0=Non
 
 
 def lstm_seq_timed_out(ws):
-    """True if a workgroup of the last cluster-form launch on `ws` gave up waiting for its peers (synchronises)."""
+    """True if a workgroup of any cluster-form launch on `ws` since the last call gave up waiting for its peers; the flag is
+    sticky across launches and reset by this read (synchronises)."""
     v = C.c_int(0)
     _ffi.call("vl_lstm_seq_status", _p(ws), C.byref(v))
     return bool(v.value)
+
+
+def lstm_seq_check(*workspaces):
+    """Raises VltfError when a cluster-form LSTM launch on one of the workspaces timed out (results of that step are invalid)."""
+    bad = [i for i, ws in enumerate(workspaces) if ws is not None and lstm_seq_timed_out(ws)]
+    if bad:
+        raise _ffi.VltfError("LSTM cluster kernel timed out waiting for its peer workgroups (workspace %s): the recurrence needs "
+                             "every workgroup resident at once and another kernel was holding compute units; this step's results "
+                             "are invalid" % bad)
+
+
+def lstm_seq_test_hooks(spin_limit=0, mute_workgroup=-1):
+    """Test hooks (vl_lstm_seq_test_hooks): shorter spin limit / one workgroup that never publishes.  Defaults restore production."""
+    _ffi.call("vl_lstm_seq_test_hooks", int(spin_limit), int(mute_workgroup))
 
 
 def transpose(src, dst, rows, cols, ld=None):

@@ -202,7 +202,7 @@ def do_test(settings, val, feeder, engine, rank=0, world=1):
             fr, vec = (fdict, other) if "frames_u8" in fdict else (other, fdict)
             logits = engine.forward(torch.from_numpy(fr["frames_u8"]).to(dev), torch.from_numpy(vec["vectors"]).to(dev), fr["mean_bgr"],
                                     torch.from_numpy(fr["crop_y"]).to(dev), torch.from_numpy(fr["crop_x"]).to(dev),
-                                    torch.from_numpy(fr["mirror"]).to(dev)).cpu().numpy()
+                                    torch.from_numpy(fr["mirror"]).to(dev), resize=fr.get("resize")).cpu().numpy()
             if engine.per_step:                          # one logits row per record of the vectors dataset: its own targets
                 fdict = dict(fdict, labels=(fdict if "record_labels" in fdict else other)["record_labels"])
         elif "device" in fdict:          # read and uploaded ahead by the feeder's BatchPrefetcher
@@ -214,6 +214,8 @@ def do_test(settings, val, feeder, engine, rank=0, world=1):
             logits = engine.forward_u8(torch.from_numpy(fdict["frames_u8"]).to(dev), fdict["mean_bgr"],
                                        torch.from_numpy(fdict["crop_y"]).to(dev), torch.from_numpy(fdict["crop_x"]).to(dev),
                                        torch.from_numpy(fdict["mirror"]).to(dev), resize=fdict.get("resize")).cpu().numpy()
+        if num_labels:
+            engine.check_status()                        # a timed-out LSTM cluster launch invalidates these logits: fail, do not save
         labels = fdict["labels"].astype(np.float32)
         if world > 1:
             parts = [None] * world
