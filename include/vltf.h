@@ -284,8 +284,14 @@ int vl_resize_u8(const vl_resize_desc* d, const uint8_t* src, uint8_t* tmp, uint
 int vl_copy2d(const float* src, int64_t src_ld, float* dst, int64_t dst_ld, int rows, int cols, vl_stream_t stream);
 /* op 0: a + b; 1: mean of the two (tf.reduce_mean, fusion avg, tf_util.py:142-143); 2: max (fusion maximum, :144-145). */
 int vl_eltwise2(const float* a, const float* b, float* out, int64_t count, int op, vl_stream_t stream);
-/* gradient of max(a, b) w.r.t. both (the larger input takes d; a on ties). */
+/* gradient of max(a, b) w.r.t. both: the larger input takes d, equal inputs share it evenly (tf.reduce_max's _MinOrMaxGrad). */
 int vl_max2_grad(const float* a, const float* b, const float* d, float* da, float* db, int64_t count, vl_stream_t stream);
+/* apply_tensor_list_fusion avg | maximum over a LIST of n <= 8 equally shaped tensors (tf.reduce_mean / tf.reduce_max over the
+ * stacked list, tf_util.py:142-145).  ins / dins: HOST arrays of n device pointers.  op 0: mean, 1: maximum.
+ * vl_fuse_n_grad writes dins[i] (null entries are skipped): d / n for the mean; for the maximum the inputs equal to it share d
+ * evenly (ins may be null for op 0). */
+int vl_fuse_n(const float* const* ins, int n, float* out, int64_t count, int op, vl_stream_t stream);
+int vl_fuse_n_grad(const float* const* ins, int n, const float* d, float* const* dins, int64_t count, int op, vl_stream_t stream);
 
 /* ---- tf.nn.dropout (lstm.py:50-56): y = x * mask / keep, mask ~ Bernoulli(keep) ------------------
  * Counter-based RNG keyed by (seed, element index); mask (uint8) is written for the backward. */

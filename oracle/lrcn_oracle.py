@@ -280,15 +280,31 @@ def init_params(rng, num_classes=101, final_layer="fc6", lstm_hidden=256, lstm_l
     return p
 
 
-def alexnet_forward(p, x, final_layer="fc6", dtype=F64, keep=False):
+def bf16_round(a):
+    """Round to the nearest bfloat16 (ties to even), returned in a's float type: the operand rounding of the bf16 conv path."""
+    b = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    b = ((b + 0x7FFF + ((b >> 16) & 1)) >> 16 << 16).astype(np.uint32)
+    return b.view(np.float32).astype(np.asarray(a).dtype if np.asarray(a).dtype.kind == "f" else np.float32)
+
+
+def alexnet_forward(p, x, final_layer="fc6", dtype=F64, keep=False, q=None):
     """dcnn.create (alexnet.py:49-275).  x: [N,H,W,3] float (BGR, mean-subtracted), NHWC.
-    Returns (output, cache).  final_layer: 'fc6' | 'fc7' | anything else -> fc8 logits."""
+    Returns (output, cache).  final_layer: 'fc6' | 'fc7' | anything else -> fc8 logits.
+
+    q (optional, tests only): operand quantiser of the engine's opt-in bf16 conv path (NetConfig.conv_math = "bf16", BASELINE
+    config 5; not a reference feature): q = bf16_round reproduces where that path stores a tensor as packed bf16 -- the input
+    frames, the weights of every conv and of fc6, the outputs of conv1..conv4 (conv1 / conv2: also what LRN reads), the pooled
+    outputs of pool1 / pool2, pool5's output as fc6's operand -- so that device and oracle differ by fp32 rounding only."""
     cache = {"x": x} if keep else {}
     a = x.astype(dtype, copy=False)
+    qq = (lambda v: v) if q is None else (lambda v: q(v).astype(dtype))
+    a = qq(a)
     for name, kh, kw, co, s, g in ALEXNET_CONVS:
-        z = grouped_conv(a, p["dcnn/%sW" % name], p["dcnn/%sb" % name], s, g, dtype)
+        z = grouped_conv(a, qq(p["dcnn/%sW" % name]), p["dcnn/%sb" % name], s, g, dtype)
         a_in = a
         a = relu(z)
+        if name != "conv5":
+            a = qq(a)
         if keep:
             cache[name + "_in"] = a_in
             cache[name] = a
@@ -301,13 +317,15 @@ def alexnet_forward(p, x, final_layer="fc6", dtype=F64, keep=False):
         if name in ("conv1", "conv2", "conv5"):
             pin = a
             a, arg = max_pool_valid(a)
+            if name != "conv5":
+                a = qq(a)
             if keep:
                 cache["pool" + name[-1] + "_in_shape"] = pin.shape
                 cache["pool" + name[-1] + "_arg"] = arg
                 cache["pool" + name[-1]] = a
     n = a.shape[0]
-    flat = a.reshape(n, -1)                    # (h, w, c)-major flatten (alexnet.py:228)
-    fc6 = relu(xw_plus_b(flat, p["dcnn/fc6W"], p["dcnn/fc6b"], dtype))
+    flat = qq(a.reshape(n, -1))                # (h, w, c)-major flatten (alexnet.py:228)
+    fc6 = relu(xw_plus_b(flat, qq(p["dcnn/fc6W"]), p["dcnn/fc6b"], dtype))
     if keep:
         cache["flat"], cache["fc6"] = flat, fc6
     if final_layer == "fc6":
@@ -321,7 +339,7 @@ def alexnet_forward(p, x, final_layer="fc6", dtype=F64, keep=False):
     return fc8, cache
 
 
-def alexnet_backward(p, cache, dout, final_layer="fc6", dtype=F64, gates=None):
+def alexnet_backward(p, cache, dout, final_layer="fc6", dtype=F64, gates=None, q=None):
     """Gradients of alexnet_forward wrt every parameter; dout is d(loss)/d(output).
 
     gates (optional, tests only): the DISCRETE decisions of the forward pass taken from another evaluation of the same network
@@ -330,6 +348,7 @@ def alexnet_backward(p, cache, dout, final_layer="fc6", dtype=F64, gates=None):
     evaluation may take a near-tie the other way than this fp64 one, which moves gradient elements by O(1) without either being
     wrong.  With the other evaluation's decisions substituted, the remaining difference is rounding only."""
     gates = gates or {}
+    qq = (lambda v: v) if q is None else (lambda v: q(v).astype(dtype))     # see alexnet_forward: the bf16 path's stored operands
 
     def rgrad(name, dd):
         return dd * gates[name] if name in gates else relu_grad(cache[name], dd)
@@ -346,17 +365,17 @@ def alexnet_backward(p, cache, dout, final_layer="fc6", dtype=F64, gates=None):
         g["dcnn/fc7b"] = d.sum(0)
         d = d @ p["dcnn/fc7W"].astype(dtype).T
     d = rgrad("fc6", d)
-    g["dcnn/fc6W"] = cache["flat"].T @ d
+    g["dcnn/fc6W"] = cache["flat"].T @ qq(d)
     g["dcnn/fc6b"] = d.sum(0)
-    d = (d @ p["dcnn/fc6W"].astype(dtype).T).reshape(cache["pool5"].shape)
+    d = (qq(d) @ qq(p["dcnn/fc6W"].astype(dtype)).T).reshape(cache["pool5"].shape)
     for name, kh, kw, co, s, grp in reversed(ALEXNET_CONVS):
         i = name[-1]
         if name in ("conv1", "conv2", "conv5"):
             d = max_pool_valid_grad(cache["pool%s_in_shape" % i], gates.get("pool%s_arg" % i, cache["pool%s_arg" % i]), d)
         if name in ("conv1", "conv2"):
             d = lrn_grad(cache["lrn%s_in" % i], d, dtype=dtype)
-        d = rgrad(name, d)
-        dx, dw, db = grouped_conv_grad(cache[name + "_in"], p["dcnn/%sW" % name], d, s, grp, dtype,
+        d = qq(rgrad(name, d))                 # the bf16 path reads this gradient packed: wgrad, dgrad AND the bias gradient
+        dx, dw, db = grouped_conv_grad(cache[name + "_in"], qq(p["dcnn/%sW" % name]), d, s, grp, dtype,
                                        need_dx=(name != "conv1"))
         g["dcnn/%sW" % name] = dw
         g["dcnn/%sb" % name] = db
@@ -370,10 +389,12 @@ def alexnet_backward(p, cache, dout, final_layer="fc6", dtype=F64, gates=None):
 FORGET_BIAS = 1.0   # tf.contrib.rnn.BasicLSTMCell default, not overridden at lstm.py:17
 
 
-def lstm_layer_forward(x, kernel, bias, h0=None, c0=None, dtype=F64):
+def lstm_layer_forward(x, kernel, bias, h0=None, c0=None, dtype=F64, q=None):
     """One BasicLSTMCell unrolled by dynamic_rnn over x [B,T,D] (all rows full length, lstm.py:136).
     gates = concat([x_t, h]) @ kernel + bias; split i, j, f, o;
-    c' = c*sigmoid(f + 1.0) + sigmoid(i)*tanh(j); h' = tanh(c')*sigmoid(o)."""
+    c' = c*sigmoid(f + 1.0) + sigmoid(i)*tanh(j); h' = tanh(c')*sigmoid(o).
+    q (tests only, see alexnet_forward): the engine's bf16 mode rounds both operands of the hoisted input projection x @ kernel[:D];
+    the recurrent product h @ kernel[D:] stays fp32."""
     x = x.astype(dtype, copy=False)
     kernel = kernel.astype(dtype, copy=False)
     bias = bias.astype(dtype, copy=False)
@@ -382,6 +403,9 @@ def lstm_layer_forward(x, kernel, bias, h0=None, c0=None, dtype=F64):
     h = np.zeros((b, hdim), dtype) if h0 is None else h0.astype(dtype)
     c = np.zeros((b, hdim), dtype) if c0 is None else c0.astype(dtype)
     hs, cs, gates = [], [], []
+    if q is not None:
+        x = q(x).astype(dtype)
+        kernel = np.concatenate([q(kernel[:d]).astype(dtype), kernel[d:]], axis=0)
     for s in range(t):
         z = np.concatenate([x[:, s, :], h], axis=1) @ kernel + bias
         i, j, f, o = np.split(z, 4, axis=1)
@@ -397,11 +421,15 @@ def lstm_layer_forward(x, kernel, bias, h0=None, c0=None, dtype=F64):
     return out, (c, h), {"x": x, "gates": gates, "cs": cs}
 
 
-def lstm_layer_backward(kernel, cache, dout, dh_last=None, dc_last=None, dtype=F64):
-    """BPTT through lstm_layer_forward.  dout [B,T,H] = d/d(outputs)."""
+def lstm_layer_backward(kernel, cache, dout, dh_last=None, dc_last=None, dtype=F64, q=None):
+    """BPTT through lstm_layer_forward.  dout [B,T,H] = d/d(outputs).
+    q (tests only): bf16 operands of the three whole-sequence products x^T dz, h_prev^T dz, dz kernel[:D]^T (the engine's bf16 mode);
+    the recurrent dz kernel[D:]^T stays fp32."""
     kernel = kernel.astype(dtype, copy=False)
     x = cache["x"]
     b, t, d = x.shape
+    qq = (lambda v: v) if q is None else (lambda v: q(v).astype(dtype))
+    kq = np.concatenate([qq(kernel[:d]), kernel[d:]], axis=0) if q is not None else kernel
     hdim = kernel.shape[1] // 4
     dk = np.zeros_like(kernel)
     db = np.zeros(4 * hdim, dtype)
@@ -420,12 +448,11 @@ def lstm_layer_backward(kernel, cache, dout, dh_last=None, dc_last=None, dtype=F
         df = dc * c_prev
         dc = dc * gf
         dz = np.concatenate([di * gi * (1 - gi), dj * (1 - gj * gj), df * gf * (1 - gf), do * go * (1 - go)], axis=1)
-        xin = np.concatenate([x[:, s, :], h_prev], axis=1)
-        dk += xin.T @ dz
+        xin = np.concatenate([x[:, s, :], qq(h_prev)], axis=1)          # cache["x"] is already the rounded operand
+        dk += xin.T @ qq(dz)
         db += dz.sum(0)
-        dxin = dz @ kernel.T
-        dx[:, s, :] = dxin[:, :d]
-        dh = dxin[:, d:]
+        dx[:, s, :] = qq(dz) @ kq[:d].T
+        dh = dz @ kq[d:].T
     return dx, dk, db, dh, dc
 
 
@@ -511,12 +538,12 @@ def labels_to_one_hot(labels, num_classes):
 # LRCN pipeline -- models/model.py:18-155 (dcnn representation -> lstm | fc classifier)
 # ----------------------------------------------------------------------------------------------
 def lrcn_forward(p, frames, fpc, final_layer="fc6", lstm_layers=1, fusion="avg", classifier="lstm",
-                 frame_fusion=None, dtype=F64, keep=False, chunk=32):
-    """frames [B*T,H,W,3] NHWC float, fpc = T.  Returns (logits [B,C], cache)."""
+                 frame_fusion=None, dtype=F64, keep=False, chunk=32, q=None):
+    """frames [B*T,H,W,3] NHWC float, fpc = T.  Returns (logits [B,C], cache).  q: see alexnet_forward (tests only)."""
     n = frames.shape[0]
     feats, caches = [], []
     for s in range(0, n, chunk):
-        f, c = alexnet_forward(p, frames[s:s + chunk], final_layer, dtype, keep)
+        f, c = alexnet_forward(p, frames[s:s + chunk], final_layer, dtype, keep, q)
         feats.append(f)
         caches.append(c)
     feat = np.concatenate(feats, axis=0)
@@ -527,7 +554,7 @@ def lrcn_forward(p, frames, fpc, final_layer="fc6", lstm_layers=1, fusion="avg",
         lcaches = []
         for l in range(lstm_layers):
             x, _, lc = lstm_layer_forward(x, p["rnn/multi_rnn_cell/cell_%d/basic_lstm_cell/kernel" % l],
-                                          p["rnn/multi_rnn_cell/cell_%d/basic_lstm_cell/bias" % l], dtype=dtype)
+                                          p["rnn/multi_rnn_cell/cell_%d/basic_lstm_cell/bias" % l], dtype=dtype, q=q)
             lcaches.append(lc)
         # fusion `state`: lstm_state[-1].h (model.py:137-138) = the last layer's output at t = T-1 (dynamic_rnn with full
         # sequence lengths, lstm.py:136), no dropout, then convert_dim_fc("fc_convert") (model.py:140-141)
@@ -551,7 +578,7 @@ def lrcn_forward(p, frames, fpc, final_layer="fc6", lstm_layers=1, fusion="avg",
 
 
 def lrcn_backward(p, cache, dlogits, fpc, final_layer="fc6", lstm_layers=1, fusion="avg", dtype=F64, classifier="lstm",
-                  frame_fusion=None, gates=None):
+                  frame_fusion=None, gates=None, q=None):
     """Gradients of lrcn_forward wrt every parameter (classifier lstm, or fc with early / late frame fusion).
     gates: see alexnet_backward; arrays cover ALL frames and are sliced per chunk here."""
     g = {}
@@ -565,7 +592,7 @@ def lrcn_backward(p, cache, dlogits, fpc, final_layer="fc6", lstm_layers=1, fusi
         d = temporal_fusion_grad(cache["seq_shape"], "last" if fusion == "state" else fusion, d)
         for l in reversed(range(lstm_layers)):
             kname = "rnn/multi_rnn_cell/cell_%d/basic_lstm_cell/kernel" % l
-            d, dk, db, _, _ = lstm_layer_backward(p[kname], cache["lstm"][l], d, dtype=dtype)
+            d, dk, db, _, _ = lstm_layer_backward(p[kname], cache["lstm"][l], d, dtype=dtype, q=q)
             g[kname] = dk
             g[kname[:-6] + "bias"] = db
     else:   # classifier fc (model.py:115-119), late fusion after it (149-151), early fusion before it (103-106)
@@ -581,7 +608,7 @@ def lrcn_backward(p, cache, dlogits, fpc, final_layer="fc6", lstm_layers=1, fusi
     chunk = cache["chunk"]
     for ci, cc in enumerate(cache["cnn"]):
         gsl = {k: v[ci * chunk:(ci + 1) * chunk] for k, v in gates.items()} if gates else None
-        gc = alexnet_backward(p, cc, dfeat[ci * chunk:(ci + 1) * chunk], final_layer, dtype, gsl)
+        gc = alexnet_backward(p, cc, dfeat[ci * chunk:(ci + 1) * chunk], final_layer, dtype, gsl, q)
         for k, v in gc.items():
             g[k] = g[k] + v if k in g else v
     return g
@@ -976,8 +1003,17 @@ def model_forward(p, pipelines, datasets, feeds, num_classes, dtype=F64, chunk=3
     second dcnn gets TF's automatic "dcnn_1/" name scope and a second LSTM / fc_convert cannot be created at all).
     -> (logits, cache)."""
     scoped = len(pipelines) > 1
-    outs, shapes, cache = {}, {}, {"order": [n for n, _ in pipelines], "pipes": {}, "sources": {}}
+    # sess.run(logits) evaluates only what the last pipeline depends on; the others exist as variables and are never run
+    by_name, needed, stack = dict(pipelines), set(), [pipelines[-1][0]]
+    while stack:
+        n = stack.pop()
+        if n not in needed:
+            needed.add(n)
+            stack += [i for i in by_name[n]["input"] if i in by_name]
+    outs, shapes, cache = {}, {}, {"order": [n for n, _ in pipelines if n in needed], "pipes": {}, "sources": {}}
     for name, spec in pipelines:
+        if name not in needed:
+            continue
         ins = []
         for src in spec["input"]:
             if src in outs:

@@ -26,12 +26,12 @@ def build(shape, V, enc_h, enc_layers, dec_h, dec_layers, fusion, E, Tf, Tw, b, 
     eng = ComposedEngine(enc_cfg, head, max_clips=b, device=DEV)
     pe = O.init_params(rng, V, layer, enc_h, enc_layers, shape, well_scaled=True, fusion="state")
     p = {"enc/" + k: v for k, v in pe.items()}
-    e_seq = fc_out if representation == "fc" else E
-    seq_dim = e_seq + V if input_fusion == "concat" else e_seq
+    fused = E + V if input_fusion == "concat" else E            # the input fusion comes first (model.py:69-73) ...
+    seq_dim = fc_out if representation == "fc" else fused         # ... then the representation (model.py:81-96)
     p.update(O.init_lstm_classifier_params(rng, "dec/", seq_dim, dec_h, dec_layers, fusion, V,
                                            state_dim=V if input_fusion is None else None, well_scaled=True))
     if representation == "fc":
-        p["dec/fc_convert_w"] = O.truncated_normal(rng, (E, fc_out), np.sqrt(2.0 / E))
+        p["dec/fc_convert_w"] = O.truncated_normal(rng, (fused, fc_out), np.sqrt(2.0 / fused))
         p["dec/fc_convert_b"] = np.full(fc_out, 0.1, np.float32)
     eng.load_params(p)
     frames = rng.integers(0, 256, (b * Tf,) + shape, dtype=np.uint8)
@@ -100,37 +100,22 @@ def test_config4_full_geometry():
 def test_input_fusion_replication_and_fc_representation(input_fusion, representation, ratio):
     """apply_tensor_list_fusion concat (the vec_seq_concat branch: clips-per-video ratio > 1) / ibias of a word sequence with the
     per-video vector of pipeline 1, replicate_auxilliary_tensor at ratio > 1 (also on the state path, model.py:131-134), and
-    representation fc (convert_dim_fc) in front of the sequence."""
-    shape, V, E, Tf, Tw, b1, H = (67, 67, 3), 7, 5, 2, 4, 2, 8
-    fc_out = V if representation == "fc" else None            # ibias needs equal widths (the vector becomes one more time step)
+    representation fc (convert_dim_fc) -- applied AFTER the input fusion, as build_pipeline orders them (model.py:69-96): under
+    ibias the word vectors must therefore be as wide as pipeline 1's output, and the fc maps the T + 1 fused steps."""
+    shape, V, Tf, Tw, b1, H = (67, 67, 3), 7, 2, 4, 2, 8
+    E = V if input_fusion == "ibias" else 5                   # ibias: the vector becomes one more time step of the same width
+    fc_out = 6 if representation == "fc" else None
     eng, p, frames, words, rng = build(shape, V, 6, 1, H, 1, "reshape", E, Tf, Tw, b1, seed=5, input_fusion=input_fusion,
                                        representation=representation, fc_out=fc_out, ratio=ratio)
-    b = b1 * ratio
+    pipes = [("enc", dict(input=["main"], representation="dcnn", frame_encoding_layer="fc6", classifier="lstm", lstm_params=[6, 1, "state"])),
+             ("dec", dict(input=["aux", "enc"], input_fusion=input_fusion, representation=representation, fc_output_dim=fc_out,
+                          classifier="lstm", lstm_params=[H, 1, "reshape"]))]
+    ds = {"main": dict(cpv=1, fpc=Tf), "aux": dict(cpv=ratio, fpc=Tw)}
     x = frames.astype(np.float32) - MEAN
-    pe = {k[4:]: v for k, v in p.items() if k.startswith("enc/")}
-    enc_out, ec = O.lrcn_forward(pe, x, Tf, "fc6", 1, "state", "lstm", None, keep=True)
-    seq = words.astype(np.float64)
-    if representation == "fc":
-        seq = O.xw_plus_b(seq, p["dec/fc_convert_w"], p["dec/fc_convert_b"])
-    e_seq = seq.shape[1]
-    state, fcache, Ts = None, None, Tw
-    if input_fusion:
-        seq, _, Ts, _, fcache = O.tensor_list_fusion([seq, enc_out], input_fusion, [e_seq, V], [Tw, 1], [ratio, 1])
-    else:
-        state = O.replicate_auxilliary_tensor(enc_out, ratio)                                # model.py:131-134
-    logits, dc = O.lstm_classifier_forward(p, "dec/", seq, Ts, 1, "reshape", V, state=state)
-    onehot = O.labels_to_one_hot([[l] for l in rng.integers(0, V, b * Ts)], V)
+    logits, cache = O.model_forward(p, pipes, ds, {"main": x, "aux": words}, V)
+    onehot = O.labels_to_one_hot([[l] for l in rng.integers(0, V, logits.shape[0])], V)
     loss, dlogits = O.softmax_xent_mean(logits, onehot)
-    g, dseq, dstate = O.lstm_classifier_backward(p, dc, dlogits)
-    if input_fusion:
-        dseq, denc = O.tensor_list_fusion_grad(fcache, dseq)
-    else:
-        denc = O.replicate_auxilliary_tensor_grad(dstate, ratio, b1)
-    if representation == "fc":
-        g["dec/fc_convert_w"] = words.astype(np.float64).T @ dseq
-        g["dec/fc_convert_b"] = dseq.sum(0)
-    ge = O.lrcn_backward(pe, ec, denc, Tf, "fc6", 1, "state")
-    g.update({"enc/" + k: v for k, v in ge.items()})
+    g = O.model_backward(p, cache, dlogits)
     fd, wd, od = torch.tensor(frames, device=DEV), torch.tensor(words, device=DEV), torch.tensor(onehot, device=DEV)
     np.testing.assert_allclose(eng.forward(fd, wd, MEAN).cpu().numpy(), logits, rtol=1e-3, atol=1e-3)
     out = eng.train_step(fd, wd, od, lr=0.0, clip_norm=0.0, mean_bgr=MEAN)

@@ -1,0 +1,117 @@
+"""HOST LOGIC of vltf_amd.graph.GraphEngine -- the general pipeline graph of models/model.py:18-162 -- in the build container:
+the engine's own Python runs unchanged, the C-ABI kernels and the AlexNet tower are replaced by the torch-CPU stand-ins of
+tests/cpu_double.py (test infrastructure), and every logit and gradient must equal the CPU oracle's
+(oracle.lrcn_oracle.model_forward / model_backward).  What this pins: stage order, buffer routing, gradient accumulation over
+fan-out, variable naming / the flat buffer, pruning of unused pipelines, the refusals.  The kernels are the GPU tests' business."""
+import numpy as np
+import pytest
+import torch
+
+from tests import graph_cases as GC
+from tests.cpu_double import install
+
+torch.set_num_threads(4)
+
+
+def run_case(monkeypatch, name, dp=None):
+    Engine = install(monkeypatch)
+    case = GC.CASES[name]()
+    pipes, ds = GC.specs_and_datasets(case)
+    eng = Engine(pipes, ds, case["V"], device="cpu", dp=dp)
+    p = eng.init_params(seed=case["seed"], well_scaled=True)
+    eng.load_params(p)
+    raw, feeds = GC.inputs(case)
+    logits, onehot, loss, grads, _ = GC.expect(case, p, feeds)
+    dev_feeds = {t: (dict(frames_u8=torch.from_numpy(v), mean_bgr=GC.MEAN) if v.dtype == np.uint8 else torch.from_numpy(v)) for t, v in raw.items()}
+    got = eng.forward(dev_feeds).numpy().copy()
+    assert got.shape == logits.shape
+    np.testing.assert_allclose(got, logits, rtol=1e-4, atol=1e-4)
+    out = eng.train_step(dev_feeds, torch.from_numpy(onehot), lr=0.01, clip_norm=0.5)
+    assert abs(out["loss"] - loss) < 1e-4 * max(1, abs(loss))
+    clipped, gn = O_clip(grads)
+    assert abs(out["grad_norm"] - gn) < 1e-3 * gn
+    g = eng.get_grads()
+    assert set(g) == set(p)
+    for k in p:
+        scale = np.abs(grads[k]).max() + 1e-12
+        np.testing.assert_allclose(g[k], grads[k], rtol=2e-3, atol=2e-4 * scale, err_msg="grad " + k)
+    newp = eng.get_params()
+    for k in p:
+        np.testing.assert_allclose(newp[k], p[k].astype(np.float64) - 0.01 * clipped[k], rtol=1e-4, atol=1e-5, err_msg="param " + k)
+    return eng, case, p, grads
+
+
+def O_clip(grads):
+    from oracle import lrcn_oracle as O
+    return O.clip_by_global_norm(grads, 0.5)
+
+
+@pytest.mark.parametrize("name", sorted(GC.CASES))
+def test_graph_matches_oracle_on_the_cpu_double(monkeypatch, name):
+    eng, case, p, grads = run_case(monkeypatch, name)
+    if name.startswith("two_stream"):
+        assert np.abs(grads["rgb/dcnn/conv1W"]).max() > 0 and np.abs(grads["flow/dcnn/conv1W"]).max() > 0
+    if name == "fanout":
+        assert eng.skipped == ["unused"] and not any(k.startswith("unused/") for k in p)
+        assert np.abs(grads["feat/dcnn/fc7W"]).max() > 0
+    if name.startswith("fused_frames"):
+        assert "dcnn/conv1W" in p               # a single pipeline keeps the unscoped TF names
+
+
+class _CountingDp:
+    """Records the order of the gradient chunks a step hands to the exchange (no communication: world of one)."""
+    world = 1
+
+    def __init__(self):
+        self.calls = []
+
+    def reduce_async(self, flat, off, cnt):
+        self.calls.append((off, cnt))
+
+    def wait(self):
+        pass
+
+
+def test_exchange_chunks_cover_the_buffer_and_wait_for_the_last_lstm(monkeypatch):
+    """Data-parallel plumbing: every element of the flat gradient goes out exactly once, in the order backward completes it, and
+    nothing is issued before the LAST LSTM backward of the step has been launched (the cluster-form recurrence must not spin under
+    an RCCL kernel: the decoder's chunk is held until the encoder's LSTM has run)."""
+    dp = _CountingDp()
+    eng, case, p, _ = run_case(monkeypatch, "encdec_state", dp=dp)
+    calls = dp.calls
+    assert sorted(calls) == sorted(eng.grad_chunks)
+    covered = sorted(calls)
+    assert covered[0][0] == 0 and all(covered[i][0] + covered[i][1] == covered[i + 1][0] for i in range(len(covered) - 1))
+    assert covered[-1][0] + covered[-1][1] == eng.w.numel()
+    assert calls[0] == eng.grad_chunks[0]                    # the decoder's head first -- but only once the encoder's LSTM is through:
+    order = []
+    orig = eng.by_name["enc"]._lstm_backward
+    eng.by_name["enc"]._lstm_backward = lambda d: (order.append("enc_lstm"), orig(d))[1]
+    dp.reduce_async = lambda flat, off, cnt: order.append("reduce")
+    raw, _ = GC.inputs(case)
+    feeds = {t: (dict(frames_u8=torch.from_numpy(v), mean_bgr=GC.MEAN) if v.dtype == np.uint8 else torch.from_numpy(v)) for t, v in raw.items()}
+    rows = eng.forward(feeds).shape[0]
+    eng.train_step(feeds, torch.zeros((rows, case["V"]), dtype=torch.int32), lr=0.0)
+    assert order[0] == "enc_lstm" and order.count("reduce") == len(eng.grad_chunks)
+
+
+@pytest.mark.parametrize("pipes,msg", [
+    ([("a", dict(input=["main"], representation="dcnn", frame_encoding_layer="fc6", classifier=None, frame_fusion=("late", "avg")))], "late fusion with no classifier"),
+    ([("a", dict(input=["main"], representation="dcnn", frame_encoding_layer="fc6", classifier=None))], "classifier is missing"),
+    ([("a", dict(input=["aux"], representation="dcnn", frame_encoding_layer="fc6", classifier="fc"))], "rank"),
+    ([("a", dict(input=["nope"], representation="nop", classifier="fc"))], "Could not find a dataset"),
+    ([("a", dict(input=["aux"], representation="fc", fc_output_dim=9, classifier="fc"))], "already exists"),
+    ([("a", dict(input=["aux"], representation="nop", classifier="lstm", lstm_params=(4, 1, "avg"), frame_fusion=("early", "avg")))], "only with"),
+    ([("a", dict(input=["aux", "main"], representation="nop", classifier="fc"))], "neither an input_fusion"),
+    ([("f", dict(input=["main"], representation="dcnn", frame_encoding_layer="fc6", classifier=None)),
+      ("a", dict(input=["aux", "f"], input_fusion="concat", representation="nop", classifier="fc"))], "ratio"),
+    ([("f", dict(input=["main"], representation="dcnn", frame_encoding_layer="fc6", classifier="fc", frame_fusion=("early", "avg"))),
+      ("a", dict(input=["aux", "f"], input_fusion="ibias", representation="nop", classifier="lstm", lstm_params=(4, 1, "avg")))], "equal widths"),
+])
+def test_refusals_follow_the_reference(monkeypatch, pipes, msg):
+    from vltf_amd._ffi import VltfError
+    Engine = install(monkeypatch)
+    case = dict(pipes=pipes, data={"main": dict(mode="video", fpc=3, cpv=1), "aux": dict(mode="vectors", fpc=4, cpv=1, dim=6)}, V=7, items=2)
+    specs, ds = GC.specs_and_datasets(case)
+    with pytest.raises(VltfError, match=msg):
+        Engine(specs, ds, 7, device="cpu")

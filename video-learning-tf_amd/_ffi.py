@@ -82,6 +82,8 @@ SIGNATURES = {
     "vl_copy2d": (i32, [p, i64, p, i64, i32, i32, p]),
     "vl_eltwise2": (i32, [p, p, p, i64, i32, p]),
     "vl_max2_grad": (i32, [p, p, p, p, p, i64, p]),
+    "vl_fuse_n": (i32, [p, i32, p, i64, i32, p]),
+    "vl_fuse_n_grad": (i32, [p, i32, p, p, i64, i32, p]),
     "vl_relu_grad": (i32, [p, p, i64, p]),
 }
 

@@ -1672,20 +1672,81 @@ extern "C" int vl_eltwise2(const float* a, const float* b, float* out, int64_t c
     return 0;
 }
 
-// gradient of max(a, b): the first maximum takes it (np.argmax / tf.reduce_max's gradient splits ties evenly in TF; ties have
-// measure zero for float activations and the oracle routes them to the first input, as here)
+// gradient of max(a, b) as tf.reduce_max registers it (_MinOrMaxGrad): the inputs equal to the maximum share the gradient evenly
+// (two ReLU outputs that are both 0 tie all the time)
 __global__ void max2_grad_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ d,
                                  float* __restrict__ da, float* __restrict__ db, int64_t count) {
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (int64_t)gridDim.x * blockDim.x) {
-        const bool first = a[e] >= b[e];
-        da[e] = first ? d[e] : 0.f;
-        db[e] = first ? 0.f : d[e];
+        const float x = a[e], y = b[e], g = d[e];
+        da[e] = x > y ? g : (x == y ? 0.5f * g : 0.f);
+        db[e] = y > x ? g : (x == y ? 0.5f * g : 0.f);
     }
 }
 
 extern "C" int vl_max2_grad(const float* a, const float* b, const float* d, float* da, float* db, int64_t count, vl_stream_t stream) {
     VL_CHECK(a && b && d && da && db && count > 0, "vl_max2_grad: bad argument");
     hipLaunchKernelGGL(max2_grad_kernel, dim3(grid_for(count, 256, 4096)), dim3(256), 0, (hipStream_t)stream, a, b, d, da, db, count);
+    VL_LAUNCH_CHECK();
+    return 0;
+}
+
+// apply_tensor_list_fusion avg | maximum over a LIST of equally shaped tensors (tf.reduce_mean / tf.reduce_max over axis 0 of the
+// stacked list, tf_util.py:142-145) and its gradient.  The pointer lists are host arrays, passed to the kernel by value.
+static constexpr int FUSE_MAX = 8;
+struct FuseList { const float* in[FUSE_MAX]; float* din[FUSE_MAX]; int n; };
+
+__global__ void fuse_n_kernel(const FuseList l, float* __restrict__ out, int64_t count, int op) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (int64_t)gridDim.x * blockDim.x) {
+        float acc = l.in[0][e];
+        for (int i = 1; i < l.n; ++i) acc = op == 0 ? acc + l.in[i][e] : fmaxf(acc, l.in[i][e]);
+        out[e] = op == 0 ? acc / (float)l.n : acc;
+    }
+}
+
+// avg: every input gets d / n; maximum: the inputs equal to the maximum share d evenly (tf _MinOrMaxGrad); din[i] == null is skipped
+__global__ void fuse_n_grad_kernel(const FuseList l, const float* __restrict__ d, int64_t count, int op) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (int64_t)gridDim.x * blockDim.x) {
+        const float g = d[e];
+        if (op == 0) {
+            for (int i = 0; i < l.n; ++i)
+                if (l.din[i]) l.din[i][e] = g / (float)l.n;
+        } else {
+            float m = l.in[0][e];
+            for (int i = 1; i < l.n; ++i) m = fmaxf(m, l.in[i][e]);
+            int hits = 0;
+            for (int i = 0; i < l.n; ++i) hits += l.in[i][e] == m;
+            for (int i = 0; i < l.n; ++i)
+                if (l.din[i]) l.din[i][e] = l.in[i][e] == m ? g / (float)hits : 0.f;
+        }
+    }
+}
+
+extern "C" int vl_fuse_n(const float* const* ins, int n, float* out, int64_t count, int op, vl_stream_t stream) {
+    VL_CHECK(ins && out && n >= 1 && n <= FUSE_MAX && count > 0 && (op == 0 || op == 1), "vl_fuse_n: bad argument (1..8 inputs, op 0 avg | 1 maximum)");
+    FuseList l = {};
+    l.n = n;
+    for (int i = 0; i < n; ++i) {
+        VL_CHECK(ins[i], "vl_fuse_n: null input");
+        l.in[i] = ins[i];
+    }
+    hipLaunchKernelGGL(fuse_n_kernel, dim3(grid_for(count, 256, 4096)), dim3(256), 0, (hipStream_t)stream, l, out, count, op);
+    VL_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vl_fuse_n_grad(const float* const* ins, int n, const float* d, float* const* dins, int64_t count, int op, vl_stream_t stream) {
+    VL_CHECK(d && dins && n >= 1 && n <= FUSE_MAX && count > 0 && (op == 0 || op == 1), "vl_fuse_n_grad: bad argument");
+    VL_CHECK(op == 0 || ins, "vl_fuse_n_grad: the maximum needs the inputs");
+    FuseList l = {};
+    l.n = n;
+    for (int i = 0; i < n; ++i) {
+        if (op == 1) {
+            VL_CHECK(ins[i], "vl_fuse_n_grad: null input");
+            l.in[i] = ins[i];
+        }
+        l.din[i] = dins[i];
+    }
+    hipLaunchKernelGGL(fuse_n_grad_kernel, dim3(grid_for(count, 256, 4096)), dim3(256), 0, (hipStream_t)stream, l, d, count, op);
     VL_LAUNCH_CHECK();
     return 0;
 }

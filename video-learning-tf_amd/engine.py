@@ -45,7 +45,7 @@ class NetConfig:
     num_classes: int = 101
     fpc: int = 16                               # frames per clip (from the .size file, dataset_.py:728)
     frame_encoding_layer: str = "fc6"           # alexnet.py:233-275: "fc6" | "fc7" | anything else -> fc8
-    classifier: str = "lstm"                    # defs.classifier.{lstm, fc}
+    classifier: str = "lstm"                    # defs.classifier.{lstm, fc}; "none": a feature pipeline (classifier: None, model.py:110-112)
     lstm_hidden: int = 256
     lstm_layers: int = 1
     fusion: str = "avg"                         # lstm_params[2]: defs.fusion_method.{avg, last, reshape, state}
@@ -56,6 +56,10 @@ class NetConfig:
 
     def encode_dim(self):
         return FC_DIM if self.frame_encoding_layer in ("fc6", "fc7") else self.num_classes
+
+    def out_dim(self):
+        """Width of the pipeline's output rows: num_classes after a classifier, the encode width of a feature pipeline."""
+        return self.encode_dim() if self.classifier == "none" else self.num_classes
 
 
 def tf_same_out(n, s):
@@ -86,6 +90,8 @@ def param_specs(cfg: NetConfig):
     elif cfg.classifier == "fc":
         if dim != cfg.num_classes:
             specs += [("fc_convert_w", (dim, cfg.num_classes)), ("fc_convert_b", (cfg.num_classes,))]
+    elif cfg.classifier == "none":
+        pass
     else:
         raise VltfError("Undefined classifier [%s]" % cfg.classifier)
     if cfg.frame_encoding_layer not in ("fc6", "fc7"):
@@ -327,6 +333,8 @@ class LRCNEngine:
                 self.dfused, self.ddropped = buf(R, H), buf(R, H)
         else:
             ff = cfg.frame_fusion
+            if cfg.classifier == "none" and ff and ff[0] == "late":
+                raise VltfError("Specified late fusion with no classifier selected")       # model.py:36-37
             if ff and ff[0] in ("early", "late") and ff[1] not in ("avg", "last", "reshape"):
                 raise VltfError("Undefined frame fusion type : %s" % ff[1])              # apply_temporal_fusion, tf_util.py:28-29
             if ff and ff[1] == "reshape":
@@ -334,6 +342,7 @@ class LRCNEngine:
             self.early = bool(ff and ff[0] == "early" and T > 1)
             self.late = bool(ff and ff[0] == "late" and T > 1)
             self.ff_method = ff[1] if ff else None
+            C = cfg.out_dim()                  # a feature pipeline (classifier none) ends at the encode width: no fc, D == C below
             rows = B if self.early else N
             self.fc_in = buf(B, D) if self.early else self.feat
             self.fc_out = buf(rows, C) if D != C else self.fc_in
@@ -565,6 +574,7 @@ class LRCNEngine:
                 self.logits[:r].copy_(v[:r])
             self._rows = r
         else:
+            C = cfg.out_dim()
             v, rows = self.feat, n
             if self.early:
                 ops.temporal_fusion_fwd(self.feat, self.fc_in, b, T, D, self.ff_method)
@@ -633,18 +643,21 @@ class LRCNEngine:
                 else:
                     ops.gemm(S["dz"], K, self.lstm[l - 1]["dout"], n, H, 4 * H, transb=True, ldb=4 * H, ws=self.ws)
         else:
+            Co = cfg.out_dim()                # width of the pipeline output (= D for a feature pipeline)
             d, rows = self.dlogits, self._rows
             if self.late:
-                ops.temporal_fusion_bwd(self.dlogits, self.dfc_out, b, T, C, self.ff_method)
+                ops.temporal_fusion_bwd(self.dlogits, self.dfc_out, b, T, Co, self.ff_method)
                 d, rows = self.dfc_out, b * T
             relu_mask = self.feat if (self.f8 is None and not self.early) else None
             target = self.dfc_in if self.early else self.dfeat
-            if D != C:
-                ops.gemm(self.fc_in, d, G["fc_convert_w"], D, C, rows, transa=True)
-                ops.colsum(d, G["fc_convert_b"], sw, rows, C)
-                ops.gemm(d, P["fc_convert_w"], target, rows, D, C, transb=True, relu_mask=relu_mask)
+            if D != Co:
+                ops.gemm(self.fc_in, d, G["fc_convert_w"], D, Co, rows, transa=True)
+                ops.colsum(d, G["fc_convert_b"], sw, rows, Co)
+                ops.gemm(d, P["fc_convert_w"], target, rows, D, Co, transb=True, relu_mask=relu_mask)
             else:
                 target[:rows].copy_(d[:rows])
+                if relu_mask is not None:        # no fc in between (a feature pipeline): the encode layer's ReluGrad applies here
+                    ops.relu_grad(target, relu_mask, rows * D)
             if self.early:
                 # ReluGrad of the encode layer applies per frame after un-fusing
                 ops.temporal_fusion_bwd(self.dfc_in, self.dfeat, b, T, D, self.ff_method)
@@ -797,6 +810,8 @@ class LRCNEngine:
     def _train(self, n, b, onehot, lr, clip_norm, fetch, global_rows=None):
         if not self.training:
             raise VltfError("engine was built with training=False")
+        if self.cfg.classifier == "none":
+            raise VltfError("a feature pipeline (classifier none) has no loss of its own: it trains inside a GraphEngine")
         if onehot.dtype != torch.int32 or tuple(onehot.shape) != (self._rows_for(b, n), self.cfg.num_classes):
             raise VltfError("labels must be int32 one-hot of shape (%d, %d)" % (self._rows_for(b, n), self.cfg.num_classes))
         rows = self._forward(n, b, train=True)

@@ -604,6 +604,33 @@ def max2_grad(a, b, d, da, db, count=None):
     _ffi.call("vl_max2_grad", _p(a), _p(b), _p(d), _p(da), _p(db), a.numel() if count is None else int(count), stream())
 
 
+FUSE_OP = {"avg": 0, "maximum": 1}
+
+
+def _ptr_list(ts):
+    arr = (C.c_void_p * len(ts))()
+    for i, t in enumerate(ts):
+        arr[i] = None if t is None else t.data_ptr()
+    return arr
+
+
+def fuse_n(ins, out, method, count=None):
+    """out = mean | maximum over the list `ins` of equally shaped tensors (apply_tensor_list_fusion avg | maximum, tf_util.py:142-145)."""
+    _f32(out, *ins)
+    if not 1 <= len(ins) <= 8:
+        raise _ffi.VltfError("fuse_n: 1..8 inputs, got %d" % len(ins))
+    _ffi.call("vl_fuse_n", _ptr_list(ins), len(ins), _p(out), ins[0].numel() if count is None else int(count), FUSE_OP[method], stream())
+
+
+def fuse_n_grad(ins, d, dins, method, count=None):
+    """dins[i] (None = not wanted) = gradient of fuse_n w.r.t. input i: d / n, or d shared evenly among the inputs equal to the maximum."""
+    _f32(d, *[t for t in list(ins) + list(dins) if t is not None])
+    if len(ins) != len(dins) or not 1 <= len(ins) <= 8:
+        raise _ffi.VltfError("fuse_n_grad: 1..8 inputs and as many gradient slots")
+    _ffi.call("vl_fuse_n_grad", _ptr_list(ins), len(ins), _p(d), _ptr_list(dins), d.numel() if count is None else int(count),
+              FUSE_OP[method], stream())
+
+
 # ---- imresize (dataset_.py:481-495) ---------------------------------------------------------------------------------------------
 class Resize:
     """scipy.misc.imresize(image, (oh, ow, 3)) = PIL bilinear on uint8 [n, h, w, 3] device images (vl_resize_*), bit-exact."""
