@@ -4,6 +4,7 @@
 #   bench   bench.py default N=1                                -> gpurun_out/<tag>/bench_n1.json
 #   c8      bench.py --clips-per-gpu 8 (one rank's shard of the 8-GPU strong-scaling job) + rocprofv3 kernel trace of it
 #   fpc32   bench.py --fpc 32 (config 5's clip length)
+#   bf16probe  tools/bf16_grad_probe.py --gpu: the bf16 path's gradients against the rounding-aware oracle
 # Steps are joined with &&-semantics (set -e): after a failed or killed GPU step nothing else starts.
 set -eo pipefail
 tag="${1:-r02}"; shift || true
@@ -41,6 +42,9 @@ PY
       timeout -k 10 400 python bench.py --fpc 32 --no-split-math --no-cpu-baseline --steps 5 --warmup 2 > "$out/bench_fpc32.json" 2> "$out/bench_fpc32.err" \
           || { tail -20 "$out/bench_fpc32.err"; exit 1; }
       tail -c 300 "$out/bench_fpc32.json"; echo ;;
+    bf16probe)
+      timeout -k 10 900 python tools/bf16_grad_probe.py --clips 8 --gpu > "$out/bf16_probe_ref.txt" 2> "$out/bf16_probe_ref.err" || { tail -20 "$out/bf16_probe_ref.err"; exit 1; }
+      tail -25 "$out/bf16_probe_ref.txt" ;;
     *) echo "unknown step $s"; exit 2 ;;
   esac
   echo "== step $s done"

@@ -26,6 +26,20 @@ def print_iter_info(settings, feeder, num_images, num_labels, padding):
          (settings.phase, epoch_str, feeder.get_batch_index(), len(dataset.batches), str(num_images), num_labels))
 
 
+def graph_feeds(fdicts, tags, dev):
+    """{tag: feed dict of Feeder.get_feed_dict} -> GraphEngine feeds: frames with their imgproc arguments, or the vectors tensor."""
+    feeds = {}
+    for tag in tags:
+        fd = fdicts[tag]
+        if "vectors" in fd:
+            feeds[tag] = torch.from_numpy(fd["vectors"]).to(dev)
+        else:
+            feeds[tag] = dict(frames_u8=torch.from_numpy(fd["frames_u8"]).to(dev, non_blocking=True), mean_bgr=fd["mean_bgr"],
+                              crop_y=torch.from_numpy(fd["crop_y"]).to(dev), crop_x=torch.from_numpy(fd["crop_x"]).to(dev),
+                              mirror=torch.from_numpy(fd["mirror"]).to(dev), resize=fd.get("resize"))
+    return feeds
+
+
 def pipeline_net_config(settings, p, dataset):
     """NetConfig of one dcnn pipeline over `dataset` (model.py:81-151)."""
     kw = dict(image_shape=tuple(dataset.get_image_shape()), num_classes=settings.num_classes, fpc=dataset.num_frames_per_clip,
@@ -49,38 +63,35 @@ def net_config(settings, dataset):
     return pipeline_net_config(settings, p, dataset), p
 
 
-def composed_config(settings, feeder):
-    """Two chained pipelines (model.py:157-162): <dcnn pipeline over a frame dataset> feeding <nop | fc pipeline with an LSTM
-    classifier over a vectors dataset> as its state vector or through input_fusion -- BASELINE config 4 (vltf_amd.composed).
-    -> (enc NetConfig, HeadConfig, frame dataset, vector dataset, (name1, name2))"""
-    from .composed import HeadConfig
-    n1, n2 = settings.pipeline_names
-    p1, p2 = settings.pipelines[n1], settings.pipelines[n2]
-    if p1.representation != defs.representation.dcnn or len(p1.input) != 1 or p1.input[0] in settings.pipelines:
-        error("Pipeline [%s] must be a dcnn pipeline over one dataset." % n1)
-    if len(p2.input) != 2 or p2.input[1] != n1 or p2.input[0] in settings.pipelines:
-        error("Pipeline [%s] must take [<vectors dataset>, %s] as input." % (n2, n1))
-    if p2.representation not in (defs.representation.nop, defs.representation.fc) or p2.classifier != defs.classifier.lstm:
-        error("Pipeline [%s] must be a nop | fc representation with an lstm classifier." % n2)
-    if p2.frame_fusion and p2.frame_fusion[0] != defs.fusion_type.none:
-        error("The LSTM classifier should be used only with [none] fusion, but it's [%s]" % p2.frame_fusion[0])
-    d1, d2 = feeder.get_dataset_by_tag(p1.input[0]), feeder.get_dataset_by_tag(p2.input[0])
-    if len(d1) != 1 or len(d2) != 1:
-        error("Could not find exactly one dataset for each of the tags %s, %s" % (p1.input[0], p2.input[0]))
-    d1, d2 = d1[0], d2[0]
-    if d2.input_mode != defs.input_mode.vectors or d1.input_mode != defs.input_mode.video:
-        error("Pipeline [%s] needs a video dataset and pipeline [%s] a vectors dataset." % (n1, n2))
-    cpv1, cpv2 = d1.clips_per_video, d2.clips_per_video
-    if not all(c == cpv1[0] for c in cpv1) or not all(c == cpv2[0] for c in cpv2):
-        warning("Non equal clips per item")                        # model.py:57-58
-    ratio = int(cpv2[0] / cpv1[0])
-    if ratio < 1 or any(c2 != ratio * c1 for c1, c2 in zip(cpv1, cpv2)) or d1.num_items != d2.num_items:
-        error("The datasets of the two pipelines do not pair up item by item (clips per item %s vs %s)." % (cpv1[:3], cpv2[:3]))
-    head = HeadConfig(in_dim=d2.vector_dim(), fpc=d2.num_frames_per_clip, num_classes=settings.num_classes,
-                      lstm_hidden=p2.lstm_params[0], lstm_layers=p2.lstm_params[1], fusion=p2.lstm_params[2],
-                      representation=p2.representation, fc_output_dim=getattr(p2, "fc_output_dim", None),
-                      input_fusion=p2.input_fusion, dropout_keep_prob=settings.get_dropout(), cpv_ratio=ratio)
-    return pipeline_net_config(settings, p1, d1), head, d1, d2, (n1, n2)
+def graph_config(settings, feeder, batch):
+    """Any list of pipelines (model.py:18-162) -> ([PipelineSpec], {tag: DatasetInfo}, {tag: Dataset}) for vltf_amd.graph.GraphEngine.
+    batch: videos per batch on this rank; a dataset's clips per batch follow from its clips-per-video list."""
+    from .graph import DatasetInfo, PipelineSpec
+    specs = []
+    for name in settings.pipeline_names:
+        p = settings.pipelines[name]
+        specs.append(PipelineSpec(name=name, input=list(p.input), representation=p.representation,
+                                  frame_encoding_layer=p.frame_encoding_layer, fc_output_dim=getattr(p, "fc_output_dim", None),
+                                  classifier=p.classifier, lstm_params=tuple(p.lstm_params) if p.lstm_params else None,
+                                  frame_fusion=tuple(p.frame_fusion) if p.frame_fusion else None, input_fusion=p.input_fusion))
+    infos, dsets = {}, {}
+    for tag in sorted({i for sp in specs for i in sp.input if i not in settings.pipelines}):
+        found = feeder.get_dataset_by_tag(tag)
+        if len(found) != 1:
+            error("%d datasets satisfy the network input requirement [%s], but exactly one must." % (len(found), tag))
+        d = found[0]
+        cpv = d.clips_per_video
+        if not all(c == cpv[0] for c in cpv):
+            warning("Non equal clips per item")                        # model.py:57-58
+        if d.input_mode == defs.input_mode.vectors:
+            infos[tag] = DatasetInfo("vectors", d.num_frames_per_clip, cpv[0], batch * max(cpv), dim=d.vector_dim())
+        else:
+            infos[tag] = DatasetInfo("video", d.num_frames_per_clip, cpv[0], batch * max(cpv), image_shape=tuple(d.get_image_shape()))
+        dsets[tag] = d
+    n_items = {d.num_items for d in dsets.values()}
+    if len(n_items) > 1:
+        error("The datasets of the pipelines do not pair up item by item (%s items)." % sorted(n_items))
+    return specs, infos, dsets
 
 
 class _ArraysOnlyUnpickler(pickle.Unpickler):
@@ -152,13 +163,16 @@ def do_train(settings, train, feeder, engine):
         while feeder.loop():
             tic = time.perf_counter()
             fdict, num_data, num_labels, padding = feeder.get_feed_dict()
-            other = None
-            if getattr(settings, "other_tag", None):         # two-pipeline model: the second dataset's batch of the same items
-                other, nd2, _, _ = feeder.get_feed_dict(settings.other_tag)
-                num_data = num_data + nd2
+            others = None
+            if getattr(settings, "graph_tags", None) is not None:      # multi-pipeline model: every other dataset's batch of the same items
+                others = {}
+                for tag in settings.graph_tags:
+                    if tag != defs.dataset_tag.main:
+                        others[tag], nd2, _, _ = feeder.get_feed_dict(tag)
+                        num_data = num_data + nd2
             print_iter_info(settings, feeder, num_data, num_labels, padding)
             run_batch_count += 1
-            batch_loss, learning_rate, settings.global_step = train.run_step(fdict, other)
+            batch_loss, learning_rate, settings.global_step = train.run_step(fdict, others)
             if run_batch_count > 1:
                 fed_clips, fed_time = fed_clips + num_labels, fed_time + time.perf_counter() - tic
             if min_train_loss[0] > batch_loss:
@@ -189,22 +203,22 @@ def do_test(settings, val, feeder, engine, rank=0, world=1):
     tic = time.time()
     settings.global_step = 0
     dev = engine.dev
-    composed = getattr(settings, "other_tag", None)
+    graph = getattr(settings, "graph_tags", None) is not None
     while feeder.loop():
         fdict, num_data, num_labels, padding = feeder.get_feed_dict()
-        if composed:
-            other, nd2, _, _ = feeder.get_feed_dict(settings.other_tag)
-            num_data = num_data + nd2
+        fdicts = {defs.dataset_tag.main: fdict}
+        if graph:
+            for tag in settings.graph_tags:
+                if tag != defs.dataset_tag.main:
+                    fdicts[tag], nd2, _, _ = feeder.get_feed_dict(tag)
+                    num_data = num_data + nd2
         print_iter_info(settings, feeder, num_data, num_labels, padding)
         if num_labels == 0:
             logits = np.zeros((0, settings.num_classes), np.float32)
-        elif composed:
-            fr, vec = (fdict, other) if "frames_u8" in fdict else (other, fdict)
-            logits = engine.forward(torch.from_numpy(fr["frames_u8"]).to(dev), torch.from_numpy(vec["vectors"]).to(dev), fr["mean_bgr"],
-                                    torch.from_numpy(fr["crop_y"]).to(dev), torch.from_numpy(fr["crop_x"]).to(dev),
-                                    torch.from_numpy(fr["mirror"]).to(dev), resize=fr.get("resize")).cpu().numpy()
-            if engine.per_step:                          # one logits row per record of the vectors dataset: its own targets
-                fdict = dict(fdict, labels=(fdict if "record_labels" in fdict else other)["record_labels"])
+        elif graph:
+            logits = engine.forward(graph_feeds(fdicts, settings.graph_tags, dev)).cpu().numpy()
+            if engine.per_step and "record_labels" in fdict:      # one logits row per record of the vectors dataset: its own targets
+                fdict = dict(fdict, labels=fdict["record_labels"])
         elif "device" in fdict:          # read and uploaded ahead by the feeder's BatchPrefetcher
             torch.cuda.current_stream(dev).wait_event(fdict["ready"])
             t = fdict["device"]
@@ -222,7 +236,7 @@ def do_test(settings, val, feeder, engine, rank=0, world=1):
             torch.distributed.all_gather_object(parts, (logits, labels))
             logits, labels = np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
         if rank == 0:
-            if composed and engine.per_step:             # per-step logits are their own items (no clip -> video fusion applies)
+            if graph and engine.per_step:                # per-step logits are their own items (no clip -> video fusion applies)
                 val.add_items(logits, labels)
             else:
                 val.process_validation_logits(fdict["dataset"], settings, logits, labels, fdict["batch_index"])
@@ -246,42 +260,50 @@ def main(init_file, seed=0, device=None):
     batch = settings.train.batch_size if settings.train else settings.val.batch_size
     gar = dpmod.GradAllReduce() if world > 1 else None
     dev_name = device or "cuda:%d" % local
-    settings.other_tag = None
-    if len(settings.pipeline_names) == 2:
-        # two chained pipelines (BASELINE config 4): vltf_amd.composed
-        from .composed import ComposedEngine, init_head_params
-        cfg, head, dframes, dvec, names = composed_config(settings, feeder)
-        datasets = [dframes, dvec]
-        main = feeder.get_dataset_by_tag(defs.dataset_tag.main)[0]           # labels come from the main dataset (train.py:117)
-        settings.other_tag = dvec.tag if main is dframes else dframes.tag
-        pipeline = settings.pipelines[names[0]]
-    else:
-        dataset = feeder.get_dataset_by_tag(defs.dataset_tag.main)[0]
-        cfg, pipeline = net_config(settings, dataset)
-        datasets = [dataset]
+    settings.graph_tags = None
+    p0 = settings.pipelines[settings.pipeline_names[0]]
+    single = len(settings.pipeline_names) == 1 and p0.representation == defs.representation.dcnn and p0.input == [defs.dataset_tag.main]
     if world > 1:
-        # data parallel: `batch_size` stays the GLOBAL batch of the config; every rank works on its videos of it
+        batch = -(-batch // world)           # data parallel: `batch_size` stays the GLOBAL batch of the config
+    if single:
+        dataset = feeder.get_dataset_by_tag(defs.dataset_tag.main)[0]
+        cfg, _ = net_config(settings, dataset)
+        datasets = [dataset]
+    else:
+        # any other list of pipelines (model.py:18-162): vltf_amd.graph -- BASELINE config 4's encoder-decoder, two-stream models ...
+        from .graph import GraphEngine
+        specs, infos, by_tag = graph_config(settings, feeder, batch)
+        if defs.dataset_tag.main not in by_tag:
+            error("No pipeline reads the [%s] dataset, whose labels the loss is taken on (train.py:117)." % defs.dataset_tag.main)
+        datasets = list(by_tag.values())
+        settings.graph_tags = sorted(by_tag)
+    if world > 1:
+        # every rank works on its videos of the global batch; rank 0 writes the checkpoints (parameters are identical everywhere)
         for d in datasets:
             d.set_shard(rank, world)
-        batch = -(-batch // world)
         if rank != 0:
-            feeder.save = lambda *a, **k: None              # rank 0 writes the checkpoints (parameters are identical everywhere)
-    max_clips = batch * max(datasets[0].clips_per_video)
-    if len(datasets) == 2:
-        engine = ComposedEngine(cfg, head, max_clips=max_clips, device=dev_name, training=bool(settings.train), dp=gar, scopes=names)
-        params = {names[0] + "/" + k: v for k, v in init_params(cfg, seed=seed).items()}
-        params.update(init_head_params(head, cfg.num_classes, names[1] + "/", seed=seed + 1))
-        scope = names[0] + "/dcnn/"
-    else:
-        engine = LRCNEngine(cfg, max_clips=max_clips, device=dev_name, training=bool(settings.train), dp=gar)
+            feeder.save = lambda *a, **k: None
+    if single:
+        engine = LRCNEngine(cfg, max_clips=batch * max(datasets[0].clips_per_video), device=dev_name, training=bool(settings.train), dp=gar)
         params = init_params(cfg, seed=seed)
-        scope = "dcnn/"
-    if pipeline.weights_file:
-        loaded = {scope[:-len("dcnn/")] + k: v for k, v in load_weights_file(pipeline.weights_file).items()}
-        params.update({k: v for k, v in loaded.items() if k in params and not k.startswith(scope + "fc8")})   # fc8 is re-initialised (alexnet.py:273)
+    else:
+        engine = GraphEngine(specs, infos, settings.num_classes, device=dev_name, training=bool(settings.train), dp=gar,
+                             optimizer=settings.train.optimizer if settings.train else "sgd", dropout_keep_prob=settings.get_dropout(),
+                             conv_math=os.environ.get("VLTF_CONV_MATH", "f32"))
+        for name in engine.skipped:
+            warning("Pipeline [%s] does not feed the output pipeline [%s]: it is never evaluated and is not built." %
+                    (name, settings.pipeline_names[-1]))
+        params = engine.init_params(seed=seed)
+    for name in settings.pipeline_names:
+        pl = settings.pipelines[name]
+        if pl.weights_file and pl.representation == defs.representation.dcnn:
+            scope = "" if single or not engine.scoped else name + "/"
+            loaded = {scope + k: v for k, v in load_weights_file(pl.weights_file).items()}
+            # fc8 is re-initialised (alexnet.py:273)
+            params.update({k: v for k, v in loaded.items() if k in params and not k.startswith(scope + "dcnn/fc8")})
     engine.load_params(params)
     feeder.init_saveload(engine, settings.resume_file)
-    if os.environ.get("VLTF_PREFETCH", "2") != "0" and len(datasets) == 1:      # batches read + uploaded ahead of the loop (0 = the reference's synchronous feed)
+    if os.environ.get("VLTF_PREFETCH", "2") != "0" and single:      # batches read + uploaded ahead of the loop (0 = the reference's synchronous feed)
         feeder.enable_prefetch(engine.dev, depth=int(os.environ.get("VLTF_PREFETCH", "2")))
     if gar is not None:
         gar.broadcast_params(engine.w)

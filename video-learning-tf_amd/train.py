@@ -55,11 +55,11 @@ class Train:
         self.global_step = settings.global_step
         self.clip_norm = float(settings.train.clip_norm or 0)
 
-    def run_step(self, fdict, other=None):
+    def run_step(self, fdict, others=None):
         """-> (loss, current_lr, global_step) like sess.run([.., loss, current_lr, global_step, optimizer]).
-        other: the second dataset's batch of a two-pipeline model (fdict is the MAIN dataset's: the labels are its, train.py:117)."""
-        if other is not None:
-            return self.run_step_composed(fdict, other)
+        others: {tag: batch} of the other datasets of a multi-pipeline model (fdict is the MAIN dataset's: the labels are its, train.py:117)."""
+        if others is not None:
+            return self.run_step_graph(fdict, others)
         if self.global_step >= len(self.learning_rates):
             error("global step %d exceeds the precomputed learning-rate table (%d)" % (self.global_step, len(self.learning_rates)))
         lr = float(self.learning_rates[self.global_step])
@@ -92,25 +92,27 @@ class Train:
         self.last = out
         return out["loss"], lr, self.global_step
 
-    def run_step_composed(self, fdict, other):
-        """Two-pipeline model (vltf_amd.composed): one of the batches holds frames, the other vectors; a per-step model takes the
-        main dataset's per-record targets, any other its per-clip ones."""
+    def run_step_graph(self, fdict, others):
+        """Multi-pipeline model (vltf_amd.graph): one batch per dataset tag; a per-step model (the last pipeline an LSTM with
+        fusion reshape) takes the main dataset's per-record targets, any other its per-clip ones."""
+        from .defs_ import defs
+        from .run_task import graph_feeds
         if self.global_step >= len(self.learning_rates):
             error("global step %d exceeds the precomputed learning-rate table (%d)" % (self.global_step, len(self.learning_rates)))
         lr = float(self.learning_rates[self.global_step])
         eng, dev = self.engine, self.engine.dev
-        fr, vec = (fdict, other) if "frames_u8" in fdict else (other, fdict)
         labels = fdict["record_labels"] if (eng.per_step and "record_labels" in fdict) else fdict["labels"]
         grows = None
-        if eng.dp is not None and fdict.get("global_clips") is not None:
-            grows = fdict["global_clips"] * (eng.Ts if eng.per_step else 1) * (eng.h.cpv_ratio if "frames_u8" in fdict else 1)
+        if eng.dp is not None and fdict.get("global_clips") is not None and len(fdict["labels"]):
+            # rows of the GLOBAL batch: the main dataset's global clips times this model's logits rows per main clip
+            grows = fdict["global_clips"] * len(labels) // len(fdict["labels"])
         if len(labels) == 0:                 # this rank's shard of a short last batch is empty
             out = eng.train_step_empty(lr, self.clip_norm)
         else:
-            out = eng.train_step(torch.from_numpy(fr["frames_u8"]).to(dev, non_blocking=True), torch.from_numpy(vec["vectors"]).to(dev),
-                                 torch.from_numpy(np.ascontiguousarray(labels)).to(dev), lr, self.clip_norm, fr["mean_bgr"],
-                                 torch.from_numpy(fr["crop_y"]).to(dev), torch.from_numpy(fr["crop_x"]).to(dev),
-                                 torch.from_numpy(fr["mirror"]).to(dev), global_rows=grows, resize=fr.get("resize"))
+            fdicts = dict(others)
+            fdicts[defs.dataset_tag.main] = fdict
+            out = eng.train_step(graph_feeds(fdicts, sorted(fdicts), dev), torch.from_numpy(np.ascontiguousarray(labels)).to(dev), lr,
+                                 self.clip_norm, global_rows=grows)
         if eng.dp is not None:
             tot = eng.dp.sum_scalars(torch.tensor([out["loss_sum"], out["correct"], float(out["rows"])], device=dev, dtype=torch.float64))
             tot = tot.cpu().numpy()
