@@ -235,6 +235,7 @@ def main():
         oracle_check = oracle_first_step(eng, frames, onehot, clips, args.fpc, args.classes)
         eng.load_params(init_params(cfg, seed=2))
         eng.step_count = 0
+    eng_chunks = list(eng.grad_chunks)
     elapsed, times, out = timed(eng, frames, onehot, clips, total_clips, probe=True)
     overlapped = clips > 0 and eng._side_stream() is not None      # the backward ran its independent launches on two streams
     # forward only (sess.run(model.logits), run_task.py:95; SURVEY 8d asks for it beside the train step): per rank, untimed for `value`
@@ -349,7 +350,11 @@ def main():
                                "full train step" % (args.fpc, args.classes),
                    "global_batch": total_clips, "clips_per_gpu": clips, "frames_per_clip": args.fpc,
                    "parallelism": "dp%d" % world, "optimizer": "sgd+clip_by_global_norm(10)", "init": "reference (sigma 0.05)",
-                   "dropout_keep_prob": args.dropout},
+                   "dropout_keep_prob": args.dropout,
+                   # what torch.distributed itself reports (so that a multi-GPU record shows the collective saw N ranks over RCCL)
+                   "dist_world_size": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
+                   "dist_backend": torch.distributed.get_backend() if torch.distributed.is_initialized() else None,
+                   "grad_exchange": None if gar is None else {"all_reduces_issued": gar.issued, "chunks_per_step": len(eng_chunks)}},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                      "frac": round(achieved / peak, 4),
                      "traffic": traffic_rec["bytes_per_launch"] if (traffic_rec and n == 1024 and f32_main) else None,

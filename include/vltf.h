@@ -17,7 +17,8 @@
  *   - Activations are NCHW fp32.  Parameters keep the reference's layouts: conv kernels HWIO
  *     [kh][kw][cin/group][cout] (alexnet.py:73,113), fc weights [in][out] (alexnet.py:225),
  *     LSTM kernel [D+H][4H] with gate order i, j, f, o (TF BasicLSTMCell; lstm.py:17).
- *   - Thread-compatible: one stream/descriptor set per host thread.
+ *   - Thread-compatible: one stream/descriptor set per host thread (exceptions, both process-wide words: vl_set_conv_math
+ *     and the test hooks vl_lstm_seq_test_hooks).
  */
 #ifndef VLTF_H
 #define VLTF_H
@@ -86,7 +87,11 @@ int vl_conv_x_phase(const vl_conv_desc* d);
  *      layer, i.e. to fp32 rounding (as close as two fp32 summation orders are to each other); opt-in like mode 3.
  *   1  plain bf16 products (heads only), fp32 accumulation: ~2.3e-3 relative L2 per layer -- the reduced-precision conv path
  *      of BASELINE config 5; outside the fp32 parity tolerances by design (tests hold it to 3e-2 on logits).
- * The environment variable VL_CONV_MATH=bf16x3 | bf16x6 | bf16 presets mode 3 | 6 | 1. */
+ * The environment variable VL_CONV_MATH=bf16x3 | bf16x6 | bf16 presets mode 3 | 6 | 1.
+ * NOT thread-safe: the mode is ONE process-wide word read by every later launch call, the only exception to this header's
+ * "thread-compatible" convention.  A process that mixes arithmetics sets it before each group of launches from the one thread
+ * that issues them (LRCNEngine does, at the top of every forward and backward pass); two host threads launching with
+ * different modes need an external lock around (set, launches). */
 int vl_set_conv_math(int math);
 int vl_conv_math(void);
 /* y[n][cout][oh][ow] = conv(x[n][cin][h][w], w_hwio) + bias, optional fused ReLU (alexnet.py:77). */
@@ -114,6 +119,10 @@ int vl_conv_wgrad(const vl_conv_desc* d, const float* x, const float* dy, float*
  * beyond c).  Kernels fetch 16 bytes per lane straight into LDS and run v_mfma_f32_32x32x16_bf16 with no conversion in the loop.
  * Layers: channels per group a multiple of 8, padded layout (vl_conv_set_halo), not phase split; dgrad / wgrad: stride 1, wgrad
  * additionally x_halo == dy_halo (every SAME layer with an odd kernel).  Halos are those of the descriptor, as for the fp32 calls.
+ * PRECONDITION on every c8 tensor handed to these calls: halo chunks and channels beyond c hold ZEROS.  No kernel here writes them
+ * (only interiors are ever written), so a buffer zeroed once at allocation stays valid; a caller that recycles memory must zero it
+ * first.  vl_conv_c8_wgrad (it sweeps each image's plane linearly, halo columns included: their dy must be 0) and vl_bias_grad_c8
+ * (it sums whole rows) return WRONG dw / db on a dirty halo, without any check; forward / dgrad read halo taps as the padding zeros.
  *   vl_c8_bytes            bytes of a c8 tensor (allocate zeroed once: only interiors are ever written)
  *   vl_pack_c8             fp32 NCHW (x_halo) -> c8 (xb_halo): the stand-alone producer
  *   vl_conv_c8_pack_w      HWIO fp32 weights -> the packed operand of vl_conv_c8_fwd (bwd = 0) / vl_conv_c8_dgrad (bwd = 1);

@@ -10,6 +10,8 @@ Cases (full AlexNet geometry, 227x227x3, fc6 encode -> LSTM(256, 1 layer, avg) -
              frames, the first 128 frames / 8 labels of cfg2_ref's streams), reference initialiser; a plain 8-clip step (the
              shard's 1/64 loss scaling is a constant factor 8/64 on every gradient, applied by the test)
   c3pair_ws  the same 8 clips as ONE global batch with well-scaled weights: the answer a 2-rank run (4 + 4 clips) must reproduce
+  t32_ws_q   t32_ws evaluated with the operand roundings of the engine's bf16 conv path (oracle q = bf16_round: every tensor that
+             path stores as packed bf16 is rounded to bf16, accumulation stays fp64) -- the arithmetic BASELINE config 5 runs in
 
 Inputs are regenerated from these seeds by the tests (tests/test_full_workload_gpu.py) and by bench.py's first-step check;
 only the oracle's outputs are stored: logits, loss, global gradient norm, accuracy, per-tensor gradient norms, 16-element heads
@@ -39,6 +41,7 @@ CASES = {
     "t32_ws": (4, 32, True),
     "c3shard_ref": (8, 16, False),
     "c3pair_ws": (8, 16, True),
+    "t32_ws_q": (4, 32, True, "bf16"),
 }
 ACT_LAYERS = ("conv1", "lrn1", "pool1", "conv2", "lrn2", "pool2", "conv3", "conv4", "conv5", "pool5", "fc6")
 
@@ -46,7 +49,7 @@ ACT_LAYERS = ("conv1", "lrn1", "pool1", "conv2", "lrn2", "pool2", "conv3", "conv
 def case_inputs(name):
     """(params, frames u8 [clips*fpc,227,227,3], onehot int32 [clips,101]) -- bench.py's seeds (rank 0)."""
     from vltf_amd.engine import NetConfig, init_params      # numpy-only initialiser shared with bench.py
-    clips, fpc, ws = CASES[name]
+    clips, fpc, ws = CASES[name][:3]
     cfg = NetConfig(image_shape=SHAPE, num_classes=NCLS, fpc=fpc, lstm_hidden=HID)
     p = init_params(cfg, seed=2, well_scaled=ws)
     frames = np.random.default_rng(0).integers(0, 256, (clips * fpc,) + SHAPE, dtype=np.uint8)
@@ -55,11 +58,12 @@ def case_inputs(name):
 
 
 def run_case(name, out):
-    clips, fpc, ws = CASES[name]
+    clips, fpc, ws = CASES[name][:3]
+    q = O.bf16_round if len(CASES[name]) > 3 else None
     p, frames, onehot = case_inputs(name)
     x = frames.astype(np.float32) - MEAN
     t0 = time.time()
-    logits, cache = O.lrcn_forward(p, x, fpc, keep=True, chunk=32)
+    logits, cache = O.lrcn_forward(p, x, fpc, keep=True, chunk=32, q=q)
     loss, dlogits = O.softmax_xent_mean(logits, onehot)
     print("%s: forward %.0f s, loss %.6f" % (name, time.time() - t0, loss), flush=True)
     for l in ACT_LAYERS:
@@ -67,7 +71,7 @@ def run_case(name, out):
     hseq = cache["lstm"][0]
     out[name + "/actnorm/lstm_c_last"] = np.array([np.linalg.norm(hseq["cs"][-1])])
     out[name + "/fused"] = cache["fused"].astype(np.float64)
-    grads = O.lrcn_backward(p, cache, dlogits, fpc)
+    grads = O.lrcn_backward(p, cache, dlogits, fpc, q=q)
     del cache
     clipped, gn = O.clip_by_global_norm(grads, CLIP)
     print("%s: backward done %.0f s, grad norm %.6f" % (name, time.time() - t0, gn), flush=True)

@@ -60,11 +60,47 @@ def device_gates(eng, n):
     return g
 
 
+def device_gates_bf16(eng, n):
+    """device_gates for the bf16 conv path: conv outputs live as packed bf16 (yb, or the next layer's packed input), only conv5's as
+    fp32; arg-max maps and the fc6 output as on the fp32 path."""
+    torch.cuda.synchronize()
+    g = {}
+
+    def unpack(t, c, halo):
+        a = t.float()                                                   # [n][cb][hp][wp][8]
+        nn, cb, hp, wp, _ = a.shape
+        full = a.permute(0, 2, 3, 1, 4).reshape(nn, hp, wp, cb * 8)
+        return full[:, halo:hp - halo, halo:wp - halo, :c]
+    for li, L in enumerate(eng.layers):
+        name, cout = L["name"], L["conv"].cout
+        if "yb" in L:
+            y = unpack(L["yb"][:n], cout, 0)
+        elif li + 1 < len(eng.layers) and not L["pool"]:
+            nxt = eng.layers[li + 1]
+            y = unpack(nxt["xb"][:n], cout, nxt["x_halo"])
+        else:
+            y = L["y"][:n].permute(0, 2, 3, 1)
+        g[name] = (y > 0).cpu().numpy().astype(np.float64)
+        if L["pool"]:
+            a = L["arg"][:n]
+            if not L["hwc"]:
+                hp = L["p_halo"]
+                if hp:
+                    a = a[:, :, hp:-hp, hp:-hp]
+                a = a.permute(0, 2, 3, 1)
+            g["pool%s_arg" % name[-1]] = a.cpu().numpy().astype(np.int8)
+    g["fc6"] = (eng.f6[:n] > 0).cpu().numpy().astype(np.float64)
+    return g
+
+
 @pytest.mark.parametrize("math,logit_tol,loss_tol", [("bf16x3", 1e-3, 1e-4), ("bf16", 5e-2, 1e-2)])
 def test_config5_clip_length_in_the_bf16_conv_arithmetics(math, logit_tol, loss_tol):
     """BASELINE config 5 = the bf16-MFMA conv path on 32-frame clips: the 4-clip x 32-frame fixture job in the opt-in conv arithmetics.
-    bf16x3 (split products) is held to the fp32 bounds; plain bf16 products are reduced precision by design (2e-3 per
-    contraction) and get the bounds of test_plain_bf16_conv_mode_runs_close."""
+    bf16x3 (split products) is held to the fp32 bounds.  The bf16 PATH is reduced precision by design; it is held (a) loosely to the
+    exact fp64 answer (logits 5e-2; the gradient norm within 25 %: rounding every stored activation to bf16 moves the LSTM's gate
+    pre-activations, and with them every gradient below the LSTM by one common factor -- the fp64 oracle shows the same shift when it
+    rounds the same operands, tools/bf16_grad_probe.py) and (b) tightly to that rounding-aware oracle, fixture t32_ws_q: logits
+    3e-2, loss 5e-3, gradient norm 8 % (measured on 8 clips: 1.1e-2 / 1e-4 / 2.3 %)."""
     import dataclasses
     from vltf_amd.engine import LRCNEngine
     gold = np.load(GOLD)
@@ -74,9 +110,57 @@ def test_config5_clip_length_in_the_bf16_conv_arithmetics(math, logit_tol, loss_
     out = eng.train_step_u8(torch.from_numpy(frames).to(DEV), torch.from_numpy(onehot).to(DEV), lr=LR, clip_norm=CLIP, mean_bgr=MEAN)
     want = gold["t32_ws/logits"]
     loss, gn, _ = gold["t32_ws/loss_gn_acc"]
-    assert np.abs(eng.logits_host() - want).max() <= logit_tol
+    logits = eng.logits_host()
+    assert np.abs(logits - want).max() <= logit_tol
     assert abs(out["loss"] - loss) <= loss_tol * max(1.0, abs(loss))
-    assert abs(out["grad_norm"] - gn) <= (5e-3 if math == "bf16x3" else 0.3) * gn
+    assert abs(out["grad_norm"] - gn) <= (5e-3 if math == "bf16x3" else 0.25) * gn
+    if math == "bf16":
+        if "t32_ws_q/logits" not in gold.files:
+            pytest.fail("fixture case t32_ws_q missing from lrcn_full.npz (run tests/golden/make_golden_full.py t32_ws_q)")
+        lq, gq, _ = gold["t32_ws_q/loss_gn_acc"]
+        print("bf16 path vs rounding-aware oracle: max |dlogit| %.3e, loss %.6f / %.6f, gradient norm %.4f / %.4f (exact fp64: %.4f)" %
+              (np.abs(logits - gold["t32_ws_q/logits"]).max(), out["loss"], lq, out["grad_norm"], gq, gn))
+        assert np.abs(logits - gold["t32_ws_q/logits"]).max() <= 3e-2
+        assert abs(out["loss"] - lq) <= 5e-3 * max(1.0, abs(lq))
+        assert abs(out["grad_norm"] - gq) <= 0.08 * gq
+
+
+def test_bf16_path_full_geometry_gradients_against_the_rounding_aware_oracle():
+    """The packed-bf16 conv path (BASELINE config 5) at full geometry, every gradient tensor: 2 clips x 4 frames of 227 x 227,
+    well-scaled weights.  The oracle runs with the path's operand roundings (q = bf16_round on every tensor the path stores as packed
+    bf16: frames, weights, conv1..conv4 outputs, pooled outputs, fc6 / LSTM-projection operands, the packed gradients) and with the
+    DEVICE's ReLU / arg-max decisions, so the comparison is rounding against rounding.  It is still not fp32-tight: a value within
+    an fp32 ulp of a bf16 rounding boundary rounds the other way on the device than in fp64 (forward tensors agree to 2e-5 after
+    conv1, 1e-3 at fc6), and the LSTM amplifies that (its outputs agree to ~1e-2).  Bound per tensor: 0.15 relative L2 below the
+    LSTM, 0.02 for the head (measured at 8 clips x 16 frames: 3.5e-2 .. 1.0e-1 and 5e-3); against the EXACT oracle the same
+    gradients sit at 0.2 .. 0.4 -- the distance of the arithmetic itself."""
+    import dataclasses
+    from vltf_amd.engine import LRCNEngine, NetConfig, init_params
+    fpc, b = 4, 2
+    cfg = NetConfig(image_shape=SHAPE, num_classes=NCLS, fpc=fpc, lstm_hidden=HID)
+    p = init_params(cfg, seed=7, well_scaled=True)
+    rng = np.random.default_rng(70)
+    frames = rng.integers(0, 256, (b * fpc,) + SHAPE, dtype=np.uint8)
+    onehot = O.labels_to_one_hot([[l] for l in rng.integers(0, NCLS, b)], NCLS)
+    eng = LRCNEngine(dataclasses.replace(cfg, conv_math="bf16"), max_clips=b, device=DEV)
+    eng.load_params(p)
+    out = eng.train_step_u8(torch.from_numpy(frames).to(DEV), torch.from_numpy(onehot).to(DEV), lr=0.0, clip_norm=0.0, mean_bgr=MEAN)
+    gates = device_gates_bf16(eng, b * fpc)
+    x = frames.astype(np.float32) - MEAN
+    logits, cache = O.lrcn_forward(p, x, fpc, keep=True, chunk=4, q=O.bf16_round)
+    loss, dlogits = O.softmax_xent_mean(logits, onehot)
+    assert np.abs(eng.logits_host() - logits).max() <= 3e-2
+    assert abs(out["loss"] - loss) <= 5e-3 * max(1.0, abs(loss))
+    want = O.lrcn_backward(p, cache, dlogits, fpc, gates=gates, q=O.bf16_round)
+    exact_logits, ecache = O.lrcn_forward(p, x, fpc, keep=True, chunk=4)
+    _, edl = O.softmax_xent_mean(exact_logits, onehot)
+    exact = O.lrcn_backward(p, ecache, edl, fpc)
+    g = eng.get_grads()
+    rel = lambda a, w: np.linalg.norm((a - w).ravel()) / (np.linalg.norm(w.ravel()) + 1e-30)
+    worst = {k: (rel(g[k], want[k]), rel(g[k], exact[k])) for k in p}
+    print("relative L2 per tensor (vs rounding-aware oracle with device gates, vs exact oracle):", {k: "%.1e / %.1e" % v for k, v in worst.items()})
+    for k, (err, _) in worst.items():
+        assert err < (0.02 if k.startswith("output_fc") else 0.15), "grad %s: relative L2 error %.3e" % (k, err)
 
 
 @pytest.mark.parametrize("name", ["cfg2_ws", "cfg2_ref", "t32_ws"])

@@ -201,6 +201,44 @@ def test_untrusted_record_lengths(tmp_path):
         _hostio.read_frames(bad, 0, 1, (4, 4, 3), verify_crc=False, threads=1)
 
 
+def test_python_reader_rejects_untrusted_lengths(tmp_path):
+    """The pure-Python tf_record_iterator (the reader of vectors datasets: dataset_._read_vectors, skip, vector_dim) trusts no
+    length either: an oversized length fails as a truncated file instead of a MemoryError / OverflowError from f.read, skip()
+    notices the end of the file, and running out of records inside skip() is an IOError, not a bare StopIteration."""
+    from vltf_amd import tfrecord as T
+    path = str(tmp_path / "v.tfrecord")
+    with T.TFRecordWriter(path) as w:
+        for i in range(3):
+            w.write(T.encode_example({"dimension": 4, "label": [i], "vector_raw": np.arange(4, dtype=np.float32).tobytes()}))
+    good = bytearray(open(path, "rb").read())
+    n, = struct.unpack("<Q", good[:8])
+    rec = 12 + n + 4
+    for bogus in (2 ** 64 - 3, 2 ** 63 + 5, len(good) * 2, len(good) - rec - 16 + 1):
+        raw = bytearray(good)
+        raw[rec:rec + 8] = struct.pack("<Q", bogus)
+        bad = str(tmp_path / "vbad.tfrecord")
+        open(bad, "wb").write(raw)
+        it = T.tf_record_iterator(bad, verify_crc=False)
+        next(it)                                                     # record 0 is intact
+        with pytest.raises(IOError, match="truncated"):
+            next(it)
+        it.close()
+        it = T.tf_record_iterator(bad, verify_crc=False)
+        with pytest.raises(IOError, match="truncated"):
+            it.skip(2)
+        it.close()
+    it = T.tf_record_iterator(path)
+    with pytest.raises(IOError, match="ends after 3 of the 5"):
+        it.skip(5)
+    it.close()
+    open(str(tmp_path / "cut.tfrecord"), "wb").write(good[:rec + 20])    # file cut inside record 1's payload
+    it = T.tf_record_iterator(str(tmp_path / "cut.tfrecord"))
+    next(it)
+    with pytest.raises(IOError, match="truncated"):
+        next(it)
+    it.close()
+
+
 def test_size_file(tmp_path):
     p = str(tmp_path / "x.size")
     T.write_size_file(p, 5, "video", [2, 2, 3, 3, 3], 16, 1)

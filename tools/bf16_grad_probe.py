@@ -41,19 +41,28 @@ def main():
         import dataclasses
         import torch
         sys.path.insert(0, os.path.join(ROOT, "tests"))
-        from test_full_workload_gpu import device_gates
+        from test_full_workload_gpu import device_gates_bf16
         from vltf_amd.engine import LRCNEngine
         eng = LRCNEngine(dataclasses.replace(cfg, conv_math="bf16"), max_clips=args.clips, device="cuda:0")
         eng.load_params(p)
         out = eng.train_step_u8(torch.from_numpy(frames).to("cuda:0"), torch.from_numpy(onehot).to("cuda:0"), lr=0.0, clip_norm=0.0, mean_bgr=MEAN)
         res["device bf16"] = (out["loss"], out["grad_norm"], eng.get_grads(), eng.logits_host())
         gates = device_gates_bf16(eng, args.clips * args.fpc)
+        acts = device_activations_bf16(eng, args.clips * args.fpc)
     for tag, q in (("oracle exact", None), ("oracle bf16-rounded", O.bf16_round)):
         logits, cache = O.lrcn_forward(p, x, args.fpc, keep=True, chunk=32, q=q)
         loss, dlogits = O.softmax_xent_mean(logits, onehot)
         g = O.lrcn_backward(p, cache, dlogits, args.fpc, q=q)
         _, gn = O.clip_by_global_norm(g, 0.0)
         res[tag] = (loss, gn, g, logits)
+        if args.gpu:
+            print("forward activations, device bf16 path vs %s (relative L2):" % tag)
+            want = {k: np.concatenate([c[k] for c in cache["cnn"]], axis=0) for k in ("conv1", "pool1", "conv2", "pool2", "conv3", "conv4", "conv5", "pool5", "fc6")}
+            want["lstm_out"] = np.stack([np.tanh(cs) * gt[3] for cs, gt in zip(cache["lstm"][0]["cs"], cache["lstm"][0]["gates"])], 1)
+            want["fused"] = cache["fused"]
+            for k, v in acts.items():
+                w = want[k].reshape(v.shape)
+                print("   %-10s %.3e" % (k, np.linalg.norm((v - w).ravel()) / (np.linalg.norm(w.ravel()) + 1e-300)))
         if q is not None and gates is not None:
             gg = O.lrcn_backward(p, cache, dlogits, args.fpc, q=q, gates=gates)
             _, gn2 = O.clip_by_global_norm(gg, 0.0)
@@ -75,38 +84,26 @@ def main():
             np.abs(res["device bf16"][3] - res["oracle bf16-rounded"][3]).max(), np.abs(res["device bf16"][3] - res["oracle exact"][3]).max()))
 
 
-def device_gates_bf16(eng, n):
-    """device_gates for the bf16 path: conv outputs live as packed bf16 (yb / the next layer's xb), only conv5's as fp32."""
+def device_activations_bf16(eng, n):
+    """Forward tensors of the engine's last step in the oracle's layouts (NHWC / row-major), unpacked from wherever the bf16 path keeps them."""
     import torch
     torch.cuda.synchronize()
-    g = {}
 
     def unpack(t, c, halo):
-        a = t.float()                                                   # [n][cb][hp][wp][8]
+        a = t.float()
         nn, cb, hp, wp, _ = a.shape
         full = a.permute(0, 2, 3, 1, 4).reshape(nn, hp, wp, cb * 8)
-        return full[:, halo:hp - halo, halo:wp - halo, :c]
-    for li, L in enumerate(eng.layers):
-        name = L["name"]
-        cout = L["conv"].cout
-        if "yb" in L:
-            y = unpack(L["yb"][:n], cout, 0)
-        elif li + 1 < len(eng.layers) and not L["pool"]:
-            nxt = eng.layers[li + 1]
-            y = unpack(nxt["xb"][:n], cout, nxt["x_halo"])
-        else:
-            y = L["y"][:n].permute(0, 2, 3, 1)
-        g[name] = (y > 0).cpu().numpy().astype(np.float64)
-        if L["pool"]:
-            a = L["arg"][:n]
-            if not L["hwc"]:
-                hp = L["p_halo"]
-                if hp:
-                    a = a[:, :, hp:-hp, hp:-hp]
-                a = a.permute(0, 2, 3, 1)
-            g["pool%s_arg" % name[-1]] = a.cpu().numpy().astype(np.int8)
-    g["fc6"] = (eng.f6[:n] > 0).cpu().numpy().astype(np.float64)
-    return g
+        return full[:, halo:hp - halo, halo:wp - halo, :c].cpu().numpy().astype(np.float64)
+    L = eng.layers
+    out = {"conv1": unpack(L[0]["yb"][:n], 96, 0), "pool1": unpack(L[1]["xb"][:n], 96, L[1]["x_halo"]),
+           "conv2": unpack(L[1]["yb"][:n], 256, 0), "pool2": unpack(L[2]["xb"][:n], 256, L[2]["x_halo"]),
+           "conv3": unpack(L[3]["xb"][:n], 384, L[3]["x_halo"]), "conv4": unpack(L[4]["xb"][:n], 384, L[4]["x_halo"]),
+           "conv5": L[4]["y"][:n].permute(0, 2, 3, 1).cpu().numpy().astype(np.float64),
+           "pool5": L[4]["p"][:n].cpu().numpy().astype(np.float64),
+           "fc6": eng.f6[:n].cpu().numpy().astype(np.float64),
+           "lstm_out": eng.lstm[0]["hseq"][:n].cpu().numpy().astype(np.float64),
+           "fused": eng.fused[:n // eng.T].cpu().numpy().astype(np.float64)}
+    return out
 
 
 if __name__ == "__main__":

@@ -43,7 +43,7 @@ PY
           || { tail -20 "$out/bench_fpc32.err"; exit 1; }
       tail -c 300 "$out/bench_fpc32.json"; echo ;;
     bf16probe)
-      timeout -k 10 900 python tools/bf16_grad_probe.py --clips 8 --gpu > "$out/bf16_probe_ref.txt" 2> "$out/bf16_probe_ref.err" || { tail -20 "$out/bf16_probe_ref.err"; exit 1; }
+      timeout -k 10 900 python tools/bf16_grad_probe.py --clips ${PROBE_CLIPS:-8} --gpu ${PROBE_ARGS:-} > "$out/bf16_probe_ref.txt" 2> "$out/bf16_probe_ref.err" || { tail -20 "$out/bf16_probe_ref.err"; exit 1; }
       tail -25 "$out/bf16_probe_ref.txt" ;;
     *) echo "unknown step $s"; exit 2 ;;
   esac

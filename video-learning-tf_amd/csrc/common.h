@@ -47,6 +47,19 @@ __device__ __forceinline__ uint32_t fd_div(uint32_t n, const FastDiv& f) { retur
 
 static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// compute units of the current device (256 on MI355X), cached per translation unit: launch plans that size a grid to "one round of
+// workgroups" take it from here, not from a literal
+static inline int vl_device_cus() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                  ? prop.multiProcessorCount : 256;
+    }
+    return cus;
+}
+
 // one 64-lane wavefront reductions (gfx950: wave = 64)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

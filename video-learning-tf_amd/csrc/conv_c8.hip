@@ -886,7 +886,7 @@ static int c8_wgrad_plan(const vl_conv_desc* d, int n, C8WgPlan* p) {
     p->L = (d->oh - 1) * Wp + d->ow;
     p->Rtot = (int64_t)n * p->L;
     const int tiles = p->tiles_a * p->tiles_b * d->groups;
-    int slabs = (2 * 256) / tiles;                                   // ONE round of two workgroups per CU: a 513th workgroup would run alone
+    int slabs = (2 * vl_device_cus()) / tiles;                       // ONE round of two workgroups per CU: one more would run alone
     const int64_t stages = (p->Rtot + 31) / 32;
     if (slabs > stages / 8) slabs = (int)(stages / 8);               // at least 8 stages per slab
     if (slabs < 1) slabs = 1;
@@ -1266,7 +1266,7 @@ static void gemm_kc8_plan(int m, int n, int k, int* tiles_a, int* tiles_b, int* 
     *tiles_b = (n + 127) / 128;
     const int tiles = *tiles_a * *tiles_b;
     const int64_t stages = ((int64_t)k + 31) / 32;
-    int s = (2 * 256) / tiles;
+    int s = (2 * vl_device_cus()) / tiles;
     if (s > stages / 8) s = (int)(stages / 8);
     if (s < 1) s = 1;
     const int64_t per = (stages + s - 1) / s;

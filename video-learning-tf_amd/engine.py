@@ -762,17 +762,19 @@ class LRCNEngine:
                     self._run(name + ".dgrad", conv.c8_dgrad, L["dyb"][:n], L["wbt"], dxb=prev["dyb"][:n], relu_mask_c8=L["xb"][:n])
                 continue
             side = self._side_stream()
-            if side is not None:           # experiment (VLTF_WGRAD_STREAM=1): wgrad on a second stream beside this layer's dgrad
+            if side is not None:           # the weight gradient on the second stream, beside this layer's dgrad / the next pool backward
                 side.wait_stream(torch.cuda.current_stream(self.dev))
                 ctx = torch.cuda.stream(side)
-            else:
+                wws, wsw = self.ws_side, self.small_ws_side      # the side stream's OWN scratch: nothing the main stream launches
+            else:                                                # meanwhile can touch it, whatever takes a workspace there later
                 ctx = contextlib.nullcontext()
+                wws, wsw = self.ws, sw
             with ctx:
                 if conv.fuses_bias():      # bias gradient comes out of the same pass over dy
-                    self._run(name + ".wgrad", conv.wgrad, x_in, dy, G["dcnn/%sW" % name], self.ws, db=G["dcnn/%sb" % name])
+                    self._run(name + ".wgrad", conv.wgrad, x_in, dy, G["dcnn/%sW" % name], wws, db=G["dcnn/%sb" % name])
                 else:
-                    self._run(name + ".wgrad", conv.wgrad, x_in, dy, G["dcnn/%sW" % name], self.ws)
-                    ops.bias_grad_nchw(dy, G["dcnn/%sb" % name], sw)
+                    self._run(name + ".wgrad", conv.wgrad, x_in, dy, G["dcnn/%sW" % name], wws)
+                    ops.bias_grad_nchw(dy, G["dcnn/%sb" % name], wsw)
                 if self.dp is not None and name == "conv3":
                     # issued from the stream the weight gradients ran on: RCCL's stream waits for that stream only
                     self.dp.reduce_async(self.g, *self.grad_chunks[-2])
@@ -800,7 +802,11 @@ class LRCNEngine:
             return None
         if getattr(self, "_side", None) is None:
             self._side = torch.cuda.Stream(device=self.dev)
-            self.ws_side = torch.empty((64 << 20) // 4, device=self.dev)        # split-k slabs of a GEMM that runs on the side stream
+            # Invariant of the two-stream backward: a launch on the side stream reads tensors the main stream has finished (it waits
+            # for the main stream at the start of every layer), writes only its own gradient tensors, and takes its scratch from
+            # THESE buffers, never from self.ws / self.small_ws -- so no main-stream launch between the fork and the join can race it.
+            self.ws_side = torch.empty_like(self.ws)              # wgrad slabs / split-k slabs of what runs on the side stream
+            self.small_ws_side = torch.empty_like(self.small_ws)
         return self._side
 
     def _pool_bwd(self, L, n, dx, relu_mask, dx_halo):

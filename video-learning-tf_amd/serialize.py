@@ -93,100 +93,115 @@ class SerializationSettings:
         return self
 
 
-# ---- clip / frame selection per video (serialize.py:269-378) ----------------------------------------------------------------------
-def _missing_frames(avail, settings, path, message):
-    """Common too-few-frames handling of rand_frames and iterative: abort | compromise (duplicate random frames) | report."""
-    if settings.generation_error == defs.generation_error.abort:
+# ---- clip / frame selection per video (serialize.py:269-408) ----------------------------------------------------------------------
+# The three clipframe modes share two stages.  Stage 1: a video with fewer frames than one clip (num_frames_per_clip) meets the
+# `generation_error` policy -- one helper for all modes.  Stage 2, per mode: where the clips start.
+def _shortfall(settings, path, message):
+    """The generation_error policy for a video that cannot supply what was asked (serialize.py:277-289,309-335,366-376).
+    abort: raise.  Otherwise the problem is logged in settings.generation_log and the caller is told whether to PAD the request
+    (compromise -> True) or to DROP the video (report -> False)."""
+    policy = settings.generation_error
+    if policy == defs.generation_error.abort:
         error(message)
+    if policy not in (defs.generation_error.compromise, defs.generation_error.report):
+        error("Undefined generation error strategy: %s" % policy)
     settings.generation_log.append((message, path))
-    if settings.generation_error == defs.generation_error.compromise:
-        avail.extend([random.choice(avail) for _ in range(settings.num_frames_per_clip - len(avail))])
-        return True
-    if settings.generation_error == defs.generation_error.report:
-        return False
-    error("Undefined generation error strategy: %s" % settings.generation_error)
+    return policy == defs.generation_error.compromise
 
 
-def get_random_frames(avail_frame_idxs, settings, path):
-    """serialize.py:269-291: num_frames_per_clip frames drawn at random from the video.  (The reference assigns the None that
-    random.shuffle returns and hands back a flat index list that generate_frames_for_video cannot iterate as clips; the evident
-    intent -- ONE clip of shuffled frames -- is what this returns.)"""
-    avail = list(avail_frame_idxs)
-    random.shuffle(avail)
-    if settings.num_frames_per_clip - len(avail) > 0:
-        msg = "Attempted to get a %d-framed clip from video %s which has %d frames." % (settings.num_frames_per_clip, os.path.basename(path), len(avail))
-        if not avail or not _missing_frames(avail, settings, path, msg):
-            return []
-    return [avail[:settings.num_frames_per_clip]]
+def _pad_with_random_frames(frames, missing):
+    return frames + [random.choice(frames) for _ in range(missing)]
 
 
-def get_random_clips(avail_frame_idxs, settings, path):
-    """serialize.py:293-357: clip_offset_or_num clips of consecutive frames at random starts, spread over the video (a chosen
-    start removes the starts within one clip length of it until none are left, then the pool refills)."""
-    avail = list(avail_frame_idxs)
-    num_frames, fpc, want = len(avail), settings.num_frames_per_clip, settings.clip_offset_or_num
-    if num_frames == 0:
-        error("No frames for path [%s]" % path)
-    if fpc - num_frames > 0:
-        msg = "Video %s cannot sustain a number of %d fpc, as it has %d frames" % (os.path.basename(path), fpc, num_frames)
-        if settings.generation_error == defs.generation_error.abort:
-            error(msg)
-        settings.generation_log.append((msg, path))
-        if settings.generation_error == defs.generation_error.compromise:
-            avail = [0] * (fpc - num_frames) + avail                 # duplicate the start frame up to the clip length
-            return [list(avail) for _ in range(want)]
-        if settings.generation_error != defs.generation_error.report:
-            error("Undefined generation error strategy: %s" % settings.generation_error)
-    possible = list(range(num_frames - fpc + 1))
-    if want - len(possible) > 0:
-        msg = "Video %s cannot sustain a number of %d cpv as it has %d frames" % (os.path.basename(path), want, num_frames)
-        if settings.generation_error == defs.generation_error.abort:
-            error(msg)
-        settings.generation_log.append((msg, path))
-        if settings.generation_error == defs.generation_error.compromise:
-            possible.extend([random.choice(possible) for _ in range(want - len(possible))])
-        elif settings.generation_error == defs.generation_error.report:
-            return []
-        else:
-            error("Undefined generation error strategy: %s" % settings.generation_error)
+def _pad_with_start_frame(frames, missing):
+    return [0] * missing + frames                       # rand_clips duplicates the first frame up to the clip length
+
+
+#                     message of stage 1 (clip length, video, frames it has)                                        padding
+_TOO_SHORT = {
+    defs.clipframe_mode.rand_frames: ("Attempted to get a %d-framed clip from video %s which has %d frames.", _pad_with_random_frames),
+    defs.clipframe_mode.rand_clips: ("Video %s cannot sustain a number of %d fpc, as it has %d frames", _pad_with_start_frame),
+    defs.clipframe_mode.iterative: ("Attempted to get %d-framed sequential clips from video %s which has %d frames.", _pad_with_random_frames),
+}
+
+
+def _fit_to_clip_length(frames, mode, settings, path):
+    """Stage 1.  -> (frames to continue with, padded?) or (None, False) when the policy drops the video."""
+    fpc, n = settings.num_frames_per_clip, len(frames)
+    if fpc - n <= 0:
+        return frames, False
+    text, pad = _TOO_SHORT[mode]
+    name = os.path.basename(path)
+    message = text % ((name, fpc, n) if mode == defs.clipframe_mode.rand_clips else (fpc, name, n))
+    if not frames or not _shortfall(settings, path, message):
+        return None, False
+    return pad(frames, fpc - n), True
+
+
+def _spread_random_starts(possible, want, fpc):
+    """rand_clips, stage 2 (serialize.py:337-357): `want` random starts; a chosen start takes the starts within one clip length of
+    it out of the pool, and the pool refills when it runs dry."""
     starts, pool = [], list(possible)
     for _ in range(want):
         st = random.choice(pool)
         starts.append(st)
-        for i in range(st - fpc + 1, st + fpc):
+        for i in range(st - fpc + 1, st + fpc):          # ONE occurrence each: a pool padded with repeated starts keeps the others
             if i in pool:
                 pool.remove(i)
         if not pool:
             pool = list(possible)
-    return [list(range(st, st + fpc)) for st in starts]
+    return starts
+
+
+def select_clips(avail_frame_idxs, settings, path, mode=None):
+    """Frame indices per clip of one video under settings.clipframe_mode (serialize.py:269-378).
+      rand_frames  ONE clip of num_frames_per_clip frames drawn at random.  (The reference assigns the None that random.shuffle returns
+                   and hands back a flat index list generate_frames_for_video cannot iterate as clips; the evident intent is built.)
+      rand_clips   clip_offset_or_num clips of consecutive frames at random, spread starts
+      iterative    every clip of consecutive frames whose starts are num_frames_per_clip + clip_offset_or_num frames apart"""
+    mode = mode or settings.clipframe_mode
+    if mode not in _TOO_SHORT:
+        error("Undefined clipframe mode [%s]" % mode)
+    frames = list(avail_frame_idxs)
+    n, fpc, k = len(frames), settings.num_frames_per_clip, settings.clip_offset_or_num
+    if mode == defs.clipframe_mode.rand_clips and n == 0:
+        error("No frames for path [%s]" % path)
+    if mode == defs.clipframe_mode.rand_frames:
+        random.shuffle(frames)
+    fitted, padded = _fit_to_clip_length(frames, mode, settings, path)
+    if mode == defs.clipframe_mode.rand_frames:
+        return [] if fitted is None else [fitted[:fpc]]
+    if mode == defs.clipframe_mode.iterative:
+        # (like the reference, the start range uses the ORIGINAL frame count: a compromised short video yields no clip here and is
+        # caught by check_cpv_per_item)
+        return [] if fitted is None else [list(range(st, st + fpc)) for st in range(0, n - fpc + 1, fpc + k)]
+    if padded:                                           # rand_clips on a padded video: the one possible clip, k times
+        return [list(fitted) for _ in range(k)]
+    possible = list(range(n - fpc + 1))                  # (a dropped video goes on: with no start left it is reported a second time)
+    if k - len(possible) > 0:
+        message = "Video %s cannot sustain a number of %d cpv as it has %d frames" % (os.path.basename(path), k, n)
+        if not _shortfall(settings, path, message):
+            return []
+        possible = _pad_with_random_frames(possible, k - len(possible))
+    return [list(range(st, st + fpc)) for st in _spread_random_starts(possible, k, fpc)]
+
+
+def get_random_frames(avail_frame_idxs, settings, path):
+    return select_clips(avail_frame_idxs, settings, path, defs.clipframe_mode.rand_frames)
+
+
+def get_random_clips(avail_frame_idxs, settings, path):
+    return select_clips(avail_frame_idxs, settings, path, defs.clipframe_mode.rand_clips)
 
 
 def get_sequential_clips(avail_frame_idxs, settings, path):
-    """serialize.py:359-378: every clip of fpc consecutive frames whose starts are fpc + clip_offset_or_num frames apart."""
-    avail = list(avail_frame_idxs)
-    num_frames, fpc = len(avail), settings.num_frames_per_clip
-    if fpc - num_frames > 0:
-        msg = "Attempted to get %d-framed sequential clips from video %s which has %d frames." % (fpc, os.path.basename(path), num_frames)
-        if not avail or not _missing_frames(avail, settings, path, msg):
-            return []
-    # (like the reference, the start range uses the ORIGINAL frame count: a compromised short video yields no clip here and is
-    # caught by check_cpv_per_item)
-    return [list(range(st, st + fpc)) for st in range(0, num_frames - fpc + 1, fpc + settings.clip_offset_or_num)]
+    return select_clips(avail_frame_idxs, settings, path, defs.clipframe_mode.iterative)
 
 
 def generate_frames_for_video(path, settings):
     """serialize.py:381-408: the sorted frame files of the folder `path` -> frame paths per clip."""
     files = sorted(f for f in os.listdir(path) if os.path.isfile(os.path.join(path, f)))
-    avail = list(range(len(files)))
-    if settings.clipframe_mode == defs.clipframe_mode.rand_frames:
-        clips = get_random_frames(avail, settings, path)
-    elif settings.clipframe_mode == defs.clipframe_mode.rand_clips:
-        clips = get_random_clips(avail, settings, path)
-    elif settings.clipframe_mode == defs.clipframe_mode.iterative:
-        clips = get_sequential_clips(avail, settings, path)
-    else:
-        error("Undefined clipframe mode [%s]" % settings.clipframe_mode)
-    return [[os.path.join(path, files[i]) for i in clip] for clip in clips]
+    return [[os.path.join(path, files[i]) for i in clip] for clip in select_clips(range(len(files)), settings, path)]
 
 
 def check_cpv_per_item(paths_per_item, items_list, settings):

@@ -11,6 +11,7 @@
   (serialize.py:138-151, dataset_.py:701-756).
 """
 import itertools
+import os
 import struct
 from ast import literal_eval
 
@@ -90,6 +91,7 @@ class tf_record_iterator:
     def __init__(self, path, verify_crc=True):
         self.f = open(path, "rb")
         self.verify = verify_crc
+        self.size = os.fstat(self.f.fileno()).st_size          # record lengths come from the file: none may reach past its end
 
     def __iter__(self):
         return self
@@ -103,6 +105,9 @@ class tf_record_iterator:
         length, = struct.unpack("<Q", hdr[:8])
         if self.verify and struct.unpack("<I", hdr[8:])[0] != masked_crc32c(hdr[:8]):
             raise IOError("corrupted TFRecord length CRC")
+        if length > self.size - self.f.tell() - 4:             # payload + its CRC must fit in what is left (as vlh's record_fits)
+            raise IOError("truncated TFRecord: a record of %d bytes at offset %d reaches past the end of the file (%d bytes)" %
+                          (length, self.f.tell() - 12, self.size))
         return length
 
     def __next__(self):
@@ -116,8 +121,11 @@ class tf_record_iterator:
         return payload
 
     def skip(self, count):
-        for _ in range(count):
-            length = self._header()
+        for i in range(count):
+            try:
+                length = self._header()
+            except StopIteration:                              # a bare StopIteration would end somebody's for-loop silently
+                raise IOError("truncated TFRecord: the file ends after %d of the %d records to skip" % (i, count))
             self.f.seek(length + 4, 1)
 
     def close(self):
