@@ -107,6 +107,28 @@ def test_gemm_split_products(ops, conv_math, ta, tb, m, n, k):
         close(got2, want2)
 
 
+@pytest.mark.parametrize("m,n,k,ws_mb", [(130, 300, 200, 4), (1000, 384, 130, 16), (256, 512, 4096, 16), (9216, 4096, 128, 64), (4352, 1024, 1024, 64)])
+def test_gemm_reduction_major_operands_at_the_step_sizes(ops, m, n, k, ws_mb):
+    """vl_gemm transa = 1 (x^T dy: the fc / LSTM weight gradients) with leading dimensions, split reduction through the workspace,
+    bias + ReLU + mask, up to fc6's weight gradient on an 8-clip shard (9216 x 4096 x 128) and the benchmark's LSTM kernel gradient
+    (4352 x 1024 x 1024)."""
+    rng = np.random.default_rng(m + n + k)
+    at = rng.standard_normal((k, m + 3)).astype(np.float32)            # A stored [k][m], lda = m + 3
+    b = rng.standard_normal((k, n + 5)).astype(np.float32)             # ldb = n + 5
+    bias = rng.standard_normal(n).astype(np.float32)
+    ws = torch.empty(ws_mb << 18, device=DEV)
+    c = torch.zeros((m, n + 2), device=DEV)
+    atd, bd = dev(at), dev(b)
+    ops.gemm(atd, bd, c, m, n, k, transa=True, lda=m + 3, ldb=n + 5, ldc=n + 2, ws=ws)
+    want = (torch.from_numpy(at[:, :m]).double().t() @ torch.from_numpy(b[:, :n]).double()).numpy()
+    got = host(c)
+    close(got[:, :n], want)
+    assert np.all(got[:, n:] == 0)                                      # padding untouched
+    mask = rng.standard_normal((m, n + 2)).astype(np.float32)
+    ops.gemm(atd, bd, c, m, n, k, transa=True, lda=m + 3, ldb=n + 5, ldc=n + 2, bias=dev(bias), relu=True, relu_mask=dev(mask), ws=ws)
+    close(host(c)[:, :n], np.maximum(want + bias, 0) * (mask[:, :n] > 0))
+
+
 def test_gemm_ld_and_splitk(ops):
     rng = np.random.default_rng(7)
     m, n, k = 64, 200, 2048
