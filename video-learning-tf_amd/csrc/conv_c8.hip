@@ -513,7 +513,9 @@ static int dispatch_c8(C8ConvArgs& a, int groups, hipStream_t stream) {
     static const bool q192 = getenv("VL_C8_Q192") != nullptr;
     if (a.Cog % 128 != 0 && a.Cog % 192 == 0 && !q192) return launch_c8<4, 1, 2, 3>(a, groups, stream);
     if (a.Cog % 128 != 0 && a.Cog % 192 == 0) return launch_c8<4, 2, 2, 3>(a, groups, stream);   // 256 x 192
-    return launch_c8<4, 2, 2, 2>(a, groups, stream);                           // 256 x 128 (128 x 128 tiles of 4 waves, three per CU: 1-4 % slower)
+    // 256 x 128 on 8 waves of 64 x 64.  Measured alternatives: 128 x 128 tiles of 4 waves, three per CU: 1-4 % slower; 256 x 128 on FOUR
+    // waves of 64 pixels x 128 channels (16 MFMAs per wave between barriers instead of 8): within +-4 % on every launch (round 3)
+    return launch_c8<4, 2, 2, 2>(a, groups, stream);
 }
 
 /* y = conv(x) + bias (ReLU) from the c8 operand xb and vl_conv_c8_pack_w(bwd = 0)'s weights: y (fp32 NCHW, y_halo) and / or yb

@@ -916,47 +916,65 @@ extern "C" int vl_maxpool_fwd(const float* x, float* y, uint8_t* argmax, int n, 
 // wave walks input columns, so its <= 4 pooled neighbours are c * 4 bytes apart -- every byte / float of the pooled tensors is
 // its own cache line.  Here a workgroup stages the pooled gradient and arg-max of CB channels of one image through LDS
 // (coalesced along c, which is contiguous in the source), then writes the NCHW planes coalesced along the pixels.
+// Round 3: lane = pixel, channels in the loop (was: one flat element index per thread with two divisions per element): 0.355 ->
+// 0.176 ms at 1024 frames (tools/pool5_probe.py; VL_MAXPOOL_GENERIC=1 runs the element-per-thread kernel).  The same treatment
+// of the FORWARD (64 planes copied to LDS, lane = channel) was slower than the element-per-thread kernel (0.105 vs 0.071 ms) and
+// was dropped: its strided writes are absorbed by the L2, the serial copy phase is not.
 template <int CB>
 __global__ __launch_bounds__(256) void maxpool_bwd_hwc_k3s2_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ arg,
                                                                    float* __restrict__ dx, const float* __restrict__ mask, int C, int H,
                                                                    int W, int OH, int OW, int halo) {
     extern __shared__ __attribute__((aligned(16))) unsigned char pl_smem[];
-    const int OHW = OH * OW, HW = H * W;
-    float* sdy = reinterpret_cast<float*>(pl_smem);                    // [CB][OHW + 1]
-    uint8_t* sarg = pl_smem + (size_t)CB * (OHW + 1) * sizeof(float);   // [CB][OHW + 1]
+    const int OHW = OH * OW, HW = H * W, SP = OHW + 1;
+    uint2* sp = reinterpret_cast<uint2*>(pl_smem);                     // [CB][OHW + 1] entries {dy bits, arg-max}
     const int img = blockIdx.y, c0 = blockIdx.x * CB;
+    const int nch = min(CB, C - c0);
     const float* dyp = dy + (int64_t)img * OHW * C;
     const uint8_t* ap = arg + (int64_t)img * OHW * C;
     for (int e = threadIdx.x; e < CB * OHW; e += 256) {
         const int p = e / CB, cl = e - p * CB;                        // lanes walk c: contiguous in the (h, w, c) source
-        const bool ok = c0 + cl < C;
-        sdy[cl * (OHW + 1) + p] = ok ? dyp[(int64_t)p * C + c0 + cl] : 0.f;
-        sarg[cl * (OHW + 1) + p] = ok ? ap[(int64_t)p * C + c0 + cl] : (uint8_t)255;
+        const bool ok = cl < nch;
+        sp[cl * SP + p] = make_uint2(ok ? __float_as_uint(dyp[(int64_t)p * C + c0 + cl]) : 0u, ok ? (uint32_t)ap[(int64_t)p * C + c0 + cl] : 255u);
     }
+    if ((int)threadIdx.x < CB) sp[threadIdx.x * SP + OHW] = make_uint2(0u, 255u);   // the pad entry unreachable windows read
     __syncthreads();
+    // lane = input pixel (64 at a time), wave w takes channels w, w + 4, ...: a pixel's <= 4 windows (rows ih>>1 and one above,
+    // columns iw>>1 and one to the left) are decoded ONCE per pixel chunk, the channel loop is 4 LDS reads, 4 compare-selects, the
+    // mask load and the store -- no division per element
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wp = W + 2 * halo;
     const int64_t pp = (int64_t)(H + 2 * halo) * wp;
-    for (int e = threadIdx.x; e < CB * HW; e += 256) {
-        const int cl = e / HW, p = e - cl * HW;
-        if (c0 + cl >= C) break;
-        const int ih = p / W, iw = p - ih * W;
-        const int64_t plane = (int64_t)img * C + c0 + cl;
-        float acc = 0.f;
-        if (!mask || mask[plane * HW + p] > 0.f) {
+    for (int pc = 0; pc * 64 < HW; ++pc) {
+        const int p = pc * 64 + lane;
+        const bool valid = p < HW;
+        const int pcl = valid ? p : HW - 1;
+        const int ih = pcl / W, iw = pcl - ih * W;
+        int off[4], wl[4];
 #pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                const int oh = (ih >> 1) - a, lr = (ih & 1) + 2 * a;
-                if (oh < 0 || oh >= OH || lr > 2) continue;
+        for (int a = 0; a < 2; ++a) {
+            const int oh = (ih >> 1) - a, lr = (ih & 1) + 2 * a;
 #pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    const int ow = (iw >> 1) - b, lc = (iw & 1) + 2 * b;
-                    if (ow < 0 || ow >= OW || lc > 2) continue;
-                    const int o = cl * (OHW + 1) + oh * OW + ow;
-                    if ((int)sarg[o] == lr * 3 + lc) acc += sdy[o];
-                }
+            for (int b = 0; b < 2; ++b) {
+                const int ow = (iw >> 1) - b, lc = (iw & 1) + 2 * b;
+                const bool ok = oh >= 0 && oh < OH && lr <= 2 && ow >= 0 && ow < OW && lc <= 2;
+                off[a * 2 + b] = ok ? oh * OW + ow : OHW;              // entry OHW of a row: the pad, never a match
+                wl[a * 2 + b] = ok ? lr * 3 + lc : 254;
             }
         }
-        dx[plane * pp + (int64_t)(ih + halo) * wp + iw + halo] = acc;
+        const int64_t dxo = (int64_t)(ih + halo) * wp + iw + halo;
+        for (int cl = wave; cl < nch; cl += 4) {
+            const int64_t plane = (int64_t)img * C + c0 + cl;
+            const float mk = (mask && valid) ? mask[plane * HW + p] : 1.f;
+            const uint2* row = sp + cl * SP;
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint2 e = row[off[k]];
+                acc += ((int)e.y == wl[k]) ? __uint_as_float(e.x) : 0.f;
+            }
+            if (!(mk > 0.f)) acc = 0.f;
+            if (valid) dx[plane * pp + dxo] = acc;
+        }
     }
 }
 
@@ -968,10 +986,10 @@ extern "C" int vl_maxpool_bwd(const float* dy, const uint8_t* argmax, float* dx,
     const int64_t total = (int64_t)n * c * h * w;
     VL_CHECK(total < (1ll << 31), "vl_maxpool_bwd: tensor too large");
     if (k == 3 && s == 2 && ys_c == 1 && ys_w == c && ys_h == (int64_t)ow * c && ys_n == (int64_t)oh * ow * c && n <= 65535 &&
-        (size_t)64 * (oh * ow + 1) * 5 <= 48 * 1024) {
+        (size_t)64 * (oh * ow + 1) * 8 <= 48 * 1024 && !getenv("VL_MAXPOOL_GENERIC")) {
         // the (h, w, c)-flat pooled layout (pool5 -> fc6): LDS-transposed form
         constexpr int CB = 64;
-        const size_t lds = (size_t)CB * (oh * ow + 1) * 5;
+        const size_t lds = (size_t)CB * (oh * ow + 1) * 8;
         hipLaunchKernelGGL((maxpool_bwd_hwc_k3s2_kernel<CB>), dim3(ceil_div(c, CB), n), dim3(256), lds, (hipStream_t)stream, dy, argmax, dx,
                            relu_mask, c, h, w, oh, ow, dx_halo);
         VL_LAUNCH_CHECK();
