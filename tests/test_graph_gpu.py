@@ -80,6 +80,26 @@ def test_two_stream_full_geometry():
         assert err < (2.5e-2 if "/dcnn/conv" in k else 1e-3), "grad %s: relative L2 error %.3e" % (k, err)
 
 
+def test_two_stream_on_the_bf16_conv_path():
+    """The graph's towers on the packed-bf16 conv path (conv_math="bf16", BASELINE config 5's arithmetic; heads' large GEMMs follow the
+    mode): reduced precision by design -- logits within 5e-2 of the fp64 oracle, loss within 1e-2, and a finite step that moves both towers."""
+    from vltf_amd.graph import GraphEngine
+    case = GC.CASES["two_stream_avg"]()
+    pipes, ds = GC.specs_and_datasets(case)
+    eng = GraphEngine(pipes, ds, case["V"], device=DEV, conv_math="bf16")
+    p = eng.init_params(seed=case["seed"], well_scaled=True)
+    eng.load_params(p)
+    raw, feeds = GC.inputs(case)
+    logits, onehot, loss, grads, _ = GC.expect(case, p, feeds)
+    out = eng.train_step(device_feeds(raw), torch.from_numpy(onehot).to(DEV), lr=0.01, clip_norm=0.5)
+    assert np.abs(eng.logits_host() - logits).max() < 5e-2
+    assert abs(out["loss"] - loss) < 1e-2 * max(1, abs(loss)) and np.isfinite(out["grad_norm"])
+    g = eng.get_grads()
+    for k in ("rgb/dcnn/conv1W", "flow/dcnn/conv1W", "rgb/dcnn/fc6W", "fuse/output_fc_w"):
+        err = np.linalg.norm((g[k] - grads[k]).ravel()) / np.linalg.norm(grads[k].ravel())
+        assert err < 0.2, "grad %s: relative L2 %.3e" % (k, err)
+
+
 def test_tie_semantics_of_the_maximum_fusion():
     """vl_fuse_n / vl_fuse_n_grad / vl_max2_grad: inputs equal to the maximum share the gradient evenly (tf.reduce_max's
     _MinOrMaxGrad) -- two ReLU outputs that are both zero tie all the time."""
