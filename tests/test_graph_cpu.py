@@ -103,6 +103,8 @@ def test_exchange_chunks_cover_the_buffer_and_wait_for_the_last_lstm(monkeypatch
     ([("a", dict(input=["aux"], representation="fc", fc_output_dim=9, classifier="fc"))], "already exists"),
     ([("a", dict(input=["aux"], representation="nop", classifier="lstm", lstm_params=(4, 1, "avg"), frame_fusion=("early", "avg")))], "only with"),
     ([("a", dict(input=["aux", "main"], representation="nop", classifier="fc"))], "neither an input_fusion"),
+    ([("a", dict(input=["main"], representation="nop", classifier="fc"))], "cannot take the frame dataset"),
+    ([("a", dict(input=["aux", "main"], representation="nop", classifier="lstm", lstm_params=(4, 1, "avg")))], "holds frames"),
     ([("f", dict(input=["main"], representation="dcnn", frame_encoding_layer="fc6", classifier=None)),
       ("a", dict(input=["aux", "f"], input_fusion="concat", representation="nop", classifier="fc"))], "ratio"),
     ([("f", dict(input=["main"], representation="dcnn", frame_encoding_layer="fc6", classifier="fc", frame_fusion=("early", "avg"))),

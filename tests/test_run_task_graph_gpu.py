@@ -124,3 +124,71 @@ def test_encoder_decoder_validation_resizes_frames_like_training(tmp_path, monke
     want, _ = O.encdec_forward(params, x, np.concatenate(seqs), 3, TW, dict(layer="fc6", layers=1), dict(layers=1, fusion="reshape"), V)
     assert got.shape == want.shape
     np.testing.assert_allclose(got, want, rtol=1e-3, atol=1e-3)
+
+
+def _dp_worker(rank, world, port, cfg_path, val_cfg):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      VLTF_DIST_BACKEND="gloo", VLTF_CONV_MATH="f32")
+    from vltf_amd import run_task
+    run_task.main(cfg_path, seed=3, device="cuda:0")
+    run_task.main(val_cfg, device="cuda:0")
+
+
+def test_two_rank_two_stream_run_task_equals_one_rank(tmp_path, monkeypatch):
+    """The three-pipeline model data parallel through the workflow: two ranks (gloo, one GPU) each take their videos of every global
+    batch of BOTH datasets; 5 videos at a global batch of 4 -> the last batch has one video, so rank 1's shard of it is EMPTY
+    (GraphEngine.train_step_empty joins the exchange with zeros).  Rank 0's checkpoint and the sharded validation must equal the
+    one-process run's."""
+    import socket
+    import torch.multiprocessing as mp
+    monkeypatch.setenv("VLTF_CONV_MATH", "f32")
+    from vltf_amd import run_task
+    runs = {}
+    for tag in ("one", "two"):
+        folder = str(tmp_path / tag)
+        os.makedirs(folder)
+        rpath, _, _ = make_dataset(folder, "rgb.txt", nvid=5, cpv=CPV, shape=RAW, classes=V, seed=7)
+        fpath, _, _ = make_dataset(folder, "flow.txt", nvid=5, cpv=CPV, shape=RAW, classes=V, seed=8)
+        cfgs = []
+        for name, phase, resume in (("train.yml", "train", None), ("val.yml", "val", "latest")):
+            path = write_two_stream_cfg(folder, name, rpath, fpath, phase, resume)
+            with open(path) as f:
+                c = yaml.safe_load(f)
+            c["run"]["train"]["batch_size"] = 4
+            c["run"]["val"]["batch_size"] = 4
+            with open(path, "w") as f:
+                yaml.safe_dump(c, f)
+            cfgs.append(path)
+        runs[tag] = (folder, cfgs)
+    folder, (tcfg, vcfg) = runs["one"]
+    run_task.main(tcfg, seed=3)
+    acc1 = run_task.main(vcfg)
+    folder2, (tcfg2, vcfg2) = runs["two"]
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, tcfg2, vcfg2)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    for pr in procs:
+        pr.join(300)
+        assert pr.exitcode == 0, "rank exited with %s" % pr.exitcode
+
+    def weights(folder):
+        ck = sorted(glob.glob(os.path.join(folder, "run", "checkpoints", "*.weights.npz")), key=os.path.getmtime)
+        with np.load(ck[-1], allow_pickle=False) as z:
+            return {k: z[k] for k in z.files}
+    want, got = weights(folder), weights(folder2)
+    assert set(want) == set(got)
+    for k in want:
+        assert np.abs(got[k] - want[k]).max() < 2e-5 * (np.abs(want[k]).max() + 1e-12), k
+    t1 = glob.glob(os.path.join(folder, "run", "validation_logits_*.total"))
+    t2 = glob.glob(os.path.join(folder2, "run", "validation_logits_*.total"))
+    assert len(t1) == 1 and len(t2) == 1
+    with open(t1[0], "rb") as f1, open(t2[0], "rb") as f2:
+        l1, l2 = pickle.load(f1), pickle.load(f2)                     # files these runs wrote
+    assert l1.shape == l2.shape == (5, V)
+    np.testing.assert_allclose(l2, l1, rtol=1e-4, atol=1e-4)
+    assert float(open(glob.glob(os.path.join(folder2, "run", "accuracy_*"))[0]).read()) == acc1

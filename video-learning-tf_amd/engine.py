@@ -13,7 +13,7 @@ classifier -> fc -> conv5..conv1, i.e. the order backward produces gradients, so
 data-parallel all-reduce of the first (large: fc6 = 85 % of bytes) bucket overlaps the conv backward.
 """
 import math
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import Optional, Tuple
 
 import contextlib

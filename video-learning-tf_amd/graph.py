@@ -25,7 +25,7 @@ A pipeline the last one does not depend on is never evaluated by sess.run(logits
 
 The oracle of this class is oracle.lrcn_oracle.model_forward / model_backward (cross-checked against torch autograd)."""
 import math
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import List, Optional, Tuple
 
 import numpy as np
@@ -88,7 +88,6 @@ class PipeNode:
     def __init__(self, g, spec: PipelineSpec, srcs, index):
         self.g, self.spec, self.srcs, self.index = g, spec, srcs, index
         self.scope = spec.name + "/" if g.scoped else ""
-        self.consumers = 0
         s, C = spec, g.num_classes
         ftype, fmethod = s.frame_fusion if s.frame_fusion else (None, None)
         if ftype == "none":
@@ -149,6 +148,10 @@ class PipeNode:
                 self.x_dim, self.fpc, self.max_rows0 = a.dim, a.fpc + 1, a.max_rows // a.fpc * (a.fpc + 1)
         else:
             self.x_dim, self.fpc, self.max_rows0 = srcs[0].dim, srcs[0].fpc, srcs[0].max_rows
+        if s.representation != "dcnn" and any(x.kind == "video" for x in (srcs if self.fusion else srcs[:1])):
+            # a frame placeholder is rank 4: convert_dim_fc / the LSTM's reshape cannot take it (only DCNN.build can)
+            raise VltfError("pipeline [%s]: representation %s cannot take the frame dataset [%s] (representation dcnn does)" %
+                            (s.name, s.representation, [x.ref for x in srcs if x.kind == "video"][0]))
         if self.fusion is None and len(srcs) > 1:
             if s.classifier != "lstm":
                 raise VltfError("pipeline [%s] has %d inputs but neither an input_fusion nor an LSTM classifier that would take the "
@@ -156,6 +159,9 @@ class PipeNode:
             if len(srcs) != 2:
                 raise VltfError("pipeline [%s]: an LSTM takes one state input (tf_util.py:184: too many values to unpack)" % s.name)
             self.state_src = srcs[1]
+            if self.state_src.kind == "video":
+                raise VltfError("pipeline [%s]: the LSTM's state input must be vectors or a pipeline output, [%s] holds frames" %
+                                (s.name, self.state_src.ref))
             self.state_ratio = int(srcs[0].cpv / srcs[1].cpv)
             if self.state_ratio < 1 or srcs[1].max_rows * self.state_ratio * self.fpc != self.max_rows0:
                 raise VltfError("pipeline [%s]: the state input has %d rows per batch, the sequence %d clips at clips-per-video ratio "
@@ -170,7 +176,6 @@ class PipeNode:
         self.feat_dim = dim
         # ---- stage 2: early fusion ---------------------------------------------------------------------------------------------------
         self.early = ftype == "early" and self.fpc > 1 and fmethod != "reshape"      # `reshape` of [B, T, d] back to [B*T, d]: identity
-        self.early_keeps_fpc = ftype == "early" and self.fpc > 1 and fmethod == "reshape"
         self.fmethod = fmethod
         out_fpc = 1 if (ftype == "early" and self.fpc > 1) else self.fpc              # model.py:103-106
         rows = self.max_rows0 // self.fpc if self.early else self.max_rows0
@@ -669,7 +674,6 @@ class GraphEngine:
             for src in spec.input:
                 if src in self.by_name:
                     nd = self.by_name[src]
-                    nd.consumers += 1
                     srcs.append(_Src("pipe", nd, nd.out_dim, nd.cpv_out, nd.fpc_out, nd.max_rows))
                 elif src in by_name:
                     raise VltfError("Input identifier [%s] of pipeline [%s] is a pipeline that has not been declared yet." % (src, spec.name))
