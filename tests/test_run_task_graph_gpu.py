@@ -173,8 +173,12 @@ def test_two_rank_two_stream_run_task_equals_one_rank(tmp_path, monkeypatch):
     for pr in procs:
         pr.start()
     for pr in procs:
-        pr.join(300)
-        assert pr.exitcode == 0, "rank exited with %s" % pr.exitcode
+        pr.join(240)
+    codes = [pr.exitcode for pr in procs]
+    for pr in procs:
+        if pr.is_alive():                         # a rank whose peer died waits in the rendezvous: do not leave it behind
+            pr.terminate()
+    assert codes == [0, 0], "ranks exited with %s" % codes
 
     def weights(folder):
         ck = sorted(glob.glob(os.path.join(folder, "run", "checkpoints", "*.weights.npz")), key=os.path.getmtime)
@@ -183,7 +187,8 @@ def test_two_rank_two_stream_run_task_equals_one_rank(tmp_path, monkeypatch):
     want, got = weights(folder), weights(folder2)
     assert set(want) == set(got)
     for k in want:
-        assert np.abs(got[k] - want[k]).max() < 2e-5 * (np.abs(want[k]).max() + 1e-12), k
+        # (the LSTM bias starts at 0 and moves by ~1e-6 under these saturated gates: an absolute floor for summation-order noise)
+        assert np.abs(got[k] - want[k]).max() < 2e-5 * np.abs(want[k]).max() + 1e-9, k
     t1 = glob.glob(os.path.join(folder, "run", "validation_logits_*.total"))
     t2 = glob.glob(os.path.join(folder2, "run", "validation_logits_*.total"))
     assert len(t1) == 1 and len(t2) == 1

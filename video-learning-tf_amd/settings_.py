@@ -104,8 +104,7 @@ class Settings:
         trainval = ("train" if defs.phase.train in self.phases else "") + ("val" if defs.phase.val in self.phases else "")
         trainval += "_resume" if self.should_resume() else "_scratch"
         self.run_id = "_".join([self.run_id or os.path.basename(init_file), trainval])
-        if not os.path.exists(self.run_folder):
-            os.makedirs(self.run_folder)
+        os.makedirs(self.run_folder, exist_ok=True)       # (every rank of a data-parallel launch gets here at the same moment)
         lg = config["logging"]
         self.save_freq_per_epoch = lg["save_freq_per_epoch"]
         self.logging_level = lg["level"]
