@@ -49,8 +49,12 @@ def write_two_stream_cfg(folder, name, rgb_path, flow_path, phase, resume=None):
     return path
 
 
-def test_two_stream_train_and_validate(tmp_path, monkeypatch):
+@pytest.mark.parametrize("prefetch", ["2", "0"])
+def test_two_stream_train_and_validate(tmp_path, monkeypatch, prefetch):
+    """prefetch 2 (the default): BOTH frame datasets are read and uploaded ahead of the loop, each by its own BatchPrefetcher;
+    prefetch 0: the reference's synchronous feed.  Same checkpoints, logs and validation results."""
     monkeypatch.setenv("VLTF_CONV_MATH", "f32")
+    monkeypatch.setenv("VLTF_PREFETCH", prefetch)
     from vltf_amd import run_task
     folder = str(tmp_path)
     rpath, rgb, labels = make_dataset(folder, "rgb.txt", nvid=5, cpv=CPV, shape=RAW, classes=V, seed=7)

@@ -103,7 +103,8 @@ class Feeder:
         self.save_freq_per_epoch = save_freq_per_epoch
         self.save_interval, self.num_saves = -1, 0
         self.saved = []
-        self.prefetch = None
+        self.prefetch = None          # the read-ahead of the MAIN dataset (None: synchronous feed)
+        self.prefetchers = {}         # tag -> BatchPrefetcher: every frame dataset a multi-pipeline model reads
 
     def add_dataset(self, dataset_phase, id, path, mean_image, prepend_folder, image_shape, imgproc, raw_image_shape, data_format,
                     frame_format, batch_item, num_classes, tag, read_tries, captioning_config=None):
@@ -126,9 +127,13 @@ class Feeder:
                 bs = self.train.batch_size if (defs.phase.train in self.phases and self.train) else self.val.batch_size
                 dset.calculate_batches(bs, self.input_mode)
 
+    def _any_prefetch(self):
+        return next(iter(self.prefetchers.values())) if self.prefetchers else None
+
     def loop(self):
-        if self.prefetch is not None:
-            return self.prefetch.consumed < self.get_num_batches()
+        pf = self._any_prefetch()
+        if pf is not None:            # a dataset that is read ahead is past the batch the loop is at: count what was handed out
+            return pf.consumed < self.get_num_batches()
         return self.datasets[self.phase][0].loop()
 
     def get_dataset_by_tag(self, tag):
@@ -141,27 +146,32 @@ class Feeder:
         return len(self.datasets[self.phase][0].batches) if self.datasets else -1
 
     def get_batch_index(self):
-        if self.prefetch is not None:
-            return self.prefetch.consumed       # batches handed to the training loop, not batches read ahead
+        pf = self._any_prefetch()
+        if pf is not None:
+            return pf.consumed                  # batches handed to the training loop, not batches read ahead
         return self.datasets[self.phase][0].batch_index
 
     def get_batch_sizes(self):
         return [d.batch_size for d in self.datasets[self.phase]]
 
     def rewind_datasets(self):
-        if self.prefetch is not None:
-            self.prefetch.stop()
+        for pf in self.prefetchers.values():
+            pf.stop()
         for d in self.datasets[self.phase]:
             d.rewind()
-        if self.prefetch is not None:
-            self.prefetch.consumed = 0
+        for pf in self.prefetchers.values():
+            pf.consumed = 0
 
     def enable_prefetch(self, device, depth=2, tag=defs.dataset_tag.main):
         """Read ahead of the training loop (BatchPrefetcher).  get_feed_dict / loop / get_batch_index keep their meaning."""
         dsets = self.get_dataset_by_tag(tag)
         if len(dsets) != 1:
             error("%d datasets satisfy the network input requirement [%s], but exactly one must." % (len(dsets), tag))
-        self.prefetch = BatchPrefetcher(dsets[0], device, depth)
+        if dsets[0].input_mode == defs.input_mode.vectors:
+            return                                  # a few KB per batch: read synchronously
+        self.prefetchers[tag] = BatchPrefetcher(dsets[0], device, depth)
+        if tag == defs.dataset_tag.main:
+            self.prefetch = self.prefetchers[tag]
 
     def get_feed_dict(self, tag=defs.dataset_tag.main):
         """feeder.py:84-106: -> (fdict, num_data, num_labels, padding).  fdict holds the raw uint8 frames and the
@@ -170,8 +180,8 @@ class Feeder:
         if len(dsets) != 1:
             error("%d datasets satisfy the network input requirement [%s], but exactly one must." % (len(dsets), tag))
         d = dsets[0]
-        if self.prefetch is not None:
-            fdict = self.prefetch.next()
+        if tag in self.prefetchers:
+            fdict = self.prefetchers[tag].next()
             return fdict, [len(fdict["frames_u8"])], len(fdict["labels"]), 0
         frames, cy, cx, mirror, onehot = d.get_next_batch()
         if d.input_mode == defs.input_mode.vectors:            # float32 vectors instead of frames; per-record targets beside the per-clip ones

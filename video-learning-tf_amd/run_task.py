@@ -33,6 +33,11 @@ def graph_feeds(fdicts, tags, dev):
         fd = fdicts[tag]
         if "vectors" in fd:
             feeds[tag] = torch.from_numpy(fd["vectors"]).to(dev)
+        elif "device" in fd:             # read and uploaded ahead by the feeder's BatchPrefetcher: wait for the copy on the stream
+            torch.cuda.current_stream(dev).wait_event(fd["ready"])
+            t = fd["device"]
+            feeds[tag] = dict(frames_u8=t["frames_u8"], mean_bgr=fd["mean_bgr"], crop_y=t["crop_y"], crop_x=t["crop_x"], mirror=t["mirror"],
+                              resize=fd.get("resize"))
         else:
             feeds[tag] = dict(frames_u8=torch.from_numpy(fd["frames_u8"]).to(dev, non_blocking=True), mean_bgr=fd["mean_bgr"],
                               crop_y=torch.from_numpy(fd["crop_y"]).to(dev), crop_x=torch.from_numpy(fd["crop_x"]).to(dev),
@@ -303,8 +308,9 @@ def main(init_file, seed=0, device=None):
             params.update({k: v for k, v in loaded.items() if k in params and not k.startswith(scope + "dcnn/fc8")})
     engine.load_params(params)
     feeder.init_saveload(engine, settings.resume_file)
-    if os.environ.get("VLTF_PREFETCH", "2") != "0" and single:      # batches read + uploaded ahead of the loop (0 = the reference's synchronous feed)
-        feeder.enable_prefetch(engine.dev, depth=int(os.environ.get("VLTF_PREFETCH", "2")))
+    if os.environ.get("VLTF_PREFETCH", "2") != "0":      # batches read + uploaded ahead of the loop (0 = the reference's synchronous feed)
+        for tag in ([defs.dataset_tag.main] if single else settings.graph_tags):       # every frame dataset the model reads
+            feeder.enable_prefetch(engine.dev, depth=int(os.environ.get("VLTF_PREFETCH", "2")), tag=tag)
     if gar is not None:
         gar.broadcast_params(engine.w)
     result = None
