@@ -106,7 +106,13 @@ extern "C" int vl_pack_c8(const float* x, void* xb, int n, int c, int h, int w, 
 }
 
 // ---- reduction taps and packed weights -------------------------------------------------------------------------------------
-static constexpr int KT = 4;   // taps (32 reduction positions = two MFMA steps) per pipeline stage of conv_c8_kernel
+#ifndef C8_KT
+#define C8_KT 4
+#endif
+static constexpr int KT = C8_KT;   // taps (8 reduction positions each; 4 taps = two MFMA steps) per pipeline stage of conv_c8_kernel
+// (round 3: -DC8_KT=8 -DC8_NBUF=2 with 128-pixel tiles -- 16 MFMAs per wave between barriers, two workgroups per CU at 64 KB -- was
+// measured: the conv stack of the benchmark step 5.24 ms against 4.60 with 4-tap stages, three of them in the ring, 256-pixel tiles;
+// the barrier count is not what holds these kernels back, the fetch depth and the tile's operand reuse are)
 #ifndef C8_NBUF
 #define C8_NBUF 0     // 0: by tile (C8Cfg)
 #endif
