@@ -239,3 +239,41 @@ def test_weights_file_dict_npy_is_read_without_running_code(tmp_path):
     npz = str(tmp_path / "w.npz")
     np.savez(npz, **{"dcnn/conv1W": net["conv1"][0]})
     assert np.array_equal(load_weights_file(npz)["dcnn/conv1W"], net["conv1"][0])
+
+
+def test_graph_config_from_yaml(tmp_path):
+    """run_task.graph_config: a three-pipeline `network:` block (two dcnn feature pipelines on main / aux fused into an LSTM) ->
+    PipelineSpec list + DatasetInfo per tag, exactly what Model.__init__ walks (model.py:157-162); `input_shape` that contradicts
+    the dataset is refused (model.py:47-54).  Host logic only: no engine is built."""
+    from vltf_amd import run_task
+    folder = str(tmp_path)
+    p1, _, _ = make_dataset(folder, "rgb.txt", cpv=(1, 2, 1, 1, 2))
+    p2, _, _ = make_dataset(folder, "flow.txt", cpv=(1, 2, 1, 1, 2), seed=1)
+    path = config(folder, p1)
+    with open(path) as f:
+        cfg = yaml.safe_load(f)
+    d1 = cfg["run"]["data"]["d1"]
+    cfg["run"]["data"]["d2"] = dict(d1, data_path=p2, tag="defs.dataset_tag.aux")
+    cfg["run"]["network"]["pipelines"] = [
+        {"rgb": {"input": "defs.dataset_tag.main", "representation": "defs.representation.dcnn", "frame_encoding_layer": "fc6"}},
+        {"flow": {"input": "defs.dataset_tag.aux", "representation": "defs.representation.dcnn", "frame_encoding_layer": "fc7",
+                  "input_shape": "(16, 16, 3)"}},
+        {"fuse": {"input": ["rgb", "flow"], "input_fusion": "defs.fusion_method.maximum", "representation": "defs.representation.nop",
+                  "classifier": "defs.classifier.lstm", "lstm_params": [8, 2, "defs.fusion_method.last"]}}]
+    with open(path, "w") as f:
+        yaml.safe_dump(cfg, f)
+    s = settings_.Settings()
+    feeder = s.initialize(path)
+    specs, infos, by_tag = run_task.graph_config(s, feeder, batch=2)
+    assert [sp.name for sp in specs] == ["rgb", "flow", "fuse"] and specs[2].input == ["rgb", "flow"]
+    assert specs[0].classifier is None and specs[1].frame_encoding_layer == "fc7" and specs[2].input_fusion == "maximum"
+    assert specs[2].lstm_params == (8, 2, "last") and specs[2].representation == "nop"
+    assert set(infos) == {"main", "aux"} and infos["main"].mode == "video" and infos["main"].fpc == 3 and infos["main"].cpv == 1
+    assert infos["aux"].max_clips == 2 * 2 and tuple(infos["aux"].image_shape) == (16, 16, 3) and set(by_tag) == {"main", "aux"}
+    cfg["run"]["network"]["pipelines"][1]["flow"]["input_shape"] = "(20, 24, 3)"
+    with open(path, "w") as f:
+        yaml.safe_dump(cfg, f)
+    s2 = settings_.Settings()
+    feeder2 = s2.initialize(path)
+    with pytest.raises(Exception, match="input_shape"):
+        run_task.graph_config(s2, feeder2, batch=2)

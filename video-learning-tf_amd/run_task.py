@@ -12,6 +12,7 @@ import torch
 from . import dp as dpmod
 from .defs_ import defs
 from .engine import LRCNEngine, NetConfig, init_params
+from .parse_opts import parse_seq
 from .settings_ import Settings
 from .train import Train
 from .utils_ import elapsed_str, error, info, warning
@@ -93,6 +94,17 @@ def graph_config(settings, feeder, batch):
         else:
             infos[tag] = DatasetInfo("video", d.num_frames_per_clip, cpv[0], batch * max(cpv), image_shape=tuple(d.get_image_shape()))
         dsets[tag] = d
+    # `input_shape` (model.py:47-54): the placeholder's shape, when given, "has to be the same as the image shape in the dataset
+    # configuration" -- a different one would be fed frames it cannot hold
+    for sp in specs:
+        shapes = getattr(settings.pipelines[sp.name], "input_shape", None) or []
+        for src, shp in zip(sp.input, shapes):
+            if shp in (None, "None") or src not in dsets:
+                continue
+            want = tuple(parse_seq(shp)) if isinstance(shp, str) else tuple(shp)
+            have = tuple(dsets[src].get_image_shape()) if infos[src].mode == "video" else (infos[src].dim,)
+            if tuple(int(v) for v in want) != have:
+                error("Pipeline [%s]: input_shape %s of input [%s] differs from the dataset's %s" % (sp.name, want, src, have))
     n_items = {d.num_items for d in dsets.values()}
     if len(n_items) > 1:
         error("The datasets of the pipelines do not pair up item by item (%s items)." % sorted(n_items))
