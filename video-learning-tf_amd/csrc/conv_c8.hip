@@ -202,6 +202,7 @@ struct C8ConvArgs {
     const char* maskb;      // bf16 c8 ReluGrad mask (the producing layer's packed output), or null
     int mb_halo, mb_row;
     int64_t mb_plane;
+    int sched;              // 1: the second half of the waves issues its stage fetches after its first MFMA group (stagger)
 };
 
 template <int WP, int WQ, int TP, int TQ>
@@ -297,6 +298,13 @@ __global__ __launch_bounds__(64 * WP * WQ, (C8Cfg<WP, WQ, TP, TQ>::WPS)) void co
             for (int q = 0; q < 16; ++q) acc[j][i][q] = 0.f;
 
     for (int st = 0; st < NBUF - 1 && st < nstages; ++st) issue(st);
+    // Stagger (MI355X guide, "two waves per SIMD", item 9): all waves run the same program with one barrier per stage, so they reach
+    // their fetch issue (3 LDS-DMA pieces, ~100 cycles each inside such a phase), their LDS read burst and their MFMAs together.  The
+    // second-dispatched half (the SIMD partners of waves 0 .. NW/2 - 1) issues its fetches after its first MFMA group instead: the
+    // partners' MFMAs run beside them.  Measured (tools/c8_probe.py, 1024 frames): conv2 fwd 0.529 -> 0.503 ms, conv3 fwd 0.279 ->
+    // 0.273, conv3 dgrad 0.297 -> 0.284; the 4-wave tiles (conv4) unchanged.  A static s_setprio 1 for that half on top was mixed
+    // (conv2 fwd 0.497 but conv4 +3..9 %) and is not used.  VL_C8_SCHED=0 runs the lockstep order (A/B).
+    const bool late = a.sched != 0 && wave >= NW / 2;       // (uniform)
     const uint32_t rd_p = (uint32_t)((lane >> 5) * P * 16 + (wp * TP * 32 + (lane & 31)) * 16);
     const uint32_t rd_w = (uint32_t)(C::PIX_BYTES + (lane >> 5) * QF * 16 + (wq * TQ * 32 + (lane & 31)) * 16);
     for (int st = 0; st < nstages; ++st) {
@@ -309,10 +317,11 @@ __global__ __launch_bounds__(64 * WP * WQ, (C8Cfg<WP, WQ, TP, TQ>::WPS)) void co
         else
             wait_vm<0>();
         __syncthreads();   // every wave's pieces of stage st are in LDS; every wave is done reading stage st - 1
-        if (st + NBUF - 1 < nstages) issue(st + NBUF - 1);
+        if (!late && st + NBUF - 1 < nstages) issue(st + NBUF - 1);
         const char* slot = lds + (st % NBUF) * SLOT;
 #pragma unroll
         for (int kk = 0; kk < KT / 2; ++kk) {
+            if (kk == 1 && late && st + NBUF - 1 < nstages) issue(st + NBUF - 1);
             i32x4 bp[TP], aq[TQ];
 #pragma unroll
             for (int i = 0; i < TP; ++i) bp[i] = *reinterpret_cast<const i32x4*>(slot + rd_p + kk * 2 * P * 16 + i * 512);
@@ -512,6 +521,8 @@ static int launch_c8(const C8ConvArgs& a, int groups, hipStream_t stream) {
 
 // channel tile by the group's channel count: 128-wide tiles, 192 as one tile of 192 (conv4 / conv5 dgrad), 64 for narrow groups
 static int dispatch_c8(C8ConvArgs& a, int groups, hipStream_t stream) {
+    static const int sched = getenv("VL_C8_SCHED") ? atoi(getenv("VL_C8_SCHED")) : 1;      // 0: lockstep fetch issue (A/B)
+    a.sched = sched;
     if (a.Cog <= 64) return launch_c8<4, 1, 2, 2>(a, groups, stream);          // 256 pixels x 64 channels, 4 waves
     if (a.Cog <= 96) return launch_c8<4, 1, 2, 3>(a, groups, stream);          // 256 x 96 (conv1 as a 3x3 conv over 48 channels)
     // 192-channel groups (conv4 forward, conv4 / conv5 dgrad): two 96-wide tiles of 4 waves, two workgroups per CU (72 KB each), rather
