@@ -304,7 +304,7 @@ __global__ __launch_bounds__(64 * WP * WQ, (C8Cfg<WP, WQ, TP, TQ>::WPS)) void co
     // partners' MFMAs run beside them.  Measured (tools/c8_probe.py, 1024 frames): conv2 fwd 0.529 -> 0.503 ms, conv3 fwd 0.279 ->
     // 0.273, conv3 dgrad 0.297 -> 0.284; the 4-wave tiles (conv4) unchanged.  A static s_setprio 1 for that half on top was mixed
     // (conv2 fwd 0.497 but conv4 +3..9 %) and is not used.  VL_C8_SCHED=0 runs the lockstep order (A/B).
-    const bool late = a.sched != 0 && wave >= NW / 2;       // (uniform)
+    const bool late = NW >= 8 && a.sched != 0 && wave >= NW / 2;       // (uniform; 4-wave tiles: no effect measured, not applied)
     const uint32_t rd_p = (uint32_t)((lane >> 5) * P * 16 + (wp * TP * 32 + (lane & 31)) * 16);
     const uint32_t rd_w = (uint32_t)(C::PIX_BYTES + (lane >> 5) * QF * 16 + (wq * TQ * 32 + (lane & 31)) * 16);
     for (int st = 0; st < nstages; ++st) {
@@ -653,6 +653,7 @@ struct C8WgradArgs {
     float* ws;            // [slab][group][rowsP][CoP]
     int rowsP, CoP;       // rows (taps * 8) / columns of a slab image, padded to the tiling
     FastDiv dL;
+    int sched;            // 1: the second half of the waves issues its stage fetches after its first MFMA group (conv_c8_kernel's stagger)
 };
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -788,6 +789,9 @@ __global__ __launch_bounds__(64 * WA * WB) void wgrad_c8_kernel(const C8WgradArg
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
     for (int st = 0; st < NBUF - 1 && st < nstages; ++st) issue(st);
+    // stagger, see conv_c8_kernel; workgroups of 8 / 12 waves only (conv4 wgrad 0.336 -> 0.299 ms, conv3 0.319 -> 0.307, conv2 0.506 ->
+    // 0.484 in the benchmark step; the 4-wave tile of conv1 ran 8 % SLOWER staggered: its SIMDs hold one wave of the workgroup each)
+    const bool late = NW >= 8 && a.sched != 0 && wave >= NW / 2;       // (uniform)
     // transposed operand reads: 16-lane group g16 -> (columns 16 (g16 & 1) .. + 15 of the 32-wide block, positions 8 (g16 >> 1) .. + 7);
     // lane 4 q + p of the group addresses row q, columns 4 p .. 4 p + 3 = chunk 2 (g16 & 1) + (p >> 1), byte 8 (p & 1)
     const int g16 = lane >> 4, rq = (lane & 15) >> 2, rp = lane & 3;
@@ -812,7 +816,7 @@ __global__ __launch_bounds__(64 * WA * WB) void wgrad_c8_kernel(const C8WgradArg
         else
             wait_vm<0>();
         __syncthreads();
-        if (st + NBUF - 1 < nstages) issue(st + NBUF - 1);
+        if (!late && st + NBUF - 1 < nstages) issue(st + NBUF - 1);
         const uint32_t so = lds0 + (uint32_t)(st % NBUF) * SLOT;
         lds_ptr pa[2], pb[TB];
         // one vector add per operand block and stage; the asm pins the sum in a register so that every read below is base + immediate
@@ -830,6 +834,9 @@ __global__ __launch_bounds__(64 * WA * WB) void wgrad_c8_kernel(const C8WgradArg
         }
         static_for<0, KP / 16>([&](auto kc) {
             constexpr int kk = decltype(kc)::value;
+            if constexpr (kk == 1) {
+                if (late && st + NBUF - 1 < nstages) issue(st + NBUF - 1);
+            }
             i32x4 av[2], bv[TB];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -922,6 +929,11 @@ extern "C" size_t vl_conv_c8_wgrad_ws_bytes(const vl_conv_desc* d, int n) {
     return (size_t)p.slabs * d->groups * p.rowsP * p.CoP * sizeof(float);
 }
 
+static int c8_wgrad_sched() {
+    static const int v = getenv("VL_C8_WG_SCHED") ? atoi(getenv("VL_C8_WG_SCHED")) : 1;      // 0: lockstep fetch issue (A/B)
+    return v;
+}
+
 template <int WA, int WB, int TB>
 static int launch_c8_wgrad(const C8WgradArgs& a, const C8WgPlan& p, int groups, hipStream_t stream) {
     using C = C8WgCfg<WA, WB, TB>;
@@ -951,6 +963,7 @@ extern "C" int vl_conv_c8_wgrad(vl_conv_desc* d, const void* xb, const void* dyb
     const int Hp = d->h + 2 * d->x_halo, Wp = d->w + 2 * d->x_halo;
     C8WgradArgs a;
     memset(&a, 0, sizeof(a));
+    a.sched = c8_wgrad_sched();
     a.x = (const char*)xb;
     a.dy = (const char*)dyb;
     a.dy_plane = (int64_t)Hp * Wp * 16;
@@ -1313,6 +1326,7 @@ extern "C" int vl_gemm_kc8(const void* a_kc8, const void* b_kc8, float* c, int m
     const bool direct = p.slabs == 1 && !bias && !relu && m % 256 == 0 && n % 128 == 0;   // one slab, nothing to add: straight into c
     C8WgradArgs a;
     memset(&a, 0, sizeof(a));
+    a.sched = c8_wgrad_sched();
     a.x = (const char*)a_kc8;
     a.dy = (const char*)b_kc8;
     a.dy_plane = (int64_t)k * 16;
