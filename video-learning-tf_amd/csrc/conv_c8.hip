@@ -303,7 +303,8 @@ __global__ __launch_bounds__(64 * WP * WQ, (C8Cfg<WP, WQ, TP, TQ>::WPS)) void co
     // second-dispatched half (the SIMD partners of waves 0 .. NW/2 - 1) issues its fetches after its first MFMA group instead: the
     // partners' MFMAs run beside them.  Measured (tools/c8_probe.py, 1024 frames): conv2 fwd 0.529 -> 0.503 ms, conv3 fwd 0.279 ->
     // 0.273, conv3 dgrad 0.297 -> 0.284; the 4-wave tiles (conv4) unchanged.  A static s_setprio 1 for that half on top was mixed
-    // (conv2 fwd 0.497 but conv4 +3..9 %) and is not used.  VL_C8_SCHED=0 runs the lockstep order (A/B).
+    // (conv2 fwd 0.497 but conv4 +3..9 %) and is not used; the FIRST half issuing at the end of its stage instead of its start: no
+    // difference.  VL_C8_SCHED=0 runs the lockstep order (A/B).
     const bool late = NW >= 8 && a.sched != 0 && wave >= NW / 2;       // (uniform; 4-wave tiles: no effect measured, not applied)
     const uint32_t rd_p = (uint32_t)((lane >> 5) * P * 16 + (wp * TP * 32 + (lane & 31)) * 16);
     const uint32_t rd_w = (uint32_t)(C::PIX_BYTES + (lane >> 5) * QF * 16 + (wq * TQ * 32 + (lane & 31)) * 16);
