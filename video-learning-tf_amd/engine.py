@@ -288,7 +288,8 @@ class LRCNEngine:
             self.k_w = kb(F * FC_DIM)                      # fc6W, reduction-major for the forward, then for the input gradient
             if training:
                 self.k_p5, self.k_d6 = kb(N * F), kb(N * FC_DIM)
-            for (gm, gn, gk) in ((N, FC_DIM, F), (N, F, FC_DIM), (F, FC_DIM, N)):
+            H4_, D_ = 4 * cfg.lstm_hidden, cfg.encode_dim()
+            for (gm, gn, gk) in ((N, FC_DIM, F), (N, F, FC_DIM), (F, FC_DIM, N), (N, H4_, D_), (D_, H4_, N), (N, D_, H4_)):
                 ws_bytes = max(ws_bytes, ops.gemm_kc8_ws_bytes(gm, gn, gk))
         self.f6 = buf(N, FC_DIM)
         self.f7 = buf(N, FC_DIM) if cfg.frame_encoding_layer != "fc6" else None
@@ -489,6 +490,14 @@ class LRCNEngine:
         """fc6 runs on the packed-operand product kernel: bf16 path, whole 8-frame blocks."""
         return self.c8 and hasattr(self, "k_w") and n % 8 == 0
 
+    def _lstm_kc8(self, n, l):
+        """The first LSTM layer's three whole-sequence products (input projection, kernel gradient, input gradient) run on the
+        packed-operand kernel too (bf16 path): the same arithmetic as the split-product GEMM in mode 1 -- operands rounded to bf16, fp32
+        accumulation -- without its operand images.  They reuse fc6's operand buffers (the launches are serial on one stream)."""
+        D, H4 = self.cfg.encode_dim(), 4 * self.cfg.lstm_hidden
+        return (l == 0 and self._fc6_kc8(n) and os.environ.get("VLTF_LSTM_KC8", "1") != "0" and D % 8 == 0 and H4 % 8 == 0
+                and D * H4 <= self.k_w.numel() and n * max(D, H4) <= self.k_act.numel() and (not self.training or n * H4 <= self.k_d6.numel()))
+
     # ---- forward -------------------------------------------------------------------------------
     def _forward(self, n, b, train):
         P, cfg = self.P, self.cfg
@@ -546,7 +555,14 @@ class LRCNEngine:
                 pre = "rnn/multi_rnn_cell/cell_%d/basic_lstm_cell/" % l
                 K = P[pre + "kernel"]
                 # hoisted input projection for all (clip, t) rows, then the serial recurrence
-                ops.gemm(xin, K, S["gx"], n, 4 * H, d, bias=P[pre + "bias"], ws=self.ws)
+                if self._lstm_kc8(n, l):
+                    a = self.k_act[:n * d].view(ops.kc8_shape(d, n))
+                    w = self.k_w[:d * 4 * H].view(ops.kc8_shape(d, 4 * H))
+                    ops.pack_kc8(xin, a, d, n, 1, d)                                  # (position j, channel frame) = x[frame][j]
+                    ops.pack_kc8(K, w, d, 4 * H, 4 * H, 1)                            # (position j, channel column) = K[j][column]
+                    ops.gemm_kc8(a, w, S["gx"], n, 4 * H, d, bias=P[pre + "bias"], ws=self.ws)
+                else:
+                    ops.gemm(xin, K, S["gx"], n, 4 * H, d, bias=P[pre + "bias"], ws=self.ws)
                 if H <= 1024:
                     ops.lstm_seq_fwd(S["gx"], K[d:], S["act"], S["cseq"], S["hseq"], S["hprev"], b, T, H, FORGET_BIAS, ws=self.lstm_ws)
                 else:
@@ -634,10 +650,26 @@ class LRCNEngine:
                         ops.lstm_step_bwd(S["dout"], self.dh if t < T - 1 else None, S["act"], S["cseq"], self.dc, S["dz"], b, T, t, H)
                         if t > 0:
                             ops.gemm(S["dz"][t:], K[din:], self.dh, b, H, 4 * H, transb=True, lda=T * 4 * H)
-                ops.gemm(xin, S["dz"], G[pre + "kernel"], din, 4 * H, n, transa=True, ws=self.ws)
+                lk = self._lstm_kc8(n, l)
+                if lk:
+                    a = self.k_act[:n * din].view(ops.kc8_shape(n, din))
+                    zb = self.k_d6[:n * 4 * H].view(ops.kc8_shape(n, 4 * H))
+                    ops.pack_kc8(xin, a, n, din, din, 1)                              # (position frame, channel j)
+                    ops.pack_kc8(S["dz"], zb, n, 4 * H, 4 * H, 1)                     # (position frame, channel column)
+                    ops.gemm_kc8(a, zb, G[pre + "kernel"], din, 4 * H, n, ws=self.ws)
+                else:
+                    ops.gemm(xin, S["dz"], G[pre + "kernel"], din, 4 * H, n, transa=True, ws=self.ws)
                 ops.gemm(S["hprev"], S["dz"], G[pre + "kernel"][din:], H, 4 * H, n, transa=True, ws=self.ws)
                 ops.colsum(S["dz"], G[pre + "bias"], sw, n, 4 * H)
-                if l == 0:
+                if l == 0 and lk:
+                    a = self.k_act[:n * 4 * H].view(ops.kc8_shape(4 * H, n))
+                    w = self.k_w[:D * 4 * H].view(ops.kc8_shape(4 * H, D))
+                    ops.pack_kc8(S["dz"], a, 4 * H, n, 1, 4 * H)                      # (position column, channel frame) = dz[frame][column]
+                    ops.pack_kc8(K, w, 4 * H, D, 1, 4 * H)                            # (position column, channel j) = K[j][column]
+                    ops.gemm_kc8(a, w, self.dfeat, n, D, 4 * H, ws=self.ws)
+                    if self.f8 is None:
+                        ops.relu_grad(self.dfeat, self.feat, n * D)                   # ReluGrad of fc6 / fc7
+                elif l == 0:
                     relu_mask = self.feat if self.f8 is None else None       # ReluGrad of fc6 / fc7 fused here
                     ops.gemm(S["dz"], K, self.dfeat, n, D, 4 * H, transb=True, ldb=4 * H, relu_mask=relu_mask, ws=self.ws)
                 else:
