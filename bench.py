@@ -238,6 +238,26 @@ def main():
     eng_chunks = list(eng.grad_chunks)
     elapsed, times, out = timed(eng, frames, onehot, clips, total_clips, probe=True)
     overlapped = clips > 0 and eng._side_stream() is not None      # the backward ran its independent launches on two streams
+    serial_times = None
+    if overlapped and world == 1:
+        # per-launch times of the conv stack need launches that run alone: the same steps once more with the second stream off
+        # (after the timed region, not part of `value`)
+        keep = os.environ.get("VLTF_WGRAD_STREAM")
+        os.environ["VLTF_WGRAD_STREAM"] = "0"
+        try:
+            for _ in range(2):
+                eng.train_step_u8(frames, onehot, lr=1e-3, clip_norm=10.0, mean_bgr=MEAN_BGR, fetch=False)
+            eng.set_probe([l + p for l in CONV_MACS for p in (".fwd", ".dgrad", ".wgrad")])
+            for _ in range(args.steps):
+                eng.train_step_u8(frames, onehot, lr=1e-3, clip_norm=10.0, mean_bgr=MEAN_BGR, fetch=False)
+            torch.cuda.synchronize()
+            serial_times = eng.probe_times_ms()
+            eng.set_probe(None)
+        finally:
+            if keep is None:
+                del os.environ["VLTF_WGRAD_STREAM"]
+            else:
+                os.environ["VLTF_WGRAD_STREAM"] = keep
     # forward only (sess.run(model.logits), run_task.py:95; SURVEY 8d asks for it beside the train step): per rank, untimed for `value`
     fwd_ms = None
     if clips > 0:
@@ -321,13 +341,19 @@ def main():
     for label, ms in times:
         per.setdefault(label, []).append(ms)
     avg = {k: sum(v) / len(v) for k, v in per.items()}
-    # Small shards run the backward's independent launches on two streams (engine._side_stream): a bracket around a backward launch
-    # then times it TOGETHER with its neighbour, so the dominant symbol is measured on its forward launches only and the conv-stack
-    # sum is flagged as overlapped
+    # Small shards run the backward's independent launches on two streams (engine._side_stream): a bracket around a launch that has a
+    # neighbour times both.  The dominant symbol is then measured live, in the timed region, on the launches that run alone there (the
+    # forward ones); the conv-stack table comes from the serial pass above.
     dominant = tuple(l for l in DOMINANT if not overlapped or l.endswith(".fwd"))
     dom_flop = sum(2.0 * CONV_MACS[l.split(".")[0]] * n for l in dominant) / len(dominant)      # per launch
     dom_ms = sum(avg[l] for l in dominant) / len(dominant)                                       # per launch
     achieved = dom_flop / (dom_ms * 1e-3) / 1e12
+    timed_avg = avg
+    if serial_times is not None:
+        per_s = {}
+        for label, ms in serial_times:
+            per_s.setdefault(label, []).append(ms)
+        avg = {k: sum(v) / len(v) for k, v in per_s.items()}
     stack_flop = sum(2.0 * CONV_MACS[l.split(".")[0]] * n for l in avg)
     stack_ms = sum(avg.values())
     traffic_rec, traffic_src = committed_traffic(DOMINANT_SYMBOL)
@@ -365,9 +391,13 @@ def main():
                                ("conv_c8_kernel<4, 2, 2, 2> (packed-bf16 operands, csrc/conv_c8.hip)" if args.conv_math == "bf16" else
                                 "conv_ring4_kernel / conv_ring_kernel (%s)" % args.conv_math),
                      "launches": list(dominant),
-                     "backward_overlap": ("conv weight gradients (and fc6's input gradient) run on a second stream beside the input "
-                                          "gradients: per-launch times of backward launches include their neighbour, conv_stack is "
-                                          "not a serial sum") if overlapped else None,
+                     "backward_overlap": None if not overlapped else
+                                         ("conv weight gradients (and fc6's input gradient) run on a second stream beside the input "
+                                          "gradients; forward launches run alone"
+                                          + ("; conv_stack below = the same steps with the second stream off (%d extra steps after "
+                                             "the timed region)" % args.steps if serial_times is not None else
+                                             "; conv_stack is not a serial sum")),
+                     "per_launch_ms_in_timed_region": {k: round(v, 3) for k, v in sorted(timed_avg.items())} if overlapped else None,
                      "flop_per_launch": dom_flop, "ms_per_launch": round(dom_ms, 4),
                      "conv_stack": {"tflops": round(stack_flop / (stack_ms * 1e-3) / 1e12, 2),
                                     "frac": round(stack_flop / (stack_ms * 1e-3) / 1e12 / peak, 4),

@@ -71,13 +71,36 @@ CASES = {
 }
 
 
+def config4_full():
+    """BASELINE config 4 at its own shapes (tools/bench_composed.py's job on 8 clips): AlexNet(fc6) + LSTM(256, state) over 16-frame
+    227x227 clips => the state of a 256-unit LSTM over 21 word vectors (BOS + 20 tokens, 300-d), per-step logits over 1000 words."""
+    return dict(
+        pipes=[("enc", dict(input=["main"], representation="dcnn", frame_encoding_layer="fc6", classifier="lstm", lstm_params=[256, 1, "state"])),
+               ("dec", dict(input=["aux", "enc"], representation="nop", classifier="lstm", lstm_params=[256, 1, "reshape"]))],
+        data={"main": dict(mode="video", fpc=16, cpv=1), "aux": dict(mode="vectors", fpc=21, cpv=1, dim=300)},
+        V=1000, items=8, seed=41, shape=(227, 227, 3))
+
+
+def two_stream_full():
+    """The two-stream LRCN at AlexNet's shapes: two dcnn towers over 4 clips x 16 frames of 227x227 each, fc6 features averaged into
+    LSTM(256) -> 101 classes (128 frames through the conv stacks, as one rank's shard of the benchmark job)."""
+    c = two_stream("avg", H=256)
+    c["data"] = {"main": dict(mode="video", fpc=16, cpv=1), "aux": dict(mode="video", fpc=16, cpv=1)}
+    c.update(V=101, items=4, seed=42, shape=(227, 227, 3))
+    return c
+
+
+# full-geometry cases whose oracle answers are committed (tests/golden/graph_full.npz, written by tests/golden/make_golden_graph.py)
+FULL_CASES = {"c4_ws": config4_full, "ts_ws": two_stream_full}
+
+
 def specs_and_datasets(case, items=None):
     """-> ([PipelineSpec], {tag: DatasetInfo}) for GraphEngine."""
     from vltf_amd.graph import DatasetInfo, PipelineSpec
     items = items or case["items"]
     pipes = [PipelineSpec(name=n, **{k: (tuple(v) if k in ("lstm_params", "frame_fusion") and v else v) for k, v in s.items()})
              for n, s in case["pipes"]]
-    ds = {t: DatasetInfo(d["mode"], d["fpc"], d["cpv"], items * d["cpv"], image_shape=SHAPE if d["mode"] == "video" else None,
+    ds = {t: DatasetInfo(d["mode"], d["fpc"], d["cpv"], items * d["cpv"], image_shape=case.get("shape", SHAPE) if d["mode"] == "video" else None,
                          dim=d.get("dim")) for t, d in case["data"].items()}
     return pipes, ds
 
@@ -90,7 +113,7 @@ def inputs(case, items=None):
     for t, d in sorted(case["data"].items()):
         rows = items * d["cpv"] * d["fpc"]
         if d["mode"] == "video":
-            raw[t] = rng.integers(0, 256, (rows,) + SHAPE, dtype=np.uint8)
+            raw[t] = rng.integers(0, 256, (rows,) + tuple(case.get("shape", SHAPE)), dtype=np.uint8)
             feeds[t] = raw[t].astype(np.float32) - MEAN
         else:
             raw[t] = rng.standard_normal((rows, d["dim"])).astype(np.float32)

@@ -117,3 +117,24 @@ def test_refusals_follow_the_reference(monkeypatch, pipes, msg):
     specs, ds = GC.specs_and_datasets(case)
     with pytest.raises(VltfError, match=msg):
         Engine(specs, ds, 7, device="cpu")
+
+
+@pytest.mark.parametrize("name", sorted(GC.FULL_CASES))
+def test_full_geometry_fixture_covers_every_variable(name):
+    """tests/golden/graph_full.npz (the fp64 oracle's answers for the full-geometry graphs of tests/test_graph_full_gpu.py) holds a
+    gradient norm, head and sample for exactly the variables the engine plans for that model -- no device needed for the plan."""
+    import os
+    from vltf_amd.graph import model_specs
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "graph_full.npz"))
+    case = GC.FULL_CASES[name]()
+    pipes, ds = GC.specs_and_datasets(case)
+    specs = model_specs(pipes, ds, case["V"])
+    want = {n for n, _ in specs}
+    have = {k.split("/gradnorm/", 1)[1] for k in gold.files if k.startswith(name + "/gradnorm/")}
+    assert want == have
+    rows = case["items"] * (case["data"]["aux"]["fpc"] if name == "c4_ws" else 1)
+    assert gold[name + "/logits"].shape == (rows, case["V"])
+    loss, gn, acc = gold[name + "/loss_gn_acc"]
+    assert np.isfinite([loss, gn, acc]).all() and gn > 0
+    for n, shp in specs:
+        assert gold["%s/gradsample/%s" % (name, n)].shape == (64,) and np.isfinite(gold["%s/gradnorm/%s" % (name, n)]).all()

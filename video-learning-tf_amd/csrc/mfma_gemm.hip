@@ -1833,25 +1833,48 @@ __global__ __launch_bounds__(256, 2) void conv_ring4_kernel(const ConvRingParams
     }
 }
 
-// out[e] = sum_s slab[s][e] (+bias[e % n_cols]) (relu) (mask) : deterministic split reduction.
-__global__ void reduce_slabs_kernel(const float* __restrict__ ws, float* __restrict__ out, int64_t count, int splits,
-                                    int64_t slab_stride, const float* __restrict__ bias, int ncols, int64_t ldc,
-                                    int relu, const float* __restrict__ mask) {
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (int64_t)gridDim.x * blockDim.x) {
+// out[e] = sum_s slab[s][e] (+bias[e % n_cols]) (relu) (mask) : deterministic split reduction.  A workgroup owns 64 consecutive
+// elements; its four waves sum a quarter of the slabs each (whole-line loads, four independent chains) and wave 0 adds the four
+// partial sums in a fixed order.  (One thread per element over all slabs left conv1's 35 k-element, ~85-slab reduction at 40 us.)
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ ws, float* __restrict__ out, int64_t count, int splits,
+                                                          int64_t slab_stride, const float* __restrict__ bias, int ncols, int64_t ldc,
+                                                          int relu, const float* __restrict__ mask) {
+    __shared__ float part[3][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int per = (splits + 3) >> 2;
+    const int z0 = w * per, z1 = min(splits, z0 + per);
+    for (int64_t e0 = (int64_t)blockIdx.x * 64; e0 < count; e0 += (int64_t)gridDim.x * 64) {
+        const int64_t e = e0 + lane;
         float s = 0.f;
-        for (int z = 0; z < splits; ++z) s += ws[(int64_t)z * slab_stride + e];
-        int64_t o = e;
-        if (ncols > 0) {
-            const int64_t row = e / ncols;
-            const int col = (int)(e - row * ncols);
-            if (bias) s += bias[col];
-            o = row * ldc + col;
+        if (e < count) {
+            const float* p = ws + (int64_t)z0 * slab_stride + e;
+            int z = z0;
+            for (; z + 4 <= z1; z += 4, p += 4 * slab_stride) {
+                const float a = p[0], b = p[slab_stride], c = p[2 * slab_stride], d = p[3 * slab_stride];
+                s += a; s += b; s += c; s += d;
+            }
+            for (; z < z1; ++z, p += slab_stride) s += p[0];
         }
-        if (relu) s = fmaxf(s, 0.f);
-        if (mask) s = mask[o] > 0.f ? s : 0.f;
-        out[o] = s;
+        if (w > 0) part[w - 1][lane] = s;
+        __syncthreads();
+        if (w == 0 && e < count) {
+            s = (s + part[0][lane]) + (part[1][lane] + part[2][lane]);
+            int64_t o = e;
+            if (ncols > 0) {
+                const int64_t row = e / ncols;
+                const int col = (int)(e - row * ncols);
+                if (bias) s += bias[col];
+                o = row * ldc + col;
+            }
+            if (relu) s = fmaxf(s, 0.f);
+            if (mask) s = mask[o] > 0.f ? s : 0.f;
+            out[o] = s;
+        }
+        __syncthreads();
     }
 }
+
+static int reduce_blocks(int64_t count) { return (int)((count + 63) / 64 < 16384 ? (count + 63) / 64 : 16384); }
 
 // A/B switches for measurements, read once: VL_CONV_STAGED=1 runs conv forward / dgrad on the register-staged mfma_contract
 // template instead of the LDS-DMA kernels, VL_GEMM_NOSPLIT=1 disables the split-K of small dense GEMMs.
@@ -2530,25 +2553,36 @@ extern "C" int vl_conv_fwd(const vl_conv_desc* d, const float* x, const float* w
     return dispatch_conv<false>(g, w, d->cout, d->cog, d->rowtab_fwd, d->cog, d->cout, o, d->wsplit_fwd, (hipStream_t)stream);
 }
 
-__global__ void conv_wt_transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, int KH, int KW, int cig,
-                                         int cog, int groups) {
+// wt[KH-1-ky][KW-1-kx][co][g*cig + ci] = w[ky][kx][ci][g*cog + co]: per tap and group a [cig][cog] -> [cog][cig] transpose, 64 x 64
+// tiles through LDS so that both the reads (along co) and the writes (along ci) are whole lines.  (Round 2's element-per-thread form
+// read one line per lane: 64 us per layer, 0.26 ms of an 8-clip step.)
+__global__ __launch_bounds__(256) void conv_wt_transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, int KH, int KW,
+                                                                int cig, int cog, int groups) {
+    __shared__ float tile[64][65];
     const int cin = cig * groups, cout = cog * groups;
-    const int64_t total = (int64_t)KH * KW * cog * cin;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        // e indexes wt[kh'][kw'][co][g*cig + ci]
-        const int cc = (int)(e % cin);
-        const int co = (int)((e / cin) % cog);
-        const int kx = (int)((e / ((int64_t)cin * cog)) % KW);
-        const int ky = (int)(e / ((int64_t)cin * cog * KW));
-        const int g = cc / cig, ci = cc % cig;
-        wt[e] = w[(((int64_t)(KH - 1 - ky) * KW + (KW - 1 - kx)) * cig + ci) * cout + g * cog + co];
+    const int tci = (cig + 63) / 64, tco = (cog + 63) / 64;
+    int b = blockIdx.x;
+    const int co0 = (b % tco) * 64; b /= tco;
+    const int ci0 = (b % tci) * 64; b /= tci;
+    const int g = b % groups;       b /= groups;
+    const int kx = b % KW, ky = b / KW;
+    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+    const float* src = w + ((int64_t)(ky * KW + kx) * cig) * cout + g * cog;
+    for (int r = ly; r < 64; r += 4) {
+        const int ci = ci0 + r, co = co0 + lx;
+        if (ci < cig && co < cog) tile[r][lx] = src[(int64_t)ci * cout + co];
+    }
+    __syncthreads();
+    float* dst = wt + ((int64_t)((KH - 1 - ky) * KW + (KW - 1 - kx)) * cog) * cin + g * cig;
+    for (int r = ly; r < 64; r += 4) {
+        const int co = co0 + r, ci = ci0 + lx;
+        if (co < cog && ci < cig) dst[(int64_t)co * cin + ci] = tile[lx][r];
     }
 }
 
 extern "C" int vl_conv_wt_transpose(const vl_conv_desc* d, const float* w, float* wt, vl_stream_t stream) {
     VL_CHECK(d && w && wt, "vl_conv_wt_transpose: null argument");
-    const int64_t total = (int64_t)d->kh * d->kw * d->cog * d->cin;
-    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    const int blocks = d->kh * d->kw * d->groups * ((d->cig + 63) / 64) * ((d->cog + 63) / 64);
     hipLaunchKernelGGL(conv_wt_transpose_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, wt, d->kh, d->kw, d->cig,
                        d->cog, d->groups);
     VL_LAUNCH_CHECK();
@@ -2582,7 +2616,7 @@ static void dy_params(const vl_conv_desc* d, const ConvGeom& g, const float* dy,
 static int reduce_wgrad(const vl_conv_desc* d, float* dw, const float* ws, int splits, hipStream_t s) {
     const int64_t slab = (int64_t)d->K * d->cout;
     if (splits > 1) {
-        const int blocks = (int)((slab + 255) / 256 < 4096 ? (slab + 255) / 256 : 4096);
+        const int blocks = reduce_blocks(slab);
         hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, s, ws, dw, slab, splits, slab, nullptr, 0, 0, 0, nullptr);
         VL_LAUNCH_CHECK();
     }
@@ -2642,7 +2676,7 @@ static int launch_wgrad_dma(const vl_conv_desc* d, const ConvGeom& g, const floa
                        ceil_div(rtiles, splits), db_slabs, d->cout);
     VL_LAUNCH_CHECK();
     if (db && splits > 1) {
-        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(ceil_div(d->cout, 256)), dim3(256), 0, s, db_slabs, db, (int64_t)d->cout, splits,
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(reduce_blocks(d->cout)), dim3(256), 0, s, db_slabs, db, (int64_t)d->cout, splits,
                            (int64_t)d->cout, nullptr, 0, 0, 0, nullptr);
         VL_LAUNCH_CHECK();
     }
@@ -2739,7 +2773,7 @@ static int launch_gemm(int m, int n, int k, const float* a, int64_t lda, const f
     VL_LAUNCH_CHECK();
     if (splits > 1) {
         const int64_t cnt = (int64_t)m * n;
-        const int blocks = (int)((cnt + 255) / 256 < 4096 ? (cnt + 255) / 256 : 4096);
+        const int blocks = reduce_blocks(cnt);
         hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, s, ws, c, cnt, splits, cnt, bias, n, ldc, relu, mask);
         VL_LAUNCH_CHECK();
     }
@@ -2992,7 +3026,7 @@ static int launch_gemm_split(int transa, int transb, int m, int n, int k, const 
     VL_LAUNCH_CHECK();
     if (splits > 1) {
         const int64_t count = (int64_t)m * n;
-        const int blocks = (int)((count + 255) / 256 < 4096 ? (count + 255) / 256 : 4096);
+        const int blocks = reduce_blocks(count);
         hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, s, slabs, c, count, splits, count, bias, n, ldc, relu,
                            relu_mask);
         VL_LAUNCH_CHECK();

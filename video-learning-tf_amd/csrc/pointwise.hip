@@ -1042,35 +1042,60 @@ __global__ void sum_partials_kernel(const float* __restrict__ ws, float* __restr
 
 extern "C" int vl_bias_grad_nchw(const float* dy, float* db, float* ws, int n, int c, int hw, vl_stream_t stream) {
     VL_CHECK(dy && db && ws && n > 0 && c > 0 && hw > 0, "vl_bias_grad_nchw: bad argument");
-    const int S = n < 64 ? n : 64;
+    // slices of >= 8192 elements per channel, so that the second stage adds a handful of partials (S = 64 for any n cost 15 us there)
+    const int64_t want = ((int64_t)n * hw + 8191) / 8192;
+    const int S = want < 1 ? 1 : want > 64 ? 64 : want > n ? n : (int)want;
     const int per = ceil_div(n, S);
     const int S2 = ceil_div(n, per);
-    hipLaunchKernelGGL(bias_grad_stage1, dim3(c, S2), dim3(256), 0, (hipStream_t)stream, dy, ws, n, c, hw, per);
+    hipLaunchKernelGGL(bias_grad_stage1, dim3(c, S2), dim3(256), 0, (hipStream_t)stream, dy, S2 == 1 ? db : ws, n, c, hw, per);
     VL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(ceil_div(c, 256)), dim3(256), 0, (hipStream_t)stream, ws, db, c, S2);
-    VL_LAUNCH_CHECK();
+    if (S2 > 1) {
+        hipLaunchKernelGGL(sum_partials_kernel, dim3(ceil_div(c, 256)), dim3(256), 0, (hipStream_t)stream, ws, db, c, S2);
+        VL_LAUNCH_CHECK();
+    }
     return 0;
 }
 
-__global__ void colsum_stage1(const float* __restrict__ a, int64_t lda, float* __restrict__ ws, int m, int ncol, int per) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= ncol) return;
+// grid (ceil(ncol / 32), S): a workgroup sums 32 columns over rows [s*per, (s+1)*per) -- 8 row groups of 32 lanes (whole 128-byte
+// lines), combined through LDS in a fixed order -> dst[s*ncol + j].  With S = 1 dst is the result itself (one launch: the
+// classifier / LSTM / fc6 bias gradients of a 128-frame shard were two launches of 6 + 17 us each).
+__global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ a, int64_t lda, float* __restrict__ dst, int m, int ncol, int per) {
+    __shared__ float part[8][32];
+    const int lx = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int j = blockIdx.x * 32 + lx;
     const int s = blockIdx.y;
-    const int r0 = s * per, r1 = min(m, r0 + per);
+    const int r1 = min(m, (s + 1) * per);
     float acc = 0.f;
-    for (int r = r0; r < r1; ++r) acc += a[(int64_t)r * lda + j];
-    ws[(int64_t)s * ncol + j] = acc;
+    if (j < ncol) {
+        int r = s * per + g;
+        for (; r + 24 < r1; r += 32) {
+            const float v0 = a[(int64_t)r * lda + j], v1 = a[(int64_t)(r + 8) * lda + j], v2 = a[(int64_t)(r + 16) * lda + j],
+                        v3 = a[(int64_t)(r + 24) * lda + j];
+            acc += v0; acc += v1; acc += v2; acc += v3;
+        }
+        for (; r < r1; r += 8) acc += a[(int64_t)r * lda + j];
+    }
+    part[g][lx] = acc;
+    __syncthreads();
+    if (g == 0 && j < ncol) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t += part[i][lx];
+        dst[(int64_t)s * ncol + j] = t;
+    }
 }
 
 extern "C" int vl_colsum(const float* a, int64_t lda, float* out, float* ws, int m, int n, vl_stream_t stream) {
     VL_CHECK(a && out && ws && m > 0 && n > 0 && lda >= n, "vl_colsum: bad argument");
-    const int S = m < 64 ? m : 64;
+    const int S = ceil_div(m, 256) < 64 ? ceil_div(m, 256) : 64;
     const int per = ceil_div(m, S);
     const int S2 = ceil_div(m, per);
-    hipLaunchKernelGGL(colsum_stage1, dim3(ceil_div(n, 256), S2), dim3(256), 0, (hipStream_t)stream, a, lda, ws, m, n, per);
+    hipLaunchKernelGGL(colsum_stage1, dim3(ceil_div(n, 32), S2), dim3(256), 0, (hipStream_t)stream, a, lda, S2 == 1 ? out : ws, m, n, per);
     VL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, ws, out, n, S2);
-    VL_LAUNCH_CHECK();
+    if (S2 > 1) {
+        hipLaunchKernelGGL(sum_partials_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, ws, out, n, S2);
+        VL_LAUNCH_CHECK();
+    }
     return 0;
 }
 

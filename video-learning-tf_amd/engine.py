@@ -757,6 +757,13 @@ class LRCNEngine:
         else:
             ops.gemm(d, P["dcnn/fc6W"], L5["dp"], n, self.flat_dim, FC_DIM, transb=True, ws=self.ws)
         # ---- conv stack, last to first
+        side = self._side_stream()
+
+        def on_side(launch):
+            side.wait_stream(torch.cuda.current_stream(self.dev))
+            with torch.cuda.stream(side):
+                launch()
+
         for li in reversed(range(len(self.layers))):
             L = self.layers[li]
             name, conv = L["name"], L["conv"]
@@ -793,15 +800,10 @@ class LRCNEngine:
                 else:      # straight into the previous conv's packed gradient; its ReluGrad reads this layer's packed input
                     self._run(name + ".dgrad", conv.c8_dgrad, L["dyb"][:n], L["wbt"], dxb=prev["dyb"][:n], relu_mask_c8=L["xb"][:n])
                 continue
-            side = self._side_stream()
-            if side is not None:           # the weight gradient on the second stream, beside this layer's dgrad / the next pool backward
-                side.wait_stream(torch.cuda.current_stream(self.dev))
-                ctx = torch.cuda.stream(side)
-                wws, wsw = self.ws_side, self.small_ws_side      # the side stream's OWN scratch: nothing the main stream launches
-            else:                                                # meanwhile can touch it, whatever takes a workspace there later
-                ctx = contextlib.nullcontext()
-                wws, wsw = self.ws, sw
-            with ctx:
+            # the side stream's OWN scratch: nothing the main stream launches meanwhile can touch it, whatever takes a workspace there later
+            wws, wsw = (self.ws_side, self.small_ws_side) if side is not None else (self.ws, sw)
+
+            def wgrad(name=name, conv=conv, x_in=x_in, dy=dy, wws=wws, wsw=wsw):
                 if conv.fuses_bias():      # bias gradient comes out of the same pass over dy
                     self._run(name + ".wgrad", conv.wgrad, x_in, dy, G["dcnn/%sW" % name], wws, db=G["dcnn/%sb" % name])
                 else:
@@ -810,6 +812,11 @@ class LRCNEngine:
                 if self.dp is not None and name == "conv3":
                     # issued from the stream the weight gradients ran on: RCCL's stream waits for that stream only
                     self.dp.reduce_async(self.g, *self.grad_chunks[-2])
+
+            if side is None:
+                wgrad()
+            else:
+                on_side(wgrad)                        # beside this layer's dgrad / the next pool backward
             if li > 0:
                 prev = self.layers[li - 1]
                 conv.wt_transpose(P["dcnn/%sW" % name], self.wt)
@@ -817,17 +824,23 @@ class LRCNEngine:
                     self._run(name + ".dgrad", conv.dgrad, dy, self.wt, prev["dp"][:n])     # into the pool output gradient
                 else:
                     self._run(name + ".dgrad", conv.dgrad, dy, self.wt, prev["dy"][:n], relu_mask=prev["y"][:n])
-        if self._side_stream() is not None:
-            torch.cuda.current_stream(self.dev).wait_stream(self._side_stream())
+        if side is not None:
+            torch.cuda.current_stream(self.dev).wait_stream(side)
         if self.dp is not None:
             self.dp.reduce_async(self.g, *self.grad_chunks[-1])
 
     def _side_stream(self):
         """Second HIP stream of the backward pass, or None.  Independent launches (a layer's weight gradient beside its input
         gradient and the next pool / LRN backward; fc6's input gradient beside its weight-gradient blocks) fill the CUs a small
-        launch leaves idle: an 8-clip shard steps 4 % faster, 16 / 32 clips 2 %, 64 clips 1.5 %.  VLTF_WGRAD_STREAM=1 / 0 forces it;
-        unset = on for shards of at most 512 frames (where launches underfill the chip), off for the full batch, whose per-kernel timings
-        (bench.py's roofline) need launches that run alone.  The fp32 path only."""
+        launch leaves idle: an 8-clip shard steps 4 % faster, 16 / 32 clips 2 %, 64 clips 1.3 %.  VLTF_WGRAD_STREAM=1 / 0 forces it;
+        unset = on for shards of at most 512 frames (where launches underfill the chip), off for the full batch: there the gain is
+        inside the box-to-box spread and costs the per-kernel timings (a bracket or a rocprof average of a launch that has a
+        neighbour times both).  Round 3 measured two other schedules at 64 clips (35.75 ms on one stream, 35.3 with every weight
+        gradient beside its input gradient): conv5..conv3's weight gradients held back until conv2's pool / LRN backward, to hide
+        that HBM-bound kernel under MFMA-bound ones -- 35.8 ms, next to a 135 KB-of-LDS wgrad workgroup a CU holds ONE pool / LRN
+        workgroup, which then crawls (1.33 ms instead of 0.65) while the chain of input gradients waits for it; and conv3's two
+        launches each alone (its dgrad is the step's dominant symbol) with the others paired -- 35.85 ms, the joins cost what the
+        pairs win.  The fp32 path only."""
         mode = os.environ.get("VLTF_WGRAD_STREAM", "")
         on = mode == "1" or (mode == "" and getattr(self, "_frames_now", 1 << 30) <= 512)
         if not on or self.cfg.conv_math != "f32":

@@ -641,14 +641,46 @@ class PipeNode:
             ops.eltwise2(prod.dout, d, prod.dout, "add", count=cnt)
 
 
+def init_params_for(specs, seed=0, stddev=0.05, well_scaled=False):
+    """Reference initialisers for a variable list [(name, shape)] (alexnet.py:40-46, tf_util.py:44-45; BasicLSTMCell: glorot-uniform /
+    zeros), drawn in list order from one generator."""
+    rng = np.random.default_rng(seed)
+    out = {}
+    for name, shp in specs:
+        if name.endswith("kernel"):
+            lim = math.sqrt(6.0 / (shp[0] + shp[1]))
+            out[name] = rng.uniform(-lim, lim, shp).astype(np.float32)
+        elif name.endswith("bias"):
+            out[name] = np.zeros(shp, np.float32)
+        elif len(shp) > 1:
+            out[name] = _trunc_normal(rng, shp, math.sqrt(2.0 / int(np.prod(shp[:-1]))) if well_scaled else stddev)
+        else:
+            out[name] = np.full(shp, 0.1, np.float32)
+    return out
+
+
+def model_specs(pipelines, datasets, num_classes):
+    """[(name, shape)] of a model's variables in flat-buffer order -- the host-side plan of GraphEngine without a device (fixture
+    generators, checkpoint tools)."""
+    eng = object.__new__(GraphEngine)
+    eng.dev, eng.training, eng.dp = torch.device("cpu"), False, None
+    eng._plan(pipelines, datasets, num_classes)
+    return list(eng.specs)
+
+
 class GraphEngine:
     def __init__(self, pipelines: List[PipelineSpec], datasets: dict, num_classes: int, device="cuda:0", training=True, dp=None,
                  optimizer="sgd", dropout_keep_prob=0.0, conv_math="f32"):
         self.dev = torch.device(device)
         self._require_device()
+        self.training, self.dp = training, dp
+        self._plan(pipelines, datasets, num_classes, optimizer, dropout_keep_prob, conv_math)
+        self._allocate()
+
+    def _plan(self, pipelines, datasets, num_classes, optimizer="sgd", dropout_keep_prob=0.0, conv_math="f32"):
+        """The graph and its variable list (self.nodes, self.specs): host logic only, no device (model_specs uses it alone)."""
         if not pipelines:
             raise VltfError("no pipeline defined")
-        self.training, self.dp = training, dp
         self.num_classes, self.optimizer, self.dropout_keep_prob, self.conv_math = int(num_classes), optimizer, float(dropout_keep_prob or 0.0), conv_math
         self.datasets = datasets
         self.scoped = len(pipelines) > 1
@@ -698,6 +730,10 @@ class GraphEngine:
         dup = {n for n, _ in self.specs if [m for m, _ in self.specs].count(n) > 1}
         if dup:
             raise VltfError("Variable %s already exists" % sorted(dup)[0])
+
+    def _allocate(self):
+        order = list(reversed(self.nodes))
+        training, optimizer = self.training, self.optimizer
         total = sum(int(np.prod(s)) for _, s in self.specs)
         dev = self.dev
         self.w = torch.zeros(total, device=dev)
@@ -749,19 +785,7 @@ class GraphEngine:
 
     def init_params(self, seed=0, stddev=0.05, well_scaled=False):
         """Reference initialisers for every variable (alexnet.py:40-46, tf_util.py:44-45; BasicLSTMCell: glorot-uniform / zeros)."""
-        rng = np.random.default_rng(seed)
-        out = {}
-        for name, shp in self.specs:
-            if name.endswith("kernel"):
-                lim = math.sqrt(6.0 / (shp[0] + shp[1]))
-                out[name] = rng.uniform(-lim, lim, shp).astype(np.float32)
-            elif name.endswith("bias"):
-                out[name] = np.zeros(shp, np.float32)
-            elif len(shp) > 1:
-                out[name] = _trunc_normal(rng, shp, math.sqrt(2.0 / int(np.prod(shp[:-1]))) if well_scaled else stddev)
-            else:
-                out[name] = np.full(shp, 0.1, np.float32)
-        return out
+        return init_params_for(self.specs, seed, stddev, well_scaled)
 
     def get_params(self):
         self._sync()
