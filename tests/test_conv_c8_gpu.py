@@ -240,9 +240,11 @@ def test_frames_straight_into_the_packed_input(ops):
 
 
 @pytest.mark.parametrize("n,h,w,c,halo", [(2, 9, 7, 96, 1), (3, 13, 13, 256, 2), (2, 27, 27, 16, 1), (1, 55, 55, 96, 1)])
-@pytest.mark.parametrize("relu", [True, False])
-def test_pool_lrn_bwd_packed_output(ops, n, h, w, c, halo, relu):
-    """vl_pool_lrn_bwd_c8 = vl_pool_lrn_bwd with the result rounded to bf16 into the c8 layout (same arithmetic before the rounding)."""
+@pytest.mark.parametrize("relu,ranges", [(True, ""), (False, ""), (True, "1"), (True, "3")])
+def test_pool_lrn_bwd_packed_output(ops, monkeypatch, n, h, w, c, halo, relu, ranges):
+    """vl_pool_lrn_bwd_c8 = vl_pool_lrn_bwd with the result rounded to bf16 into the c8 layout (same arithmetic before the rounding);
+    VL_PLB_RANGES: the count of channel ranges both kernels split a (band, image) into (multiples of 8 channels for the packed one)."""
+    monkeypatch.setenv("VL_PLB_RANGES", ranges) if ranges else monkeypatch.delenv("VL_PLB_RANGES", raising=False)
     rng = np.random.default_rng(c + h)
     x = torch.from_numpy(np.maximum(rng.standard_normal((n, c, h, w)) * 30, 0).astype(np.float32)).to(DEV)
     oh, ow = ops.pool_out(h), ops.pool_out(w)

@@ -375,6 +375,31 @@ def test_pool_lrn_bwd_fused(ops, n, h, w, c, ph, dh):
         assert float(dx[:, :, :dh].abs().max()) == 0
 
 
+@pytest.mark.parametrize("ranges", ["1", "2", "3", "4", ""])
+@pytest.mark.parametrize("n,h,w,c,ph,dh", [(2, 55, 55, 96, 2, 0), (3, 27, 27, 256, 1, 2), (2, 13, 13, 33, 1, 1)])
+def test_pool_lrn_bwd_channel_ranges(ops, monkeypatch, ranges, n, h, w, c, ph, dh):
+    """The channel-stream backward split into 1..4 channel ranges per (band, image) (grid z; VL_PLB_RANGES forces the count, unset =
+    the dispatcher's choice): every range restarts the LRN windows 4 channels early and must reproduce the oracle at its seams --
+    AlexNet's two LRN layers (5-channel chunks) and a ragged channel count (16-channel chunks)."""
+    monkeypatch.setenv("VL_PLB_RANGES", ranges) if ranges else monkeypatch.delenv("VL_PLB_RANGES", raising=False)
+    rng = np.random.default_rng(h * c + 1)
+    x = np.maximum(rng.standard_normal((n, h, w, c)) * 30, 0).astype(np.float32)
+    l, _ = O.lrn(x)
+    y, arg = O.max_pool_valid(l)
+    oh, ow = y.shape[1], y.shape[2]
+    dy = rng.standard_normal(y.shape).astype(np.float32)
+    want = O.lrn_grad(x, O.max_pool_valid_grad(x.shape, arg, dy.astype(np.float64))) * (x > 0)
+    dp = torch.zeros((n, c, oh + 2 * ph, ow + 2 * ph), device=DEV)
+    ap = torch.zeros(dp.shape, dtype=torch.uint8, device=DEV)
+    interior(dp, ph).copy_(dev(nchw(dy)))
+    interior(ap, ph).copy_(dev(nchw(arg), torch.uint8))
+    dx = torch.full((n, c, h + 2 * dh, w + 2 * dh), float("nan"), device=DEV)
+    if dh:
+        dx[:, :, :dh] = 0; dx[:, :, -dh:] = 0; dx[:, :, :, :dh] = 0; dx[:, :, :, -dh:] = 0
+    ops.pool_lrn_bwd(dev(nchw(x)), dp, ap, dx, p_halo=ph, dx_halo=dh)
+    close(nhwc(host(interior(dx, dh))), want, rtol=1e-5, atol_rel=1e-6)          # every interior element written (no NaN left)
+
+
 @pytest.mark.parametrize("n,h,w,c,ph", [(2, 9, 11, 7, 0), (3, 13, 13, 20, 1), (2, 57, 57, 96, 2), (2, 28, 28, 256, 1), (1, 31, 64, 5, 0)])
 def test_lrn_pool_fwd_fused(ops, n, h, w, c, ph):
     """Fused kernel == lrn followed by max_pool_valid of the oracle (values and first-maximum arg-max), halo untouched."""

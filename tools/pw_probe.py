@@ -28,8 +28,10 @@ def main():
     arg = torch.randint(0, 9, p.shape, dtype=torch.uint8, device=dev)
     ws = torch.empty(64 * c, device=dev)
     db = torch.empty(c, device=dev)
+    dh = {"1": 0, "2": 2, "5": 1}[layer]                              # halo of the gradient the engine's layer writes (dy_halo)
+    dxh = torch.zeros(n, c, h + 2 * dh, w + 2 * dh, device=dev)
     fns = {
-        "pool_lrn_bwd": lambda: ops.pool_lrn_bwd(x, dp, arg, y, p_halo=ph),
+        "pool_lrn_bwd": lambda: ops.pool_lrn_bwd(x, dp, arg, dxh, p_halo=ph, dx_halo=dh, relu_fused=True),
         "lrn_pool_fwd": lambda: ops.lrn_pool_fwd(x, p, arg, p_halo=ph),
         "lrn_fwd": lambda: ops.lrn_fwd(x, y),
         "lrn_bwd": lambda: ops.lrn_bwd(x, dy, y, relu_fused=True),

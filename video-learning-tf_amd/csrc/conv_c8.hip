@@ -113,6 +113,9 @@ static constexpr int KT = C8_KT;   // taps (8 reduction positions each; 4 taps =
 // (round 3: -DC8_KT=8 -DC8_NBUF=2 with 128-pixel tiles -- 16 MFMAs per wave between barriers, two workgroups per CU at 64 KB -- was
 // measured: the conv stack of the benchmark step 5.24 ms against 4.60 with 4-tap stages, three of them in the ring, 256-pixel tiles;
 // the barrier count is not what holds these kernels back, the fetch depth and the tile's operand reuse are)
+#ifndef C8_EXP
+#define C8_EXP 0      // limit experiments on conv_c8_kernel (tools/c8_limits.sh; results are garbage): 1 no fetches inside the loop,
+#endif                // 2 operands read from LDS once, 4 no MFMAs, 8 no epilogue -- never set in a product build
 #ifndef C8_NBUF
 #define C8_NBUF 0     // 0: by tile (C8Cfg)
 #endif
@@ -298,13 +301,21 @@ __global__ __launch_bounds__(64 * WP * WQ, (C8Cfg<WP, WQ, TP, TQ>::WPS)) void co
             for (int q = 0; q < 16; ++q) acc[j][i][q] = 0.f;
 
     for (int st = 0; st < NBUF - 1 && st < nstages; ++st) issue(st);
+#if C8_EXP & 2
+    i32x4 exp_bp[KT / 2][TP], exp_aq[KT / 2][TQ];
+#endif
     // Stagger (MI355X guide, "two waves per SIMD", item 9): all waves run the same program with one barrier per stage, so they reach
     // their fetch issue (3 LDS-DMA pieces, ~100 cycles each inside such a phase), their LDS read burst and their MFMAs together.  The
     // second-dispatched half (the SIMD partners of waves 0 .. NW/2 - 1) issues its fetches after its first MFMA group instead: the
     // partners' MFMAs run beside them.  Measured (tools/c8_probe.py, 1024 frames): conv2 fwd 0.529 -> 0.503 ms, conv3 fwd 0.279 ->
     // 0.273, conv3 dgrad 0.297 -> 0.284; the 4-wave tiles (conv4) unchanged.  A static s_setprio 1 for that half on top was mixed
     // (conv2 fwd 0.497 but conv4 +3..9 %) and is not used; the FIRST half issuing at the end of its stage instead of its start: no
-    // difference.  VL_C8_SCHED=0 runs the lockstep order (A/B).
+    // difference; a stage's fetches issued ONE AT A TIME between the wave's MFMAs (piece p behind MFMA (p + 1) NM / (F + 1), pinned
+    // by sched_barriers; 102 instead of 88 VGPRs): within +-1 % on every launch.  VL_C8_SCHED=0 runs the lockstep order (A/B).
+    // What the loop's time is made of (C8_EXP builds, tools/c8_limits.sh; conv3 forward, 1024 frames, 0.267 ms): MFMAs + barriers
+    // alone 0.183 (1675 TFLOP/s: the ceiling of this tiling at the clock the chip holds), + the LDS operand reads 0.027, + the fetches
+    // 0.034, + the epilogue 0.023 -- the parts ADD; fetches + reads without MFMAs take 0.125 (12.8 GB through the LDS arrays = 0.098 ms
+    // at 256 B/clk/CU), so the LDS array is busy for a third of the kernel, in bursts the MFMAs of all waves wait behind.
     const bool late = NW >= 8 && a.sched != 0 && wave >= NW / 2;       // (uniform; 4-wave tiles: no effect measured, not applied)
     const uint32_t rd_p = (uint32_t)((lane >> 5) * P * 16 + (wp * TP * 32 + (lane & 31)) * 16);
     const uint32_t rd_w = (uint32_t)(C::PIX_BYTES + (lane >> 5) * QF * 16 + (wq * TQ * 32 + (lane & 31)) * 16);
@@ -318,22 +329,49 @@ __global__ __launch_bounds__(64 * WP * WQ, (C8Cfg<WP, WQ, TP, TQ>::WPS)) void co
         else
             wait_vm<0>();
         __syncthreads();   // every wave's pieces of stage st are in LDS; every wave is done reading stage st - 1
-        if (!late && st + NBUF - 1 < nstages) issue(st + NBUF - 1);
-        const char* slot = lds + (st % NBUF) * SLOT;
+        if (!(C8_EXP & 1) && !late && st + NBUF - 1 < nstages) issue(st + NBUF - 1);
+        const char* slot = lds + (((C8_EXP & 2) ? 0 : st) % NBUF) * SLOT;
 #pragma unroll
         for (int kk = 0; kk < KT / 2; ++kk) {
-            if (kk == 1 && late && st + NBUF - 1 < nstages) issue(st + NBUF - 1);
+            if (!(C8_EXP & 1) && kk == 1 && late && st + NBUF - 1 < nstages) issue(st + NBUF - 1);
             i32x4 bp[TP], aq[TQ];
+            if (!(C8_EXP & 2) || st == 0) {
 #pragma unroll
-            for (int i = 0; i < TP; ++i) bp[i] = *reinterpret_cast<const i32x4*>(slot + rd_p + kk * 2 * P * 16 + i * 512);
+                for (int i = 0; i < TP; ++i) bp[i] = *reinterpret_cast<const i32x4*>(slot + rd_p + kk * 2 * P * 16 + i * 512);
 #pragma unroll
-            for (int j = 0; j < TQ; ++j) aq[j] = *reinterpret_cast<const i32x4*>(slot + rd_w + kk * 2 * QF * 16 + j * 512);
+                for (int j = 0; j < TQ; ++j) aq[j] = *reinterpret_cast<const i32x4*>(slot + rd_w + kk * 2 * QF * 16 + j * 512);
+#if C8_EXP & 2
+#pragma unroll
+                for (int i = 0; i < TP; ++i) exp_bp[kk][i] = bp[i];
+#pragma unroll
+                for (int j = 0; j < TQ; ++j) exp_aq[kk][j] = aq[j];
+#endif
+            }
+#if C8_EXP & 2
+#pragma unroll
+            for (int i = 0; i < TP; ++i) bp[i] = exp_bp[kk][i];
+#pragma unroll
+            for (int j = 0; j < TQ; ++j) aq[j] = exp_aq[kk][j];
+#endif
+#if C8_EXP & 4
+#pragma unroll
+            for (int i = 0; i < TP; ++i) asm volatile("" ::"v"(bp[i]));
+#pragma unroll
+            for (int j = 0; j < TQ; ++j) asm volatile("" ::"v"(aq[j]));
+#else
 #pragma unroll
             for (int j = 0; j < TQ; ++j)
 #pragma unroll
                 for (int i = 0; i < TP; ++i) acc[j][i] = mfma_bf16(aq[j], bp[i], acc[j][i]);
+#endif
         }
     }
+#if (C8_EXP & 8) && defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int j = 0; j < TQ; ++j)
+#pragma unroll
+        for (int i = 0; i < TP; ++i) asm volatile("" ::"v"(acc[j][i]));
+#endif
 
     // ---- epilogue ----
     typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte access at 4-byte alignment
@@ -363,7 +401,7 @@ __global__ __launch_bounds__(64 * WP * WQ, (C8Cfg<WP, WQ, TP, TQ>::WPS)) void co
     const __amdgpu_buffer_rsrc_t rs_mb = out_rsrc(a.maskb ? (const void*)a.maskb : (const void*)a.x, mb_img);
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-    for (int i = 0; i < TP; ++i) {
+    for (int i = 0; i < ((C8_EXP & 8) ? 0 : TP); ++i) {
         const int mb = p0 + (wp * TP + i) * 32;                             // first pixel of this 32-pixel block (uniform)
         const int m = mb + (lane & 31);
         const bool valid = m < a.M;

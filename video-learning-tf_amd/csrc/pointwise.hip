@@ -318,8 +318,15 @@ template <int CHK, int NST, bool RELU, int C8 = 0>
 __global__ __launch_bounds__(256, (C8 ? 3 : 1)) void pool_lrn_bwd_stream_kernel(const float* __restrict__ x, const float* __restrict__ dp,
                                                                   const uint8_t* __restrict__ arg, float* __restrict__ dx, int C,
                                                                   int H, int W, int OH, int OW, int64_t ps_n, int ps_c, int ps_h,
-                                                                  int64_t pooled_bytes_f, float alpha, float bias, int halo) {
+                                                                  int64_t pooled_bytes_f, float alpha, float bias, int halo, int cper) {
     constexpr int BUF = NST * 256 + 16;                               // entries per LDS buffer (+ pad: entries -1 and one-past-the-end are read)
+    // blockIdx.z owns the OUTPUT channels [R0, R1) (cper channels; the whole tensor when the grid is flat).  Its walk starts LEAD
+    // channels earlier with empty windows: what it computes for channels below R0 there is wrong and dropped, and by channel R0 the x
+    // window (4 back), the t window (2 more) are complete -- 4 (8: whole packed chunks) extra iterations per range buy workgroups
+    // for launches whose (band, image) grid fills the chip 1.5 times (27 x 27 x 256 at 1024 frames) or not at all (128 frames).
+    constexpr int LEAD = C8 ? 8 : 4;
+    const int R0 = blockIdx.z * cper, R1 = min(C, R0 + cper);
+    const int cs = R0 > 0 ? R0 - LEAD : 0;
     __shared__ __attribute__((aligned(16))) uint2 stage[2 * BUF];
     const int HW = H * W;
     const int img = blockIdx.y;
@@ -459,34 +466,55 @@ __global__ __launch_bounds__(256, (C8 ? 3 : 1)) void pool_lrn_bwd_stream_kernel(
                     const u2 w = {__builtin_bit_cast(uint32_t, __builtin_convertvector(f2{rr[0], rr[1]}, b2)),
                                   __builtin_bit_cast(uint32_t, __builtin_convertvector(f2{rr[2], rr[3]}, b2))};
                     const int blk = (oc - 3) >> 3;                    // uniform; outside [0, CB): dropped by the range check
-                    __builtin_amdgcn_raw_buffer_store_b64(w, rs_dx, (int)((oc - 3 >= 0 && blk < CB) ? voff_dx + (((oc - 3) & 7) * 2) : PW_OOB),
+                    __builtin_amdgcn_raw_buffer_store_b64(w, rs_dx, (int)((oc - 3 >= R0 && oc - 3 < R1 && blk < CB) ? voff_dx + (((oc - 3) & 7) * 2) : PW_OOB),
                                                           blk * dplane * 16, 0);
                 }
             } else {
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, r), rs_dx, (int)((oc >= 0 && oc < C) ? voff_dx : PW_OOB),
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, r), rs_dx, (int)((oc >= R0 && oc < R1) ? voff_dx : PW_OOB),
                                                       oc * dx_cs, 0);
             }
         }
     };
 
-    const int nchunks = (C + 4 + CHK - 1) / CHK;
-    stage_load(0);
-    x_load(0, xa);
+    const int nchunks = (R1 + 4 - cs + CHK - 1) / CHK;
+    stage_load(cs);
+    x_load(cs, xa);
     stage_write(0);
     __syncthreads();
     for (int k = 0; k < nchunks; k += 2) {                            // unrolled by two: the x registers alternate without copies
-        stage_load((k + 1) * CHK);                                    // next chunk's traffic goes out before this chunk's math;
-        x_load((k + 1) * CHK, xb);                                    // past the last chunk every lane fails the channel test
-        chunk(k * CHK, 0, xa);
+        stage_load(cs + (k + 1) * CHK);                               // next chunk's traffic goes out before this chunk's math;
+        x_load(cs + (k + 1) * CHK, xb);                               // past the last channel every lane fails the channel test
+        chunk(cs + k * CHK, 0, xa);
         stage_write(1);
         __syncthreads();
         if (k + 1 >= nchunks) break;
-        stage_load((k + 2) * CHK);
-        x_load((k + 2) * CHK, xa);
-        chunk((k + 1) * CHK, 1, xb);
+        stage_load(cs + (k + 2) * CHK);
+        x_load(cs + (k + 2) * CHK, xa);
+        chunk(cs + (k + 1) * CHK, 1, xb);
         stage_write(0);
         __syncthreads();
     }
+}
+
+// Channel ranges per (band, image) of the channel-stream backward: the count (<= 4) with the fewest rounds x channels walked, a
+// round = 8 workgroups per CU (56 VGPRs, 12.5 KB of LDS).  `unit`: ranges start at multiples of it (8 for the packed output).
+static int plb_channel_ranges(int64_t workgroups, int c, int unit, int* cper) {
+    const int64_t slots = 8ll * vl_device_cus();
+    int best = 1;
+    int64_t best_cost = 0;
+    for (int sp = 1; sp <= 4; ++sp) {
+        const int per = (int)(((c + sp - 1) / sp + unit - 1) / unit * unit);
+        if (sp > 1 && per * (sp - 1) >= c) continue;                  // the last range would be empty
+        const int64_t cost = ((workgroups * sp + slots - 1) / slots) * (per + 12);
+        if (sp == 1 || cost < best_cost) { best = sp; best_cost = cost; *cper = per; }
+    }
+    const char* e = getenv("VL_PLB_RANGES");                          // A/B and tests: force the count (read per call)
+    if (e && atoi(e) >= 1 && atoi(e) <= 4) {
+        best = atoi(e);
+        *cper = (int)(((c + best - 1) / best + unit - 1) / unit * unit);
+        while (best > 1 && *cper * (best - 1) >= c) --best;
+    }
+    return best;
 }
 
 extern "C" int vl_pool_lrn_bwd(const float* x, const float* dp, const uint8_t* argmax, float* dx, int n, int c, int h, int w,
@@ -506,16 +534,18 @@ extern "C" int vl_pool_lrn_bwd(const float* x, const float* dp, const uint8_t* a
         const int64_t pooled_f = ((int64_t)c * pplane - origin) * 4;
         const bool ok = beta == 0.75f && bytes_x < (1ll << 31) && bytes_dx < (1ll << 31) && pooled_f < (1ll << 31) && pplane < (1 << 24) &&
                         !kPoolLrnChunked;
-        const dim3 grid(ceil_div((int64_t)h * w, 256), n);
+        int cper = c;
+        const int nz = plb_channel_ranges((int64_t)ceil_div((int64_t)h * w, 256) * n, c, 1, &cper);
+        const dim3 grid(ceil_div((int64_t)h * w, 256), n, nz);
         const int64_t psn = (int64_t)c * pplane;
 #define VL_PLB_LAUNCH(CHK, NST)                                                                                                     \
     do {                                                                                                                            \
         if (relu_fused)                                                                                                             \
             hipLaunchKernelGGL((pool_lrn_bwd_stream_kernel<CHK, NST, true, 0>), grid, dim3(256), 0, (hipStream_t)stream, x, dp + origin, \
-                               argmax + origin, dx, c, h, w, oh, ow, psn, (int)pplane, owp, pooled_f, alpha, bias, dx_halo);        \
+                               argmax + origin, dx, c, h, w, oh, ow, psn, (int)pplane, owp, pooled_f, alpha, bias, dx_halo, cper);  \
         else                                                                                                                        \
             hipLaunchKernelGGL((pool_lrn_bwd_stream_kernel<CHK, NST, false, 0>), grid, dim3(256), 0, (hipStream_t)stream, x, dp + origin, \
-                               argmax + origin, dx, c, h, w, oh, ow, psn, (int)pplane, owp, pooled_f, alpha, bias, dx_halo);        \
+                               argmax + origin, dx, c, h, w, oh, ow, psn, (int)pplane, owp, pooled_f, alpha, bias, dx_halo, cper);  \
         VL_LAUNCH_CHECK();                                                                                                          \
         return 0;                                                                                                                   \
     } while (0)
@@ -556,12 +586,14 @@ extern "C" int vl_pool_lrn_bwd_c8(const void* x, int x_packed, const float* dp, 
     const int64_t pooled_f = ((int64_t)c * pplane - origin) * 4;
     VL_CHECK(bytes_x < (1ll << 31) && bytes_dx < (1ll << 31) && pooled_f < (1ll << 31) && pplane < (1 << 24) && (int64_t)8 * max_prow * ow <= 5 * 256,
              "vl_pool_lrn_bwd_c8: plane too large for the channel-stream form");
-    const dim3 grid(ceil_div((int64_t)h * w, 256), n);
+    int cper = c;
+    const int nz = plb_channel_ranges((int64_t)ceil_div((int64_t)h * w, 256) * n, c, 8, &cper);
+    const dim3 grid(ceil_div((int64_t)h * w, 256), n, nz);
     const int64_t psn = (int64_t)c * pplane;
     const float* xf = (const float*)x;
 #define VL_PLBC(RELU, MODE)                                                                                                             \
     hipLaunchKernelGGL((pool_lrn_bwd_stream_kernel<8, 5, RELU, MODE>), grid, dim3(256), 0, (hipStream_t)stream, xf, dp + origin, argmax + origin, \
-                       (float*)dxb, c, h, w, oh, ow, psn, (int)pplane, owp, pooled_f, alpha, bias, dxb_halo)
+                       (float*)dxb, c, h, w, oh, ow, psn, (int)pplane, owp, pooled_f, alpha, bias, dxb_halo, cper)
     if (relu_fused && x_packed) VL_PLBC(true, 2);
     else if (relu_fused) VL_PLBC(true, 1);
     else if (x_packed) VL_PLBC(false, 2);
