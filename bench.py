@@ -341,9 +341,9 @@ def main():
     for label, ms in times:
         per.setdefault(label, []).append(ms)
     avg = {k: sum(v) / len(v) for k, v in per.items()}
-    # Small shards run the backward's independent launches on two streams (engine._side_stream): a bracket around a launch that has a
-    # neighbour times both.  The dominant symbol is then measured live, in the timed region, on the launches that run alone there (the
-    # forward ones); the conv-stack table comes from the serial pass above.
+    # The fp32 backward runs its independent launches on two streams (engine._side_stream): a bracket around a launch that has a
+    # neighbour times both.  The dominant symbol is measured live, in the timed region, on the launches that run alone there (the
+    # forward ones: 3 of its 4 launches per step); the conv-stack table comes from the serial pass above.
     dominant = tuple(l for l in DOMINANT if not overlapped or l.endswith(".fwd"))
     dom_flop = sum(2.0 * CONV_MACS[l.split(".")[0]] * n for l in dominant) / len(dominant)      # per launch
     dom_ms = sum(avg[l] for l in dominant) / len(dominant)                                       # per launch

@@ -244,12 +244,12 @@ def test_two_stream_backward_equals_one_stream(monkeypatch):
     frames = torch.tensor(rng.integers(0, 256, (b * fpc,) + shape, dtype=np.uint8), device=DEV)
     onehot = torch.tensor(O.labels_to_one_hot([[l] for l in rng.integers(0, ncls, b)], ncls), device=DEV)
     results = []
-    for mode in ("0", "1"):
-        monkeypatch.setenv("VLTF_WGRAD_STREAM", mode)
+    for mode in ("0", ""):                         # one stream; the default = two
+        monkeypatch.setenv("VLTF_WGRAD_STREAM", mode) if mode else monkeypatch.delenv("VLTF_WGRAD_STREAM", raising=False)
         cfg, eng = make(dict(num_classes=ncls, fpc=fpc, lstm_hidden=16), shape, b)
         eng.load_params(oracle_params(np.random.default_rng(4), cfg, shape))
         outs = [eng.train_step_u8(frames, onehot, lr=0.01, clip_norm=1.0, mean_bgr=MEAN) for _ in range(3)]
-        assert (eng._side_stream() is not None) == (mode == "1")
+        assert (eng._side_stream() is not None) == (mode != "0")
         results.append((eng.get_params(), [(o["loss"], o["grad_norm"]) for o in outs]))
     (p0, o0), (p1, o1) = results
     assert o0 == o1

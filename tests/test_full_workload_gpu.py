@@ -178,7 +178,23 @@ def test_benchmark_job_matches_oracle_fixture(name):
     want = gold[name + "/logits"]
     assert np.abs(fwd - want).max() <= 1e-3, "forward logits: max |d| %.3e" % np.abs(fwd - want).max()
     out = eng.train_step_u8(fd, od, lr=LR, clip_norm=CLIP, mean_bgr=MEAN)
-    check_step_against_fixture(gold, name, p, clips, out, eng.logits_host(), eng.get_grads(), eng.get_params())
+    assert eng._side_stream() is not None                       # the default schedule: the backward on two streams
+    g2, p2 = eng.get_grads(), eng.get_params()
+    check_step_against_fixture(gold, name, p, clips, out, eng.logits_host(), g2, p2)
+    if name == "cfg2_ref":
+        # the benchmark job itself (64 clips, 1024 frames per launch): the two-stream backward leaves BITWISE the gradients and
+        # parameters of the one-stream schedule -- same kernels on the same buffers, only the overlap differs
+        os.environ["VLTF_WGRAD_STREAM"] = "0"
+        try:
+            eng.load_params(p)
+            eng.train_step_u8(fd, od, lr=LR, clip_norm=CLIP, mean_bgr=MEAN)
+            assert eng._side_stream() is None
+            g1, p1 = eng.get_grads(), eng.get_params()
+        finally:
+            del os.environ["VLTF_WGRAD_STREAM"]
+        for k in p:
+            assert np.array_equal(g1[k], g2[k]), "two-stream gradient of %s differs from the one-stream schedule" % k
+            assert np.array_equal(p1[k], p2[k]), "updated %s differs" % k
 
 
 def check_step_against_fixture(gold, name, p, clips, out, got_logits, g, newp, grad_scale=1.0):

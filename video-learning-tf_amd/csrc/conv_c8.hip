@@ -942,6 +942,10 @@ static int c8_wgrad_plan(const vl_conv_desc* d, int n, C8WgPlan* p) {
     static const bool narrow192 = getenv("VL_C8_WG192_NARROW") != nullptr;   // A/B: 16 taps x 192 channels on 6 waves (8 % slower)
     p->wa = p->wb == 3 ? (narrow192 ? 2 : 4) : 4;
     if (d->cog <= 96 && d->cog > 64) p->wa = 4, p->wb = 1, p->tb = 3;
+    // 192-channel groups (conv4): two 96-wide 4-wave tiles of 72 KB -- TWO workgroups per CU -- instead of one 12-wave, 96 KB tile that
+    // owns the CU with all its waves in lockstep: 0.349 -> 0.303 ms at 1024 frames (round 3; VL_C8_WG192_WIDE=1 runs the wide tile)
+    static const bool wide192 = getenv("VL_C8_WG192_WIDE") != nullptr;
+    if (!wide192 && d->cog % 192 == 0) p->wa = 4, p->wb = 1, p->tb = 3;
     const int taps_tile = p->wa * 8, cols_tile = p->wb * p->tb * 32;
     p->tiles_a = (ntaps + taps_tile - 1) / taps_tile;
     p->tiles_b = (d->cog + cols_tile - 1) / cols_tile;

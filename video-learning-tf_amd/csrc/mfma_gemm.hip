@@ -1833,18 +1833,22 @@ __global__ __launch_bounds__(256, 2) void conv_ring4_kernel(const ConvRingParams
     }
 }
 
-// out[e] = sum_s slab[s][e] (+bias[e % n_cols]) (relu) (mask) : deterministic split reduction.  A workgroup owns 64 consecutive
-// elements; its four waves sum a quarter of the slabs each (whole-line loads, four independent chains) and wave 0 adds the four
-// partial sums in a fixed order.  (One thread per element over all slabs left conv1's 35 k-element, ~85-slab reduction at 40 us.)
+// out[e] = sum_s slab[s][e] (+bias[e % n_cols]) (relu) (mask) : deterministic split reduction.
+// WAYS = 1: one thread per element over all slabs -- few slabs, many elements (a conv layer's weight gradient, split-k products).
+// WAYS = 4: a workgroup owns 64 consecutive elements; its four waves sum a quarter of the slabs each (whole-line loads, four
+// independent chains) and wave 0 adds the four partial sums in a fixed order -- many slabs, few elements (conv1's 35 k-element,
+// ~85-slab reduction took 40 us with one thread per element, 6 us this way).
+template <int WAYS>
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ ws, float* __restrict__ out, int64_t count, int splits,
                                                           int64_t slab_stride, const float* __restrict__ bias, int ncols, int64_t ldc,
                                                           int relu, const float* __restrict__ mask) {
     __shared__ float part[3][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int per = (splits + 3) >> 2;
-    const int z0 = w * per, z1 = min(splits, z0 + per);
-    for (int64_t e0 = (int64_t)blockIdx.x * 64; e0 < count; e0 += (int64_t)gridDim.x * 64) {
-        const int64_t e = e0 + lane;
+    constexpr int EPB = WAYS == 4 ? 64 : 256;                      // elements per workgroup
+    const int per = WAYS == 4 ? (splits + 3) >> 2 : splits;
+    const int z0 = WAYS == 4 ? w * per : 0, z1 = min(splits, z0 + per);
+    for (int64_t e0 = (int64_t)blockIdx.x * EPB; e0 < count; e0 += (int64_t)gridDim.x * EPB) {
+        const int64_t e = e0 + (WAYS == 4 ? lane : (int)threadIdx.x);
         float s = 0.f;
         if (e < count) {
             const float* p = ws + (int64_t)z0 * slab_stride + e;
@@ -1855,10 +1859,12 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
             }
             for (; z < z1; ++z, p += slab_stride) s += p[0];
         }
-        if (w > 0) part[w - 1][lane] = s;
-        __syncthreads();
-        if (w == 0 && e < count) {
-            s = (s + part[0][lane]) + (part[1][lane] + part[2][lane]);
+        if constexpr (WAYS == 4) {
+            if (w > 0) part[w - 1][lane] = s;
+            __syncthreads();
+            if (w == 0) s = (s + part[0][lane]) + (part[1][lane] + part[2][lane]);
+        }
+        if ((WAYS == 1 || w == 0) && e < count) {
             int64_t o = e;
             if (ncols > 0) {
                 const int64_t row = e / ncols;
@@ -1870,11 +1876,22 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
             if (mask) s = mask[o] > 0.f ? s : 0.f;
             out[o] = s;
         }
-        __syncthreads();
+        if constexpr (WAYS == 4) __syncthreads();
     }
 }
 
-static int reduce_blocks(int64_t count) { return (int)((count + 63) / 64 < 16384 ? (count + 63) / 64 : 16384); }
+static void launch_reduce_slabs(hipStream_t s, const float* ws, float* out, int64_t count, int splits, int64_t slab_stride, const float* bias,
+                                int ncols, int64_t ldc, int relu, const float* mask) {
+    static const int force = getenv("VL_REDUCE_WAYS") ? atoi(getenv("VL_REDUCE_WAYS")) : 0;      // A/B: 1 or 4
+    const bool four = force ? force == 4 : (splits >= 16 && count * 4 <= (int64_t)splits * 65536);
+    if (four) {
+        const int blocks = (int)((count + 63) / 64 < 16384 ? (count + 63) / 64 : 16384);
+        hipLaunchKernelGGL(reduce_slabs_kernel<4>, dim3(blocks), dim3(256), 0, s, ws, out, count, splits, slab_stride, bias, ncols, ldc, relu, mask);
+    } else {
+        const int blocks = (int)((count + 255) / 256 < 4096 ? (count + 255) / 256 : 4096);
+        hipLaunchKernelGGL(reduce_slabs_kernel<1>, dim3(blocks), dim3(256), 0, s, ws, out, count, splits, slab_stride, bias, ncols, ldc, relu, mask);
+    }
+}
 
 // A/B switches for measurements, read once: VL_CONV_STAGED=1 runs conv forward / dgrad on the register-staged mfma_contract
 // template instead of the LDS-DMA kernels, VL_GEMM_NOSPLIT=1 disables the split-K of small dense GEMMs.
@@ -2580,8 +2597,30 @@ __global__ __launch_bounds__(256) void conv_wt_transpose_kernel(const float* __r
     }
 }
 
+__global__ void conv_wt_transpose_old_kernel(const float* __restrict__ w, float* __restrict__ wt, int KH, int KW, int cig,
+                                             int cog, int groups) {
+    const int cin = cig * groups, cout = cog * groups;
+    const int64_t total = (int64_t)KH * KW * cog * cin;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int cc = (int)(e % cin);
+        const int co = (int)((e / cin) % cog);
+        const int kx = (int)((e / ((int64_t)cin * cog)) % KW);
+        const int ky = (int)(e / ((int64_t)cin * cog * KW));
+        const int g = cc / cig, ci = cc % cig;
+        wt[e] = w[(((int64_t)(KH - 1 - ky) * KW + (KW - 1 - kx)) * cig + ci) * cout + g * cog + co];
+    }
+}
+
 extern "C" int vl_conv_wt_transpose(const vl_conv_desc* d, const float* w, float* wt, vl_stream_t stream) {
     VL_CHECK(d && w && wt, "vl_conv_wt_transpose: null argument");
+    static const bool oldk = getenv("VL_WT_OLD") != nullptr;
+    if (oldk) {
+        const int64_t total = (int64_t)d->kh * d->kw * d->cog * d->cin;
+        const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+        hipLaunchKernelGGL(conv_wt_transpose_old_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, wt, d->kh, d->kw, d->cig,
+                           d->cog, d->groups);
+        return 0;
+    }
     const int blocks = d->kh * d->kw * d->groups * ((d->cig + 63) / 64) * ((d->cog + 63) / 64);
     hipLaunchKernelGGL(conv_wt_transpose_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, wt, d->kh, d->kw, d->cig,
                        d->cog, d->groups);
@@ -2616,8 +2655,7 @@ static void dy_params(const vl_conv_desc* d, const ConvGeom& g, const float* dy,
 static int reduce_wgrad(const vl_conv_desc* d, float* dw, const float* ws, int splits, hipStream_t s) {
     const int64_t slab = (int64_t)d->K * d->cout;
     if (splits > 1) {
-        const int blocks = reduce_blocks(slab);
-        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, s, ws, dw, slab, splits, slab, nullptr, 0, 0, 0, nullptr);
+        launch_reduce_slabs(s, ws, dw, slab, splits, slab, nullptr, 0, 0, 0, nullptr);
         VL_LAUNCH_CHECK();
     }
     return 0;
@@ -2676,8 +2714,7 @@ static int launch_wgrad_dma(const vl_conv_desc* d, const ConvGeom& g, const floa
                        ceil_div(rtiles, splits), db_slabs, d->cout);
     VL_LAUNCH_CHECK();
     if (db && splits > 1) {
-        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(reduce_blocks(d->cout)), dim3(256), 0, s, db_slabs, db, (int64_t)d->cout, splits,
-                           (int64_t)d->cout, nullptr, 0, 0, 0, nullptr);
+        launch_reduce_slabs(s, db_slabs, db, (int64_t)d->cout, splits, (int64_t)d->cout, nullptr, 0, 0, 0, nullptr);
         VL_LAUNCH_CHECK();
     }
     return reduce_wgrad(d, dw, ws, splits, s);
@@ -2773,8 +2810,7 @@ static int launch_gemm(int m, int n, int k, const float* a, int64_t lda, const f
     VL_LAUNCH_CHECK();
     if (splits > 1) {
         const int64_t cnt = (int64_t)m * n;
-        const int blocks = reduce_blocks(cnt);
-        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, s, ws, c, cnt, splits, cnt, bias, n, ldc, relu, mask);
+        launch_reduce_slabs(s, ws, c, cnt, splits, cnt, bias, n, ldc, relu, mask);
         VL_LAUNCH_CHECK();
     }
     return 0;
@@ -3026,9 +3062,7 @@ static int launch_gemm_split(int transa, int transb, int m, int n, int k, const 
     VL_LAUNCH_CHECK();
     if (splits > 1) {
         const int64_t count = (int64_t)m * n;
-        const int blocks = reduce_blocks(count);
-        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, s, slabs, c, count, splits, count, bias, n, ldc, relu,
-                           relu_mask);
+        launch_reduce_slabs(s, slabs, c, count, splits, count, bias, n, ldc, relu, relu_mask);
         VL_LAUNCH_CHECK();
     }
     return 0;

@@ -621,6 +621,16 @@ class LRCNEngine:
         self._frames_now = n
         D, C, H, T = cfg.encode_dim(), cfg.num_classes, cfg.lstm_hidden, self.T
         sw = self.small_ws
+        side = self._side_stream()
+        if side is not None:
+            # the flipped / transposed weights every dgrad reads, all layers now, on the second stream (idle until fc6): a transpose
+            # in front of its dgrad sits on the backward's critical chain while the weight gradient on the other stream takes the CUs
+            # (round 3, same box: 8 clips 5.71 -> 5.42 ms, 16 clips 9.90 -> 9.81, 64 clips on two streams 35.25 -> 35.05; which of
+            # dgrad / wgrad the host issues first made no difference)
+            side.wait_stream(torch.cuda.current_stream(self.dev))
+            with torch.cuda.stream(side):
+                for L in self.layers[1:]:
+                    L["conv"].wt_transpose(P["dcnn/%sW" % L["name"]], L["wt"])
         if cfg.classifier == "lstm":
             d, r = self.dlogits, self._rows
             if H != C:
@@ -759,6 +769,7 @@ class LRCNEngine:
         # ---- conv stack, last to first
         side = self._side_stream()
 
+
         def on_side(launch):
             side.wait_stream(torch.cuda.current_stream(self.dev))
             with torch.cuda.stream(side):
@@ -819,31 +830,36 @@ class LRCNEngine:
                 on_side(wgrad)                        # beside this layer's dgrad / the next pool backward
             if li > 0:
                 prev = self.layers[li - 1]
-                conv.wt_transpose(P["dcnn/%sW" % name], self.wt)
-                if prev["pool"]:
-                    self._run(name + ".dgrad", conv.dgrad, dy, self.wt, prev["dp"][:n])     # into the pool output gradient
+                wt = self.wt
+                if side is not None:
+                    wt = L["wt"]                      # transposed at the start of the backward pass
                 else:
-                    self._run(name + ".dgrad", conv.dgrad, dy, self.wt, prev["dy"][:n], relu_mask=prev["y"][:n])
+                    conv.wt_transpose(P["dcnn/%sW" % name], wt)
+                if prev["pool"]:
+                    self._run(name + ".dgrad", conv.dgrad, dy, wt, prev["dp"][:n])     # into the pool output gradient
+                else:
+                    self._run(name + ".dgrad", conv.dgrad, dy, wt, prev["dy"][:n], relu_mask=prev["y"][:n])
         if side is not None:
             torch.cuda.current_stream(self.dev).wait_stream(side)
         if self.dp is not None:
             self.dp.reduce_async(self.g, *self.grad_chunks[-1])
 
     def _side_stream(self):
-        """Second HIP stream of the backward pass, or None.  Independent launches (a layer's weight gradient beside its input
-        gradient and the next pool / LRN backward; fc6's input gradient beside its weight-gradient blocks) fill the CUs a small
-        launch leaves idle: an 8-clip shard steps 4 % faster, 16 / 32 clips 2 %, 64 clips 1.3 %.  VLTF_WGRAD_STREAM=1 / 0 forces it;
-        unset = on for shards of at most 512 frames (where launches underfill the chip), off for the full batch: there the gain is
-        inside the box-to-box spread and costs the per-kernel timings (a bracket or a rocprof average of a launch that has a
-        neighbour times both).  Round 3 measured two other schedules at 64 clips (35.75 ms on one stream, 35.3 with every weight
-        gradient beside its input gradient): conv5..conv3's weight gradients held back until conv2's pool / LRN backward, to hide
-        that HBM-bound kernel under MFMA-bound ones -- 35.8 ms, next to a 135 KB-of-LDS wgrad workgroup a CU holds ONE pool / LRN
-        workgroup, which then crawls (1.33 ms instead of 0.65) while the chain of input gradients waits for it; and conv3's two
-        launches each alone (its dgrad is the step's dominant symbol) with the others paired -- 35.85 ms, the joins cost what the
-        pairs win.  The fp32 path only."""
-        mode = os.environ.get("VLTF_WGRAD_STREAM", "")
-        on = mode == "1" or (mode == "" and getattr(self, "_frames_now", 1 << 30) <= 512)
-        if not on or self.cfg.conv_math != "f32":
+        """Second HIP stream of the backward pass, or None (VLTF_WGRAD_STREAM=0; the bf16 path).  Independent launches -- the dgrad
+        weight transposes at the start of the pass, fc6's input gradient beside its weight-gradient blocks, a layer's weight gradient
+        beside its input gradient and the next pool / LRN backward -- fill the CUs the tail of a launch leaves idle: same box, one
+        stream -> two: 8 clips 5.71 -> 5.42 ms, 16 clips 10.1 -> 9.81, 32 clips 18.5 -> 18.2, 64 clips 35.64 -> 35.05 (round 3, once the
+        transposes had left the critical chain; round 2 kept the full batch on one stream for a gain of 0.4 ms).  A bracket or a
+        rocprof average of a launch that has a neighbour times both: bench.py takes its per-launch table from extra steps with
+        VLTF_WGRAD_STREAM=0 and the dominant symbol, live, from its forward launches, which always run alone.
+        Other schedules measured at 64 clips and dropped (35.75 ms on one stream then): conv5..conv3's weight gradients held back
+        until conv2's pool / LRN backward, to hide that HBM-bound kernel under MFMA-bound ones -- 35.8 ms, next to a 135 KB-of-LDS
+        wgrad workgroup a CU holds ONE pool / LRN workgroup, which then crawls (1.33 ms instead of 0.65) while the chain of input
+        gradients waits for it; conv3's two launches each alone with the others paired -- 35.85, the joins cost what the pairs
+        win; only conv2's weight gradient on the second stream, behind conv2's input gradient, so that it runs beside conv1's pool /
+        LRN backward (off the critical chain) -- 36.03: an HBM-bound kernel beside an MFMA-bound one costs the latter more than it
+        hides; which of dgrad / wgrad the host issues first: no difference."""
+        if os.environ.get("VLTF_WGRAD_STREAM", "") == "0" or self.cfg.conv_math != "f32":
             return None
         if getattr(self, "_side", None) is None:
             self._side = torch.cuda.Stream(device=self.dev)
@@ -852,6 +868,8 @@ class LRCNEngine:
             # THESE buffers, never from self.ws / self.small_ws -- so no main-stream launch between the fork and the join can race it.
             self.ws_side = torch.empty_like(self.ws)              # wgrad slabs / split-k slabs of what runs on the side stream
             self.small_ws_side = torch.empty_like(self.small_ws)
+            for L in self.layers[1:]:
+                L["wt"] = torch.empty(L["conv"].w_shape, device=self.dev).view(-1)
         return self._side
 
     def _pool_bwd(self, L, n, dx, relu_mask, dx_halo):
