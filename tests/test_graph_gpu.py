@@ -186,3 +186,36 @@ def test_two_rank_two_stream_step_equals_one_rank():
     tag, worst, gn_err, issued, nchunks = q.get(timeout=10)
     assert tag == "ok" and issued == nchunks and nchunks >= 5, (issued, nchunks)
     assert worst < 1e-3 and gn_err < 1e-5, (worst, gn_err)
+
+
+def test_two_stream_backward_under_allocator_churn():
+    """The towers' backward runs its parameter gradients and the dgrad weight transposes on a second stream (engine._side_stream).
+    A missing dependency there shows only when the streams drift apart -- tiny launches, fresh buffers -- and only now and then (one
+    in a hundred steps, round 3: the first dgrad read weights the other stream had not finished transposing).  So: many FRESH
+    engines of the two-tower graphs, the caching allocator perturbed between them with blocks of large values (stale memory must not
+    look like zeros), every gradient of every step against the oracle."""
+    from vltf_amd.graph import GraphEngine
+    rng = np.random.default_rng(0)
+    names = ["two_stream_concat", "two_stream_avg", "fused_frames_avg", "dcnn_with_state"]
+    want, junk = {}, []
+    for it in range(80):
+        name = names[it % len(names)]
+        case = GC.CASES[name]()
+        pipes, ds = GC.specs_and_datasets(case)
+        junk.append(torch.full((int(rng.integers(1, 64)) << 18,), 1e3, device=DEV))
+        if len(junk) > 6:
+            del junk[int(rng.integers(0, len(junk)))]
+        eng = GraphEngine(pipes, ds, case["V"], device=DEV)
+        p = eng.init_params(seed=case["seed"], well_scaled=True)
+        raw, feeds = GC.inputs(case)
+        if name not in want:
+            want[name] = GC.expect(case, p, feeds)
+        _, onehot, loss, grads, _ = want[name]
+        eng.load_params(p)
+        out = eng.train_step(device_feeds(raw), torch.from_numpy(onehot).to(DEV), lr=0.01, clip_norm=0.5)
+        assert abs(out["loss"] - loss) < 1e-4 * max(1, abs(loss)), (it, name)
+        g = eng.get_grads()
+        for k in p:
+            scale = np.abs(grads[k]).max() + 1e-12
+            np.testing.assert_allclose(g[k], grads[k], rtol=2e-3, atol=2e-4 * scale, err_msg="iteration %d, %s, grad %s" % (it, name, k))
+        del eng
