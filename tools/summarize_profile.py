@@ -5,6 +5,7 @@
 
 Writes
   <prefix>_kernel_stats.csv      per-kernel calls / total / average / share  (the `--stats` summary of the bench command)
+  <prefix>_kernel_stats_alone.csv  the same averages over the launches that ran with no other kernel in flight (two-stream backward)
   <prefix>_hbm_traffic.csv       per-kernel FETCH_SIZE and WRITE_SIZE per launch (separate --pmc passes), with the
                                  gfx950 correction of MI355X_MICROARCH.md "HBM" (FETCH_SIZE x 2) and the two
                                  kernels of the same run whose byte counts are known exactly as calibration rows
@@ -52,6 +53,39 @@ def kernel_stats(con, out):
     return {short(n): (c, a) for n, c, t, a, mn, mx in rows}
 
 
+def alone_stats(con, out):
+    """Per kernel: launches that ran with NO other kernel in flight (by start / end time stamps) -- the backward's two streams put a
+    neighbour beside many launches, and a launch that shares the chip reads longer; the roofline of a symbol is the time of its
+    launches that ran alone (bench.py measures the dominant symbol on those too)."""
+    rows = con.execute("select name, start, end from kernels order by start").fetchall()
+    import bisect
+    starts = [r[1] for r in rows]
+    # running maximum of the end times of earlier launches
+    agg = {}
+    max_end = 0
+    prev_max = []
+    for n, s, e in rows:
+        prev_max.append(max_end)
+        max_end = max(max_end, e)
+    for i, (n, s, e) in enumerate(rows):
+        overl = prev_max[i] > s                                   # an earlier launch still running
+        j = bisect.bisect_right(starts, s, lo=i + 1)              # launches starting at the same time stamp
+        k = bisect.bisect_left(starts, e, lo=i + 1)               # later launches that start before this one ends
+        overl = overl or k > i + 1 or j > i + 1
+        a = agg.setdefault(short(n), [0, 0, 0, 0])
+        a[0] += 1
+        a[1] += e - s
+        if not overl:
+            a[2] += 1
+            a[3] += e - s
+    with open(out, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "Calls", "AverageNs", "CallsAlone", "AverageNsAlone"])
+        for n, (c, t, ca, ta) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            w.writerow([n, c, round(t / c, 1), ca, round(ta / ca, 1) if ca else ""])
+    return agg
+
+
 def counter_avgs(con, counter):
     q = ("select kernel_name, count(*), avg(value) from counters_collection where counter_name = ? group by kernel_name")
     return {short(n): (c, v) for n, c, v in con.execute(q, (counter,))}
@@ -64,6 +98,10 @@ def main():
     con = db(os.path.join(src, prof))
     if con:
         stats = kernel_stats(con, prefix + "_kernel_stats.csv")
+        alone = alone_stats(con, prefix + "_kernel_stats_alone.csv")
+        for n, (c, t, ca, ta) in alone.items():
+            if n.startswith(DOMINANT):
+                print("%s: %d launches, average %.1f us; %d ran alone, average %.1f us" % (n, c, t / c / 1e3, ca, ta / max(ca, 1) / 1e3))
     cf, cw = db(os.path.join(src, "pmc_fetch")), db(os.path.join(src, "pmc_write"))
     if cf and cw:
         fetch, write = counter_avgs(cf, "FETCH_SIZE"), counter_avgs(cw, "WRITE_SIZE")
