@@ -2597,30 +2597,8 @@ __global__ __launch_bounds__(256) void conv_wt_transpose_kernel(const float* __r
     }
 }
 
-__global__ void conv_wt_transpose_old_kernel(const float* __restrict__ w, float* __restrict__ wt, int KH, int KW, int cig,
-                                             int cog, int groups) {
-    const int cin = cig * groups, cout = cog * groups;
-    const int64_t total = (int64_t)KH * KW * cog * cin;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int cc = (int)(e % cin);
-        const int co = (int)((e / cin) % cog);
-        const int kx = (int)((e / ((int64_t)cin * cog)) % KW);
-        const int ky = (int)(e / ((int64_t)cin * cog * KW));
-        const int g = cc / cig, ci = cc % cig;
-        wt[e] = w[(((int64_t)(KH - 1 - ky) * KW + (KW - 1 - kx)) * cig + ci) * cout + g * cog + co];
-    }
-}
-
 extern "C" int vl_conv_wt_transpose(const vl_conv_desc* d, const float* w, float* wt, vl_stream_t stream) {
     VL_CHECK(d && w && wt, "vl_conv_wt_transpose: null argument");
-    static const bool oldk = getenv("VL_WT_OLD") != nullptr;
-    if (oldk) {
-        const int64_t total = (int64_t)d->kh * d->kw * d->cog * d->cin;
-        const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-        hipLaunchKernelGGL(conv_wt_transpose_old_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, wt, d->kh, d->kw, d->cig,
-                           d->cog, d->groups);
-        return 0;
-    }
     const int blocks = d->kh * d->kw * d->groups * ((d->cig + 63) / 64) * ((d->cog + 63) / 64);
     hipLaunchKernelGGL(conv_wt_transpose_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, wt, d->kh, d->kw, d->cig,
                        d->cog, d->groups);
