@@ -282,3 +282,37 @@ def test_engine_reports_an_lstm_cluster_timeout():
     eng.load_params(p)
     out = eng.train_step_u8(frames, onehot, lr=0.0, clip_norm=0.0, mean_bgr=MEAN)
     assert np.isfinite(out["loss"])
+
+
+def test_two_stream_backward_of_the_lstm_pipeline_under_allocator_churn():
+    """The single-pipeline LRCN (dcnn -> LSTM, 1 and 2 layers) on its default two-stream backward: head, LSTM, fc6 and conv parameter
+    gradients and the dgrad weight transposes run on the second stream.  Many FRESH engines with the caching allocator perturbed
+    between them (blocks of large stale values), every gradient of every step against the oracle -- the kind of test that found a
+    one-in-a-hundred missing dependency in round 3 (tests/test_graph_gpu.py::test_two_stream_backward_under_allocator_churn)."""
+    rng = np.random.default_rng(11)
+    shape, ncls, fpc, b = (67, 67, 3), 7, 3, 2
+    frames = rng.integers(0, 256, (b * fpc,) + shape, dtype=np.uint8)
+    lab = rng.integers(0, ncls, b)
+    onehot = O.labels_to_one_hot([[l] for l in lab], ncls)
+    x = frames.astype(np.float32) - MEAN
+    fd, od = torch.tensor(frames, device=DEV), torch.tensor(onehot, device=DEV)
+    want, junk = {}, []
+    for it in range(60):
+        layers = 1 + it % 2
+        junk.append(torch.full((int(rng.integers(1, 64)) << 18,), 1e3, device=DEV))
+        if len(junk) > 6:
+            del junk[int(rng.integers(0, len(junk)))]
+        cfg, eng = make(dict(num_classes=ncls, fpc=fpc, lstm_hidden=8, lstm_layers=layers), shape, b)
+        if layers not in want:
+            p = oracle_params(np.random.default_rng(5 + layers), cfg, shape)
+            want[layers] = (p,) + O.lrcn_train_step(p, x, onehot, fpc, lr=0.01, clip_norm=0.5, lstm_layers=layers)
+        p, newp, loss, gn, acc, logits, grads = want[layers]
+        eng.load_params(p)
+        out = eng.train_step_u8(fd, od, lr=0.01, clip_norm=0.5, mean_bgr=MEAN)
+        assert eng._side_stream() is not None
+        assert abs(out["loss"] - loss) < 1e-4 * max(1, abs(loss)), it
+        g = eng.get_grads()
+        for k in p:
+            scale = np.abs(grads[k]).max() + 1e-12
+            np.testing.assert_allclose(g[k], grads[k], rtol=2e-3, atol=2e-4 * scale, err_msg="iteration %d, grad %s" % (it, k))
+        del eng
