@@ -2721,6 +2721,10 @@ static int wgrad_splits(const vl_conv_desc* d, int n) {
     // (rounds of the chip) x (tiles per workgroup + ~2 tiles of prologue / epilogue) over split counts that give every XCD
     // the same number of units; slabs are capped at 512 MB.
     const int rtiles = ceil_div(M, 64);
+    if (const char* e = getenv("VL_WGRAD_SPLITS")) {                 // experiments: force the split count
+        const int s = atoi(e);
+        if (s >= 1 && s <= rtiles) return s;
+    }
     const int per_xcd = device_cus() / 8 > 0 ? device_cus() / 8 : 1;
     const int64_t slab_bytes = ((int64_t)d->K + 1) * d->cout * 4;
     int best = 1;
