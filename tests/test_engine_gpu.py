@@ -1,6 +1,8 @@
 """End-to-end parity of the two executor calls (forward logits, one clipped-SGD train step)
 against the CPU oracle on identical inputs.  Tolerance: north_star's 1e-3 on logits with
 well-scaled weights; parameters after the step to 1e-4 relative."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -309,7 +311,7 @@ def test_two_stream_backward_of_the_lstm_pipeline_under_allocator_churn():
         p, newp, loss, gn, acc, logits, grads = want[layers]
         eng.load_params(p)
         out = eng.train_step_u8(fd, od, lr=0.01, clip_norm=0.5, mean_bgr=MEAN)
-        assert eng._side_stream() is not None
+        assert (eng._side_stream() is not None) == (os.environ.get("VLTF_WGRAD_STREAM", "") != "0")
         assert abs(out["loss"] - loss) < 1e-4 * max(1, abs(loss)), it
         g = eng.get_grads()
         for k in p:
