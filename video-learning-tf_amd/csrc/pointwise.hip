@@ -477,6 +477,14 @@ __global__ __launch_bounds__(256, (C8 ? 3 : 1)) void pool_lrn_bwd_stream_kernel(
     };
 
     const int nchunks = (R1 + 4 - cs + CHK - 1) / CHK;
+    // The pad entries of both buffers (8 in front: "entry -1" of a band's first pooled row; 8 behind) are READ by pixels whose window
+    // does not exist and rejected only by their arg-max word never equalling wloc = 254 -- so they must not hold stale LDS bytes:
+    // beside a kernel that leaves 0xfe words in LDS (the split-bf16 wgrad on a second stream) one step in three had ~170 of 67 M
+    // gradient elements pick up a stale "dp" (round 3).  {0, 255} matches no window.
+    if (threadIdx.x < 32) {
+        const int t = threadIdx.x & 15, b2 = threadIdx.x >> 4;
+        stage[b2 * BUF + (t < 8 ? t : NST * 256 + t)] = make_uint2(0u, 255u);
+    }
     stage_load(cs);
     x_load(cs, xa);
     stage_write(0);

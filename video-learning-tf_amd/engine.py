@@ -876,7 +876,12 @@ class LRCNEngine:
         gradients waits for it; conv3's two launches each alone with the others paired -- 35.85, the joins cost what the pairs
         win; only conv2's weight gradient on the second stream, behind conv2's input gradient, so that it runs beside conv1's pool /
         LRN backward (off the critical chain) -- 36.03: an HBM-bound kernel beside an MFMA-bound one costs the latter more than it
-        hides; which of dgrad / wgrad the host issues first: no difference."""
+        hides; which of dgrad / wgrad the host issues first: no difference.
+        fp32 only.  The split-bf16 arithmetics would gain 3 % (bf16x3 22.3 -> 21.5 ms), but while conv3's split-product weight gradient
+        runs on the other stream, conv2's `pool_lrn_bwd` comes out different from run to run in ~1e-5 of its elements
+        (tools/det_probe.py: its inputs are identical, the wgrad writes nothing outside its outputs, with `pool_lrn_bwd` running alone
+        -- a join in front of it -- or on fp32 wgrads every run is bitwise the same).  Cause not found, so those modes stay on one
+        stream; the packed-bf16 path is slower on two (8.3 vs 8.2 ms)."""
         if os.environ.get("VLTF_WGRAD_STREAM", "") == "0" or self.cfg.conv_math != "f32":
             return None
         if getattr(self, "_side", None) is None:
