@@ -198,6 +198,28 @@ def test_benchmark_job_matches_oracle_fixture(name):
             assert np.array_equal(p1[k], p2[k]), "updated %s differs" % k
 
 
+def test_two_stream_step_is_bitwise_reproducible():
+    """The default (two-stream) fp32 step at full geometry, the same step from the same parameters six times: every gradient bitwise
+    equal to the first run's -- what tools/det_probe.py checks by hand (round 3: the split-bf16 arithmetics are NOT reproducible on
+    two streams, which is why they stay on one)."""
+    from vltf_amd.engine import LRCNEngine
+    cfg, p, frames, onehot = case_inputs("c3shard_ref")
+    clips = CASES["c3shard_ref"][0]
+    eng = LRCNEngine(cfg, max_clips=clips, device=DEV)
+    fd, od = torch.from_numpy(frames).to(DEV), torch.from_numpy(onehot).to(DEV)
+    ref = None
+    for rep in range(6):
+        eng.load_params(p)
+        out = eng.train_step_u8(fd, od, lr=LR, clip_norm=CLIP, mean_bgr=MEAN)
+        g = eng.get_grads()
+        if ref is None:
+            ref = (out, g)
+            continue
+        assert out["loss"] == ref[0]["loss"] and out["grad_norm"] == ref[0]["grad_norm"], rep
+        for k in p:
+            assert np.array_equal(g[k], ref[1][k]), "run %d: gradient %s differs from the first run" % (rep, k)
+
+
 def check_step_against_fixture(gold, name, p, clips, out, got_logits, g, newp, grad_scale=1.0):
     """One train step's outputs against the fixture case `name`.  grad_scale: constant factor between the step's gradients and
     the fixture's (a rank's shard of a larger global batch scales its loss by local / global rows); with it != 1 the update heads
