@@ -504,6 +504,11 @@ __global__ __launch_bounds__(256, (C8 ? 3 : 1)) void pool_lrn_bwd_stream_kernel(
     }
 }
 
+static size_t plb_extra_lds() {       // experiment: dynamic LDS the kernel never touches, to keep other workgroups off its CU
+    static const size_t v = getenv("VL_PLB_EXTRA_LDS") ? (size_t)atoi(getenv("VL_PLB_EXTRA_LDS")) : 0;
+    return v;
+}
+
 // Channel ranges per (band, image) of the channel-stream backward: the count (<= 4) with the fewest rounds x channels walked, a
 // round = 8 workgroups per CU (56 VGPRs, 12.5 KB of LDS).  `unit`: ranges start at multiples of it (8 for the packed output).
 static int plb_channel_ranges(int64_t workgroups, int c, int unit, int* cper) {
@@ -549,7 +554,7 @@ extern "C" int vl_pool_lrn_bwd(const float* x, const float* dp, const uint8_t* a
 #define VL_PLB_LAUNCH(CHK, NST)                                                                                                     \
     do {                                                                                                                            \
         if (relu_fused)                                                                                                             \
-            hipLaunchKernelGGL((pool_lrn_bwd_stream_kernel<CHK, NST, true, 0>), grid, dim3(256), 0, (hipStream_t)stream, x, dp + origin, \
+            hipLaunchKernelGGL((pool_lrn_bwd_stream_kernel<CHK, NST, true, 0>), grid, dim3(256), plb_extra_lds(), (hipStream_t)stream, x, dp + origin, \
                                argmax + origin, dx, c, h, w, oh, ow, psn, (int)pplane, owp, pooled_f, alpha, bias, dx_halo, cper);  \
         else                                                                                                                        \
             hipLaunchKernelGGL((pool_lrn_bwd_stream_kernel<CHK, NST, false, 0>), grid, dim3(256), 0, (hipStream_t)stream, x, dp + origin, \
