@@ -18,7 +18,7 @@
  *     [kh][kw][cin/group][cout] (alexnet.py:73,113), fc weights [in][out] (alexnet.py:225),
  *     LSTM kernel [D+H][4H] with gate order i, j, f, o (TF BasicLSTMCell; lstm.py:17).
  *   - Thread-compatible: one stream/descriptor set per host thread (exceptions, both process-wide words: vl_set_conv_math
- *     and the test hooks vl_lstm_seq_test_hooks).
+ *     and the test hooks vl_lstm_seq_test_hooks, vl_pool_lrn_bwd_test_ranges).
  */
 #ifndef VLTF_H
 #define VLTF_H
@@ -191,6 +191,10 @@ int vl_pool_lrn_bwd(const float* x, const float* dp, const uint8_t* argmax, floa
  * as well, c8 without a halo, as the producing conv's epilogue writes it. */
 int vl_pool_lrn_bwd_c8(const void* x, int x_packed, const float* dp, const uint8_t* argmax, void* dxb, int n, int c, int h, int w,
                        int p_halo, int radius, float alpha, float beta, float bias, int relu_fused, int dxb_halo, vl_stream_t stream);
+
+/* Test hook of vl_pool_lrn_bwd / vl_pool_lrn_bwd_c8, process-wide: force the number of channel ranges a (band, image) is split into
+ * (1..4; fewer where the channel count does not allow it); 0 = the launcher's cost model (the default). */
+int vl_pool_lrn_bwd_test_ranges(int ranges);
 
 /* Fused forward of [LRN -> max_pool 3x3/2 VALID] (alexnet.py:79-98,120-139): p = max_pool(lrn(x)), argmax = window-local
  * index (0..8) of the first maximum in scan order; the LRN output is never written (vl_pool_lrn_bwd needs only x).

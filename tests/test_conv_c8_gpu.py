@@ -241,10 +241,11 @@ def test_frames_straight_into_the_packed_input(ops):
 
 @pytest.mark.parametrize("n,h,w,c,halo", [(2, 9, 7, 96, 1), (3, 13, 13, 256, 2), (2, 27, 27, 16, 1), (1, 55, 55, 96, 1)])
 @pytest.mark.parametrize("relu,ranges", [(True, ""), (False, ""), (True, "1"), (True, "3")])
-def test_pool_lrn_bwd_packed_output(ops, monkeypatch, n, h, w, c, halo, relu, ranges):
+def test_pool_lrn_bwd_packed_output(ops, request, n, h, w, c, halo, relu, ranges):
     """vl_pool_lrn_bwd_c8 = vl_pool_lrn_bwd with the result rounded to bf16 into the c8 layout (same arithmetic before the rounding);
-    VL_PLB_RANGES: the count of channel ranges both kernels split a (band, image) into (multiples of 8 channels for the packed one)."""
-    monkeypatch.setenv("VL_PLB_RANGES", ranges) if ranges else monkeypatch.delenv("VL_PLB_RANGES", raising=False)
+    `ranges`: the forced count of channel ranges both kernels split a (band, image) into (multiples of 8 channels for the packed one)."""
+    ops.pool_lrn_bwd_test_ranges(int(ranges or 0))
+    request.addfinalizer(lambda: ops.pool_lrn_bwd_test_ranges(0))
     rng = np.random.default_rng(c + h)
     x = torch.from_numpy(np.maximum(rng.standard_normal((n, c, h, w)) * 30, 0).astype(np.float32)).to(DEV)
     oh, ow = ops.pool_out(h), ops.pool_out(w)

@@ -375,13 +375,52 @@ def test_pool_lrn_bwd_fused(ops, n, h, w, c, ph, dh):
         assert float(dx[:, :, :dh].abs().max()) == 0
 
 
+def test_pool_lrn_bwd_is_bitwise_stable_beside_a_split_bf16_weight_gradient(ops):
+    """Round 3's open defect in isolation (tools/plb_race_probe.py): conv2's pool / LRN backward on the main stream while conv3's
+    split-bf16 weight gradient (v_cvt_pk / v_pk_add + bf16 MFMAs) runs on a second stream must give, bit for bit, what it gives alone.
+    With hipcc's SLP-vectorised code (two `v_pk_add_f32 ... op_sel:[0,1]` in the kernel) about 1200 of 51 M elements differed per launch,
+    all in lanes 48..63; the build now has no such instruction (tests/test_isa_lint.py)."""
+    n = 128
+    torch.manual_seed(0)
+    y2 = torch.relu(torch.randn(n, 256, 28, 28, device=DEV) * 70.0).contiguous()
+    p2 = torch.zeros(n, 256, 15, 15, device=DEV)
+    arg2 = torch.zeros(n, 256, 15, 15, device=DEV, dtype=torch.uint8)
+    ops.lrn_pool_fwd(y2, p2, arg2, p_halo=1)
+    dp2 = torch.zeros_like(p2)
+    dp2[:, :, 1:-1, 1:-1] = torch.randn(n, 256, 13, 13, device=DEV) * 1e-6
+    dy2 = torch.zeros(n, 256, 32, 32, device=DEV)
+    conv3 = ops.Conv(256, 13, 13, 384, 3, 3, 1, 1)
+    conv3.set_halo(1, 1, 1, 1)
+    dy3 = torch.zeros(n, 384, 15, 15, device=DEV)
+    dy3[:, :, 1:-1, 1:-1] = torch.randn(n, 384, 13, 13, device=DEV) * 1e-3
+    dw3, db3 = torch.zeros(3, 3, 256, 384, device=DEV), torch.zeros(384, device=DEV)
+    side = torch.cuda.Stream()
+    try:
+        ops.set_conv_math("bf16x3")
+        ws = torch.zeros(conv3.wgrad_ws_bytes(n) // 4 + 64, device=DEV)
+        ops.pool_lrn_bwd(y2, dp2, arg2, dy2, p_halo=1, dx_halo=2)
+        torch.cuda.synchronize()
+        ref = dy2.clone()
+        for _ in range(12):
+            dy2.zero_()
+            torch.cuda.synchronize()
+            with torch.cuda.stream(side):
+                conv3.wgrad(p2, dy3, dw3, ws, db3 if conv3.fuses_bias() else None)
+            ops.pool_lrn_bwd(y2, dp2, arg2, dy2, p_halo=1, dx_halo=2)
+            torch.cuda.synchronize()
+            assert int((dy2 != ref).sum()) == 0
+    finally:
+        ops.set_conv_math("f32")
+
+
 @pytest.mark.parametrize("ranges", ["1", "2", "3", "4", ""])
 @pytest.mark.parametrize("n,h,w,c,ph,dh", [(2, 55, 55, 96, 2, 0), (3, 27, 27, 256, 1, 2), (2, 13, 13, 33, 1, 1)])
-def test_pool_lrn_bwd_channel_ranges(ops, monkeypatch, ranges, n, h, w, c, ph, dh):
-    """The channel-stream backward split into 1..4 channel ranges per (band, image) (grid z; VL_PLB_RANGES forces the count, unset =
+def test_pool_lrn_bwd_channel_ranges(ops, request, ranges, n, h, w, c, ph, dh):
+    """The channel-stream backward split into 1..4 channel ranges per (band, image) (grid z; the test hook vl_pool_lrn_bwd_test_ranges forces the count, 0 =
     the dispatcher's choice): every range restarts the LRN windows 4 channels early and must reproduce the oracle at its seams --
     AlexNet's two LRN layers (5-channel chunks) and a ragged channel count (16-channel chunks)."""
-    monkeypatch.setenv("VL_PLB_RANGES", ranges) if ranges else monkeypatch.delenv("VL_PLB_RANGES", raising=False)
+    ops.pool_lrn_bwd_test_ranges(int(ranges or 0))
+    request.addfinalizer(lambda: ops.pool_lrn_bwd_test_ranges(0))
     rng = np.random.default_rng(h * c + 1)
     x = np.maximum(rng.standard_normal((n, h, w, c)) * 30, 0).astype(np.float32)
     l, _ = O.lrn(x)

@@ -52,6 +52,7 @@ SIGNATURES = {
     "vl_lrn_bwd": (i32, [p, p, p, i32, i32, i32, i32, f32, f32, f32, i32, i32, i32, p]),
     "vl_lrn_pool_fwd": (i32, [p, p, p, i32, i32, i32, i32, i32, i32, f32, f32, f32, p]),
     "vl_pool_lrn_bwd": (i32, [p, p, p, p, i32, i32, i32, i32, i32, i32, f32, f32, f32, i32, i32, p]),
+    "vl_pool_lrn_bwd_test_ranges": (i32, [i32]),
     "vl_lrn_pool_fwd_c8": (i32, [p, i32, p, p, i32, i32, i32, i32, i32, i32, f32, f32, f32, p]),
     "vl_pool_lrn_bwd_c8": (i32, [p, i32, p, p, p, i32, i32, i32, i32, i32, i32, f32, f32, f32, i32, i32, p]),
     "vl_maxpool_fwd": (i32, [p, p, p, i32, i32, i32, i32, i32, i32, i64, i64, i64, i64, p]),

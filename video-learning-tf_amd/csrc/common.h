@@ -28,6 +28,20 @@ void vl_set_error(const char* fmt, ...);
 
 #define VL_LAUNCH_CHECK() VL_HIP(hipGetLastError())
 
+// ---- experiment / A-B switches -----------------------------------------------------------------
+// Every such switch is an environment variable read through this helper into a `static const` (once per process).  The product build
+// answers "unset" without looking at the environment; `VL_EXPERIMENTS=1 bash build.sh` builds libvltf_hip_exp.so with them compiled in
+// (tools/: VLTF_HIP_LIB=.../libvltf_hip_exp.so).  Nothing in tests/, bench.py or the package depends on one.
+#include <stdlib.h>
+static inline const char* vl_exp_env(const char* name) {
+#ifdef VL_EXPERIMENTS
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+
 // ---- division by a runtime constant: q = (mulhi(n, m) + n) >> s, valid for n < 2^31 -------------
 struct FastDiv {
     uint32_t d, m, s;

@@ -547,7 +547,7 @@ static int launch_c8e(const C8ConvArgs& a, int groups, hipStream_t stream) {
 
 template <int WP, int WQ, int TP, int TQ>
 static int launch_c8(const C8ConvArgs& a, int groups, hipStream_t stream) {
-    static const bool generic = getenv("VL_C8_GENERIC_EPILOGUE") != nullptr;      // A/B: the run-time-flag epilogue everywhere
+    static const bool generic = vl_exp_env("VL_C8_GENERIC_EPILOGUE") != nullptr;      // A/B: the run-time-flag epilogue everywhere
     const bool y = a.y != nullptr, yb = a.yb != nullptr, mb = a.maskb != nullptr, mf = a.mask != nullptr;
     if (!generic && !mf) {
         if (y && !yb && !mb && a.y_wide) return launch_c8e<WP, WQ, TP, TQ, 1>(a, groups, stream);
@@ -560,13 +560,13 @@ static int launch_c8(const C8ConvArgs& a, int groups, hipStream_t stream) {
 
 // channel tile by the group's channel count: 128-wide tiles, 192 as one tile of 192 (conv4 / conv5 dgrad), 64 for narrow groups
 static int dispatch_c8(C8ConvArgs& a, int groups, hipStream_t stream) {
-    static const int sched = getenv("VL_C8_SCHED") ? atoi(getenv("VL_C8_SCHED")) : 1;      // 0: lockstep fetch issue (A/B)
+    static const int sched = vl_exp_env("VL_C8_SCHED") ? atoi(vl_exp_env("VL_C8_SCHED")) : 1;      // 0: lockstep fetch issue (A/B)
     a.sched = sched;
     if (a.Cog <= 64) return launch_c8<4, 1, 2, 2>(a, groups, stream);          // 256 pixels x 64 channels, 4 waves
     if (a.Cog <= 96) return launch_c8<4, 1, 2, 3>(a, groups, stream);          // 256 x 96 (conv1 as a 3x3 conv over 48 channels)
     // 192-channel groups (conv4 forward, conv4 / conv5 dgrad): two 96-wide tiles of 4 waves, two workgroups per CU (72 KB each), rather
     // than one 192-wide tile of 8 waves that owns the CU (112 KB): 3-6 % faster (VL_C8_Q192=1 runs the wide tile)
-    static const bool q192 = getenv("VL_C8_Q192") != nullptr;
+    static const bool q192 = vl_exp_env("VL_C8_Q192") != nullptr;
     if (a.Cog % 128 != 0 && a.Cog % 192 == 0 && !q192) return launch_c8<4, 1, 2, 3>(a, groups, stream);
     if (a.Cog % 128 != 0 && a.Cog % 192 == 0) return launch_c8<4, 2, 2, 3>(a, groups, stream);   // 256 x 192
     // 256 x 128 on 8 waves of 64 x 64.  Measured alternatives: 128 x 128 tiles of 4 waves, three per CU: 1-4 % slower; 256 x 128 on FOUR
@@ -939,12 +939,12 @@ static int c8_wgrad_plan(const vl_conv_desc* d, int n, C8WgPlan* p) {
     // up to 96 channels (conv1 as a 3x3 conv over 48 channels): 32 taps x 96 with every wave on all 96
     p->tb = 2;
     p->wb = d->cog % 128 == 0 ? 2 : d->cog % 192 == 0 ? 3 : 2;
-    static const bool narrow192 = getenv("VL_C8_WG192_NARROW") != nullptr;   // A/B: 16 taps x 192 channels on 6 waves (8 % slower)
+    static const bool narrow192 = vl_exp_env("VL_C8_WG192_NARROW") != nullptr;   // A/B: 16 taps x 192 channels on 6 waves (8 % slower)
     p->wa = p->wb == 3 ? (narrow192 ? 2 : 4) : 4;
     if (d->cog <= 96 && d->cog > 64) p->wa = 4, p->wb = 1, p->tb = 3;
     // 192-channel groups (conv4): two 96-wide 4-wave tiles of 72 KB -- TWO workgroups per CU -- instead of one 12-wave, 96 KB tile that
     // owns the CU with all its waves in lockstep: 0.349 -> 0.303 ms at 1024 frames (round 3; VL_C8_WG192_WIDE=1 runs the wide tile)
-    static const bool wide192 = getenv("VL_C8_WG192_WIDE") != nullptr;
+    static const bool wide192 = vl_exp_env("VL_C8_WG192_WIDE") != nullptr;
     if (!wide192 && d->cog % 192 == 0) p->wa = 4, p->wb = 1, p->tb = 3;
     const int taps_tile = p->wa * 8, cols_tile = p->wb * p->tb * 32;
     p->tiles_a = (ntaps + taps_tile - 1) / taps_tile;
@@ -973,7 +973,7 @@ extern "C" size_t vl_conv_c8_wgrad_ws_bytes(const vl_conv_desc* d, int n) {
 }
 
 static int c8_wgrad_sched() {
-    static const int v = getenv("VL_C8_WG_SCHED") ? atoi(getenv("VL_C8_WG_SCHED")) : 1;      // 0: lockstep fetch issue (A/B)
+    static const int v = vl_exp_env("VL_C8_WG_SCHED") ? atoi(vl_exp_env("VL_C8_WG_SCHED")) : 1;      // 0: lockstep fetch issue (A/B)
     return v;
 }
 

@@ -407,7 +407,7 @@ int vl_lstm_cluster_run(bool bwd, LstmClusterArgs a, int batch, void* ws, size_t
     return 0;
 }
 
-static const bool kPerClip = getenv("VL_LSTM_PERCLIP") != nullptr;
+static const bool kPerClip = vl_exp_env("VL_LSTM_PERCLIP") != nullptr;
 static size_t perclip_ws_bytes(int H) { return STATUS_BYTES + (size_t)4 * H * H * sizeof(float); }   // kh transposed, for the backward
 
 extern "C" size_t vl_lstm_seq_ws_bytes(int batch, int T, int H) {

@@ -1882,7 +1882,7 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
 
 static void launch_reduce_slabs(hipStream_t s, const float* ws, float* out, int64_t count, int splits, int64_t slab_stride, const float* bias,
                                 int ncols, int64_t ldc, int relu, const float* mask) {
-    static const int force = getenv("VL_REDUCE_WAYS") ? atoi(getenv("VL_REDUCE_WAYS")) : 0;      // A/B: 1 or 4
+    static const int force = vl_exp_env("VL_REDUCE_WAYS") ? atoi(vl_exp_env("VL_REDUCE_WAYS")) : 0;      // A/B: 1 or 4
     const bool four = force ? force == 4 : (splits >= 16 && count * 4 <= (int64_t)splits * 65536);
     if (four) {
         const int blocks = (int)((count + 63) / 64 < 16384 ? (count + 63) / 64 : 16384);
@@ -1895,17 +1895,17 @@ static void launch_reduce_slabs(hipStream_t s, const float* ws, float* out, int6
 
 // A/B switches for measurements, read once: VL_CONV_STAGED=1 runs conv forward / dgrad on the register-staged mfma_contract
 // template instead of the LDS-DMA kernels, VL_GEMM_NOSPLIT=1 disables the split-K of small dense GEMMs.
-static const bool kConvStaged = getenv("VL_CONV_STAGED") != nullptr;
-static const bool kGemmNoSplit = getenv("VL_GEMM_NOSPLIT") != nullptr;
-static const bool kConvNoWideStore = getenv("VL_CONV_NO_WIDE_STORE") != nullptr;   // A/B: per-accumulator stores in conv_dma16_kernel's epilogue
-static const bool kConvNoLoadPick = getenv("VL_CONV_NO_LOAD_PICK") != nullptr;   // A/B: tile width by padded rows only (round-1 rule)
-static const bool kWgradDword = getenv("VL_WGRAD_DWORD") != nullptr;  // split-product wgrad: keep the dword fetches where 16-byte ones apply
-static const bool kRing8 = getenv("VL_CONV_RING8") != nullptr;      // bf16x3, 128-channel layers: the 8-wave conv_ring_kernel instead of conv_ring4_kernel
+static const bool kConvStaged = vl_exp_env("VL_CONV_STAGED") != nullptr;
+static const bool kGemmNoSplit = vl_exp_env("VL_GEMM_NOSPLIT") != nullptr;
+static const bool kConvNoWideStore = vl_exp_env("VL_CONV_NO_WIDE_STORE") != nullptr;   // A/B: per-accumulator stores in conv_dma16_kernel's epilogue
+static const bool kConvNoLoadPick = vl_exp_env("VL_CONV_NO_LOAD_PICK") != nullptr;   // A/B: tile width by padded rows only (round-1 rule)
+static const bool kWgradDword = vl_exp_env("VL_WGRAD_DWORD") != nullptr;  // split-product wgrad: keep the dword fetches where 16-byte ones apply
+static const bool kRing8 = vl_exp_env("VL_CONV_RING8") != nullptr;      // bf16x3, 128-channel layers: the 8-wave conv_ring_kernel instead of conv_ring4_kernel
 
 // contraction arithmetic of the three conv kernels: 0 = fp32 MFMA (default, the parity path), 3 = bf16x3 and 6 = bf16x6 split
 // products, 1 = plain bf16 products (heads only) (vl_set_conv_math; VL_CONV_MATH=bf16x3 | bf16x6 | bf16 presets it)
 static int g_conv_math = [] {
-    const char* e = getenv("VL_CONV_MATH");
+    const char* e = vl_exp_env("VL_CONV_MATH");
     return e == nullptr ? 0 : strcmp(e, "bf16x3") == 0 ? 3 : strcmp(e, "bf16x6") == 0 ? 6 : strcmp(e, "bf16") == 0 ? 1 : 0;
 }();
 
@@ -2721,10 +2721,8 @@ static int wgrad_splits(const vl_conv_desc* d, int n) {
     // (rounds of the chip) x (tiles per workgroup + ~2 tiles of prologue / epilogue) over split counts that give every XCD
     // the same number of units; slabs are capped at 512 MB.
     const int rtiles = ceil_div(M, 64);
-    if (const char* e = getenv("VL_WGRAD_SPLITS")) {                 // experiments: force the split count
-        const int s = atoi(e);
-        if (s >= 1 && s <= rtiles) return s;
-    }
+    static const int forced = vl_exp_env("VL_WGRAD_SPLITS") ? atoi(vl_exp_env("VL_WGRAD_SPLITS")) : 0;   // experiments: force the split count
+    if (forced >= 1 && forced <= rtiles) return forced;      // (this function IS the ws_bytes query's split count too: one source)
     const int per_xcd = device_cus() / 8 > 0 ? device_cus() / 8 : 1;
     const int64_t slab_bytes = ((int64_t)d->K + 1) * d->cout * 4;
     int best = 1;
@@ -3068,7 +3066,7 @@ extern "C" int vl_gemm(int transa, int transb, int m, int n, int k, const float*
     // barrier latency with co-resident workgroups: fc6 forward = 256 tiles = one per CU ran at 0.65 of peak) and a workspace
     // was provided
     int splits = 1;
-    static const int kWantPerCu = getenv("VL_GEMM_WANT") ? atoi(getenv("VL_GEMM_WANT")) : 3;   // experiments: workgroups per CU aimed at
+    static const int kWantPerCu = vl_exp_env("VL_GEMM_WANT") ? atoi(vl_exp_env("VL_GEMM_WANT")) : 3;   // experiments: workgroups per CU aimed at
     const int want = kWantPerCu * device_cus();
     if (ws && tiles < want && !kGemmNoSplit) {
         splits = ceil_div(want, tiles);

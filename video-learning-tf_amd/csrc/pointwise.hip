@@ -10,8 +10,9 @@
 
 // A/B switches for measurements, read once: VL_POOL_LRN_CHUNKED=1 runs the fused pool+LRN backward on the older chunked
 // kernel, VL_POOL_LRN_CHK16=1 forces the 16-channel chunk of the channel-stream kernel.
-static const bool kPoolLrnChunked = getenv("VL_POOL_LRN_CHUNKED") != nullptr;
-static const bool kPoolLrnChk16 = getenv("VL_POOL_LRN_CHK16") != nullptr;
+static const bool kPoolLrnChunked = vl_exp_env("VL_POOL_LRN_CHUNKED") != nullptr;
+static const bool kPoolLrnChk16 = vl_exp_env("VL_POOL_LRN_CHK16") != nullptr;
+static const bool kMaxpoolGeneric = vl_exp_env("VL_MAXPOOL_GENERIC") != nullptr;   // A/B: pool5 backward, element-per-thread kernel
 
 static inline int grid_for(int64_t work, int threads, int cap) {
     int64_t b = (work + threads - 1) / threads;
@@ -326,7 +327,7 @@ __global__ __launch_bounds__(256, (C8 ? 3 : 1)) void pool_lrn_bwd_stream_kernel(
     // for launches whose (band, image) grid fills the chip 1.5 times (27 x 27 x 256 at 1024 frames) or not at all (128 frames).
     constexpr int LEAD = C8 ? 8 : 4;
     const int R0 = blockIdx.z * cper, R1 = min(C, R0 + cper);
-    const int cs = R0 > 0 ? R0 - LEAD : 0;
+    const int cs = max(R0 - LEAD, 0);                                 // never below channel 0: windows that start there ARE empty
     __shared__ __attribute__((aligned(16))) uint2 stage[2 * BUF];
     const int HW = H * W;
     const int img = blockIdx.y;
@@ -414,7 +415,7 @@ __global__ __launch_bounds__(256, (C8 ? 3 : 1)) void pool_lrn_bwd_stream_kernel(
 #pragma unroll
             for (int i = 0; i < CHK; ++i) {
                 const int cc = c0 + i;                                    // uniform; channels past C: the range check answers 0
-                v[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, (int)(cc < C ? voff_x : PW_OOB), cc * x_cs, 0));
+                v[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, (int)(cc >= 0 && cc < C ? voff_x : PW_OOB), max(cc, 0) * x_cs, 0));
             }
         }
     };
@@ -504,30 +505,36 @@ __global__ __launch_bounds__(256, (C8 ? 3 : 1)) void pool_lrn_bwd_stream_kernel(
     }
 }
 
-static size_t plb_extra_lds() {       // experiment: dynamic LDS the kernel never touches, to keep other workgroups off its CU
-    static const size_t v = getenv("VL_PLB_EXTRA_LDS") ? (size_t)atoi(getenv("VL_PLB_EXTRA_LDS")) : 0;
-    return v;
-}
-
 // Channel ranges per (band, image) of the channel-stream backward: the count (<= 4) with the fewest rounds x channels walked, a
 // round = 8 workgroups per CU (56 VGPRs, 12.5 KB of LDS).  `unit`: ranges start at multiples of it (8 for the packed output).
-static int plb_channel_ranges(int64_t workgroups, int c, int unit, int* cper) {
+static int g_plb_forced_ranges = 0;
+static int plb_channel_ranges(int64_t workgroups, int c, int unit, int lead, int* cper) {
     const int64_t slots = 8ll * vl_device_cus();
     int best = 1;
     int64_t best_cost = 0;
     for (int sp = 1; sp <= 4; ++sp) {
         const int per = (int)(((c + sp - 1) / sp + unit - 1) / unit * unit);
-        if (sp > 1 && per * (sp - 1) >= c) continue;                  // the last range would be empty
+        if (sp > 1 && (per * (sp - 1) >= c || per < lead)) continue;  // the last range would be empty / a range shorter than the lead-in
         const int64_t cost = ((workgroups * sp + slots - 1) / slots) * (per + 12);
         if (sp == 1 || cost < best_cost) { best = sp; best_cost = cost; *cper = per; }
     }
-    const char* e = getenv("VL_PLB_RANGES");                          // A/B and tests: force the count (read per call)
-    if (e && atoi(e) >= 1 && atoi(e) <= 4) {
-        best = atoi(e);
+    if (g_plb_forced_ranges >= 1 && g_plb_forced_ranges <= 4) {            // tests: vl_pool_lrn_bwd_test_ranges
+        best = g_plb_forced_ranges;
         *cper = (int)(((c + best - 1) / best + unit - 1) / unit * unit);
-        while (best > 1 && *cper * (best - 1) >= c) --best;
+        while (best > 1 && (*cper * (best - 1) >= c || *cper < lead)) {   // a range must start >= `lead` channels in (the kernel's walk
+            --best;                                                        // restarts that far below its first output channel)
+            *cper = (int)(((c + best - 1) / best + unit - 1) / unit * unit);
+        }
     }
     return best;
+}
+
+/* Test hook (not part of the operator surface): force the number of channel ranges per (band, image) of vl_pool_lrn_bwd /
+ * vl_pool_lrn_bwd_c8 to 1..4 (fewer when the channel count does not allow it); 0 = the cost model.  Process-wide, not thread-safe. */
+extern "C" int vl_pool_lrn_bwd_test_ranges(int ranges) {
+    VL_CHECK(ranges >= 0 && ranges <= 4, "vl_pool_lrn_bwd_test_ranges: 0 (automatic) .. 4");
+    g_plb_forced_ranges = ranges;
+    return 0;
 }
 
 extern "C" int vl_pool_lrn_bwd(const float* x, const float* dp, const uint8_t* argmax, float* dx, int n, int c, int h, int w,
@@ -548,13 +555,13 @@ extern "C" int vl_pool_lrn_bwd(const float* x, const float* dp, const uint8_t* a
         const bool ok = beta == 0.75f && bytes_x < (1ll << 31) && bytes_dx < (1ll << 31) && pooled_f < (1ll << 31) && pplane < (1 << 24) &&
                         !kPoolLrnChunked;
         int cper = c;
-        const int nz = plb_channel_ranges((int64_t)ceil_div((int64_t)h * w, 256) * n, c, 1, &cper);
+        const int nz = plb_channel_ranges((int64_t)ceil_div((int64_t)h * w, 256) * n, c, 1, 4, &cper);
         const dim3 grid(ceil_div((int64_t)h * w, 256), n, nz);
         const int64_t psn = (int64_t)c * pplane;
 #define VL_PLB_LAUNCH(CHK, NST)                                                                                                     \
     do {                                                                                                                            \
         if (relu_fused)                                                                                                             \
-            hipLaunchKernelGGL((pool_lrn_bwd_stream_kernel<CHK, NST, true, 0>), grid, dim3(256), plb_extra_lds(), (hipStream_t)stream, x, dp + origin, \
+            hipLaunchKernelGGL((pool_lrn_bwd_stream_kernel<CHK, NST, true, 0>), grid, dim3(256), 0, (hipStream_t)stream, x, dp + origin, \
                                argmax + origin, dx, c, h, w, oh, ow, psn, (int)pplane, owp, pooled_f, alpha, bias, dx_halo, cper);  \
         else                                                                                                                        \
             hipLaunchKernelGGL((pool_lrn_bwd_stream_kernel<CHK, NST, false, 0>), grid, dim3(256), 0, (hipStream_t)stream, x, dp + origin, \
@@ -565,7 +572,7 @@ extern "C" int vl_pool_lrn_bwd(const float* x, const float* dp, const uint8_t* a
         // chunk = 5 channels (110 registers, 12.5 KB of LDS: four workgroups per CU instead of two) when C + 4 is a multiple of it (96
         // and 256 are: no idle tail iterations): layer 1 0.79 -> 0.71 ms, layer 2 0.57 -> 0.51 ms against the 20-channel chunks of
         // round 1 (VL_POOL_LRN_BWD_R1=1)
-        static const bool r1 = getenv("VL_POOL_LRN_BWD_R1") != nullptr;
+        static const bool r1 = vl_exp_env("VL_POOL_LRN_BWD_R1") != nullptr;
         if (ok && !r1 && (c + 4) % 5 == 0 && (int64_t)5 * max_prow * ow <= 3 * 256) VL_PLB_LAUNCH(5, 3);
         // chunk = 20 channels when C + 4 is a multiple of it (96 and 256 are): no idle tail iterations
         if (ok && (c + 4) % 20 == 0 && (int64_t)20 * max_prow * ow <= 11 * 256 && !kPoolLrnChk16) VL_PLB_LAUNCH(20, 11);
@@ -600,7 +607,7 @@ extern "C" int vl_pool_lrn_bwd_c8(const void* x, int x_packed, const float* dp, 
     VL_CHECK(bytes_x < (1ll << 31) && bytes_dx < (1ll << 31) && pooled_f < (1ll << 31) && pplane < (1 << 24) && (int64_t)8 * max_prow * ow <= 5 * 256,
              "vl_pool_lrn_bwd_c8: plane too large for the channel-stream form");
     int cper = c;
-    const int nz = plb_channel_ranges((int64_t)ceil_div((int64_t)h * w, 256) * n, c, 8, &cper);
+    const int nz = plb_channel_ranges((int64_t)ceil_div((int64_t)h * w, 256) * n, c, 8, 8, &cper);
     const dim3 grid(ceil_div((int64_t)h * w, 256), n, nz);
     const int64_t psn = (int64_t)c * pplane;
     const float* xf = (const float*)x;
@@ -820,7 +827,8 @@ static int launch_lrn_pool_fwd(const float* x, float* p, uint8_t* argmax, int n,
         threads = ceil_div(need_px > need_out ? need_px : need_out, 64) * 64;
     }
     const size_t lds = (size_t)2 * (CHK * (2 * prb + 1) * w + 1) * sizeof(float);       // two buffers, each with a spare slot
-    if (getenv("VL_LRN_POOL_VERBOSE")) fprintf(stderr, "lrn_pool_fwd<%d,%d,%d>: bands %d prb %d threads %d lds %zu\n", CHK, PPT, NSL, bands, prb, threads, lds);
+    static const bool verbose = vl_exp_env("VL_LRN_POOL_VERBOSE") != nullptr;
+    if (verbose) fprintf(stderr, "lrn_pool_fwd<%d,%d,%d>: bands %d prb %d threads %d lds %zu\n", CHK, PPT, NSL, bands, prb, threads, lds);
     hipLaunchKernelGGL((lrn_pool_fwd_kernel<CHK, PPT, NSL, C8>), dim3(bands, n), dim3(threads), lds, stream, x, p, argmax, c, h,
                        w, oh, ow, prb, (int)pplane, owp, p_halo, alpha, bias);
     VL_LAUNCH_CHECK();
@@ -841,7 +849,7 @@ extern "C" int vl_lrn_pool_fwd(const float* x, float* p, uint8_t* argmax, int n,
     // threads.  The round-1 shape <8, 3, 6> (8-channel chunks, 214 registers, 55 KB) left ONE 320-thread workgroup = 5 waves on a CU and
     // ran LRN's ~13 VALU per element at that occupancy: layer 1 0.63 -> 0.45 ms, layer 2 0.33 -> 0.28 ms (sweep of 14 shapes on MI355X,
     // tools/pw_probe.py lrn_pool_fwd; VL_LRN_POOL_R1=1 runs the old shape for comparison).
-    static const bool r1 = getenv("VL_LRN_POOL_R1") != nullptr;
+    static const bool r1 = vl_exp_env("VL_LRN_POOL_R1") != nullptr;
     hipStream_t s = (hipStream_t)stream;
     if (r1) return launch_lrn_pool_fwd<8, 3, 6>(x, p, argmax, n, c, h, w, p_halo, alpha, bias, s);
     return launch_lrn_pool_fwd<2, 2, 1>(x, p, argmax, n, c, h, w, p_halo, alpha, bias, s);
@@ -1031,7 +1039,7 @@ extern "C" int vl_maxpool_bwd(const float* dy, const uint8_t* argmax, float* dx,
     const int64_t total = (int64_t)n * c * h * w;
     VL_CHECK(total < (1ll << 31), "vl_maxpool_bwd: tensor too large");
     if (k == 3 && s == 2 && ys_c == 1 && ys_w == c && ys_h == (int64_t)ow * c && ys_n == (int64_t)oh * ow * c && n <= 65535 &&
-        (size_t)64 * (oh * ow + 1) * 8 <= 48 * 1024 && !getenv("VL_MAXPOOL_GENERIC")) {
+        (size_t)64 * (oh * ow + 1) * 8 <= 48 * 1024 && !kMaxpoolGeneric) {
         // the (h, w, c)-flat pooled layout (pool5 -> fc6): LDS-transposed form
         constexpr int CB = 64;
         const size_t lds = (size_t)CB * (oh * ow + 1) * 8;

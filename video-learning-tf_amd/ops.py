@@ -401,6 +401,11 @@ def pool_lrn_bwd(x, dp, argmax, dx, p_halo=0, dx_halo=0, radius=2, alpha=2e-5, b
               dx_halo, stream())
 
 
+def pool_lrn_bwd_test_ranges(ranges=0):
+    """Test hook: force the channel-range count of pool_lrn_bwd / pool_lrn_bwd_c8 launches (1..4); 0 = the launcher's own choice."""
+    _ffi.call("vl_pool_lrn_bwd_test_ranges", int(ranges))
+
+
 def pool_lrn_bwd_c8(x, dp, argmax, dxb, p_halo=0, dxb_halo=0, radius=2, alpha=2e-5, beta=0.75, bias=1.0, relu_fused=True):
     """pool_lrn_bwd with the gradient written as packed bf16 (c8 layout, dxb_halo): the bf16 conv path's operand.
     x: fp32 NCHW, or the packed conv output (bf16 c8, no halo)."""
