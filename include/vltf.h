@@ -324,12 +324,19 @@ int vl_softmax_xent(const float* logits, const int32_t* labels, float* dlogits, 
  * vl_sumsq: out[0] (+)= sum g^2 over count elements (ws: float[1024]); accumulate != 0 adds to out. */
 int vl_sumsq(const float* g, int64_t count, float* out, float* ws, int accumulate, vl_stream_t stream);
 /* w -= lr * gscale * clip_scale * g with clip_scale = clip_norm / max(gscale*sqrt(*sumsq), clip_norm)
- * (1 if clip_norm <= 0 or sumsq == NULL).  gscale folds the 1/world averaging of DP all-reduce. */
+ * (1 if clip_norm <= 0 or sumsq == NULL).  gscale folds the 1/world averaging of DP all-reduce.
+ * skip (device word, may be NULL): when *skip != 0 at execution time the launch changes nothing -- the step's gradients are invalid
+ * (a cluster-form LSTM launch of the step timed out, vl_status_or) and must not reach the weights; the host raises when it next reads
+ * the status (vl_lstm_seq_status). */
 int vl_sgd_apply(float* w, const float* g, int64_t count, float lr, float clip_norm, const float* sumsq,
-                 float gscale, vl_stream_t stream);
-/* tf.train.AdamOptimizer (train.py:205-206) with TF defaults beta1=.9 beta2=.999 eps=1e-8; step >= 1. */
+                 float gscale, const uint32_t* skip, vl_stream_t stream);
+/* tf.train.AdamOptimizer (train.py:205-206) with TF defaults beta1=.9 beta2=.999 eps=1e-8; step >= 1.  skip: as vl_sgd_apply (m, v
+ * stay untouched too). */
 int vl_adam_apply(float* w, const float* g, float* m, float* v, int64_t count, float lr, float clip_norm,
-                  const float* sumsq, float gscale, int step, vl_stream_t stream);
+                  const float* sumsq, float gscale, int step, const uint32_t* skip, vl_stream_t stream);
+/* *dst |= (the sticky time-out word of an LSTM cluster workspace != 0), on the stream: collects the `skip` word of a step without a
+ * host round trip (dst: one zero-initialised device word per step; the workspace's own word stays set until vl_lstm_seq_status). */
+int vl_status_or(uint32_t* dst, const void* lstm_ws, vl_stream_t stream);
 
 /* ---- utilities ------------------------------------------------------------------------------- */
 int vl_fill(float* p, int64_t count, float value, vl_stream_t stream);

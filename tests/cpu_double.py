@@ -154,7 +154,14 @@ class CpuOps:
         out[0] = float((g.double() ** 2).sum()) + (float(out[0]) if accumulate else 0.0)
 
     @staticmethod
-    def sgd_apply(w, g, lr, clip_norm=0.0, sumsq_t=None, gscale=1.0):
+    def step_guard(skip, *lstm_workspaces):
+        skip.zero_()
+        return skip
+
+    @staticmethod
+    def sgd_apply(w, g, lr, clip_norm=0.0, sumsq_t=None, gscale=1.0, skip=None):
+        if skip is not None and int(skip[0]):
+            return
         scale = gscale
         if clip_norm > 0:
             gn = math.sqrt(float(sumsq_t[0]))

@@ -95,6 +95,47 @@ def test_exchange_chunks_cover_the_buffer_and_wait_for_the_last_lstm(monkeypatch
     assert order[0] == "enc_lstm" and order.count("reduce") == len(eng.grad_chunks)
 
 
+class _SnapshotDp:
+    """Keeps what every chunk held at the moment it was handed to the exchange (the CPU double runs synchronously: that IS what an
+    all-reduce issued there would read)."""
+    world = 1
+
+    def __init__(self):
+        self.snaps = []
+
+    def reduce_async(self, flat, off, cnt):
+        self.snaps.append((off, cnt, flat[off:off + cnt].clone()))
+
+    def wait(self):
+        pass
+
+
+@pytest.mark.parametrize("name", ["encdec_ibias_r3", "dcnn_with_state", "fanout", "encdec_concat_r2", "two_stream_avg"])
+def test_every_gradient_of_a_chunk_is_written_before_the_chunk_is_exchanged(monkeypatch, name):
+    """A chunk handed to the exchange must already hold its FINAL gradients.  Round 3's GraphEngine released a pipeline's head chunk
+    before the `representation: fc` gradients (fc_convert_w / _b, part of that chunk) had been computed: under data parallelism the
+    all-reduce read stale values (the advisor's finding; `encdec_ibias_r3` and `fanout` have such a pipeline).  The gradient buffer
+    starts as NaN, so a value exchanged before it was written cannot equal the final one."""
+    Engine = install(monkeypatch)
+    case = GC.CASES[name]()
+    pipes, ds = GC.specs_and_datasets(case)
+    dp = _SnapshotDp()
+    eng = Engine(pipes, ds, case["V"], device="cpu", dp=dp)
+    eng.load_params(eng.init_params(seed=case["seed"], well_scaled=True))
+    raw, feeds = GC.inputs(case)
+    dev_feeds = {t: (dict(frames_u8=torch.from_numpy(v), mean_bgr=GC.MEAN) if v.dtype == np.uint8 else torch.from_numpy(v)) for t, v in raw.items()}
+    rows = eng.forward(dev_feeds).shape[0]
+    onehot = np.zeros((rows, case["V"]), np.int32)
+    onehot[np.arange(rows), np.random.default_rng(3).integers(0, case["V"], rows)] = 1
+    eng.g.fill_(float("nan"))
+    eng.train_step(dev_feeds, torch.from_numpy(onehot), lr=0.0, clip_norm=0.0)
+    assert sorted((o, c) for o, c, _ in dp.snaps) == sorted(eng.grad_chunks)
+    final = eng.g.clone()
+    assert not torch.isnan(final).any(), "a gradient was never written"
+    for off, cnt, snap in dp.snaps:
+        assert torch.equal(snap, final[off:off + cnt]), "chunk (%d, %d) was exchanged before all of its gradients were written" % (off, cnt)
+
+
 @pytest.mark.parametrize("pipes,msg", [
     ([("a", dict(input=["main"], representation="dcnn", frame_encoding_layer="fc6", classifier=None, frame_fusion=("late", "avg")))], "late fusion with no classifier"),
     ([("a", dict(input=["main"], representation="dcnn", frame_encoding_layer="fc6", classifier=None))], "classifier is missing"),

@@ -1671,14 +1671,17 @@ __device__ __forceinline__ float clip_scale(float clip_norm, const float* sumsq,
 }
 
 __global__ void sgd_apply_kernel(float* __restrict__ w, const float* __restrict__ g, int64_t count, float lr, float clip_norm,
-                                 const float* __restrict__ sumsq, float gscale) {
+                                 const float* __restrict__ sumsq, float gscale, const uint32_t* __restrict__ skip) {
+    if (skip && *skip) return;                                        // the step's results are invalid (vl_status_or): no update
     const float a = lr * clip_scale(clip_norm, sumsq, gscale);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
         w[i] -= a * g[i];
 }
 
 __global__ void adam_apply_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                                  int64_t count, float lr_t, float clip_norm, const float* __restrict__ sumsq, float gscale) {
+                                  int64_t count, float lr_t, float clip_norm, const float* __restrict__ sumsq, float gscale,
+                                  const uint32_t* __restrict__ skip) {
+    if (skip && *skip) return;
     const float sc = clip_scale(clip_norm, sumsq, gscale);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
         const float gi = g[i] * sc;
@@ -1690,22 +1693,33 @@ __global__ void adam_apply_kernel(float* __restrict__ w, const float* __restrict
     }
 }
 
+// *dst |= first word of an LSTM cluster workspace (its sticky time-out word, lstm_cluster.hip): the optimizer's `skip` word of a step
+__global__ void status_or_kernel(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src) {
+    if (*src) *dst = 1u;
+}
+extern "C" int vl_status_or(uint32_t* dst, const void* lstm_ws, vl_stream_t stream) {
+    VL_CHECK(dst && lstm_ws, "vl_status_or: null argument");
+    hipLaunchKernelGGL(status_or_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, dst, (const uint32_t*)lstm_ws);
+    VL_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int vl_sgd_apply(float* w, const float* g, int64_t count, float lr, float clip_norm, const float* sumsq, float gscale,
-                            vl_stream_t stream) {
+                            const uint32_t* skip, vl_stream_t stream) {
     VL_CHECK(w && g && count > 0, "vl_sgd_apply: bad argument");
     hipLaunchKernelGGL(sgd_apply_kernel, dim3(grid_for(count, 256, 4096)), dim3(256), 0, (hipStream_t)stream, w, g, count, lr,
-                       clip_norm, sumsq, gscale);
+                       clip_norm, sumsq, gscale, skip);
     VL_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int vl_adam_apply(float* w, const float* g, float* m, float* v, int64_t count, float lr, float clip_norm,
-                             const float* sumsq, float gscale, int step, vl_stream_t stream) {
+                             const float* sumsq, float gscale, int step, const uint32_t* skip, vl_stream_t stream) {
     VL_CHECK(w && g && m && v && count > 0 && step >= 1, "vl_adam_apply: bad argument");
     const double b1t = 1.0 - pow(0.9, (double)step), b2t = 1.0 - pow(0.999, (double)step);
     const float lr_t = (float)(lr * sqrt(b2t) / b1t);
     hipLaunchKernelGGL(adam_apply_kernel, dim3(grid_for(count, 256, 4096)), dim3(256), 0, (hipStream_t)stream, w, g, m, v, count,
-                       lr_t, clip_norm, sumsq, gscale);
+                       lr_t, clip_norm, sumsq, gscale, skip);
     VL_LAUNCH_CHECK();
     return 0;
 }

@@ -357,6 +357,7 @@ class LRCNEngine:
         self.stats = torch.zeros(2, device=dev)
         self.loss_rows = torch.zeros(2 * self.rows_out, device=dev)     # per-row losses | hits (vl_softmax_xent workspace)
         self.ss = torch.zeros(1, device=dev)
+        self._skip = torch.zeros(1, dtype=torch.int32, device=dev)      # ops.step_guard: the optimizer launch's skip word
         self.probe, self.probe_events = None, []
         self._resizers = {}
         self.mean_dev = torch.zeros(3, device=dev)
@@ -934,10 +935,13 @@ class LRCNEngine:
             self.dp.wait()
         ops.sumsq(self.g, self.ss, self.small_ws)
         self.step_count += 1
+        # a step whose LSTM cluster launch timed out must not reach the weights -- also with fetch=False, where the host reads the
+        # status only later: the optimizer launch drops the update on the device (ops.step_guard), check_status raises at the next fetch
+        skip = ops.step_guard(self._skip, getattr(self, "lstm_ws", None))
         if self.cfg.optimizer == "adam":
-            ops.adam_apply(self.w, self.g, self.adam_m, self.adam_v, lr, self.step_count, clip_norm, self.ss, 1.0)
+            ops.adam_apply(self.w, self.g, self.adam_m, self.adam_v, lr, self.step_count, clip_norm, self.ss, 1.0, skip=skip)
         else:
-            ops.sgd_apply(self.w, self.g, lr, clip_norm, self.ss, 1.0)
+            ops.sgd_apply(self.w, self.g, lr, clip_norm, self.ss, 1.0, skip=skip)
         if not fetch:
             return None
         torch.cuda.synchronize(self.dev)

@@ -502,7 +502,6 @@ class PipeNode:
                 d = self.dcls_in
         elif self.cls == "lstm":
             d, rows = self._lstm_backward(d)
-        g._head_done(self)                    # the head's gradients are queued (its LSTM launches included): its chunk may go
         if self.wants_feat:
             if self.early:
                 ops.temporal_fusion_bwd(d, self.dfeat_full, rows, self.fpc, self.feat_dim, self.fmethod)
@@ -513,6 +512,11 @@ class PipeNode:
                 if self.primary_pipe:
                     ops.gemm(d, P[sc + "fc_convert_w"], self.dx0, rows, self.x_dim, self.feat_dim, transb=True)
                     d = self.dx0
+        # Every gradient of the head chunk is queued now -- the classifier's, its LSTM launches, AND the `representation: fc` variables
+        # (fc_convert_w / _b belong to the same chunk, head_specs): only here may the chunk's all-reduce be issued.  Round 3 called this
+        # before the representation-fc block: under data parallelism the exchange then read those two gradients before they were written.
+        g._head_done(self)
+        if self.wants_feat:
             if self.tower is not None:
                 n, b = self._nb
                 tw = self.tower
@@ -759,6 +763,7 @@ class GraphEngine:
         self.stats = torch.zeros(2, device=dev)
         self.loss_rows = torch.zeros(2 * rows, device=dev)
         self.ss = torch.zeros(1, device=dev)
+        self._skip = torch.zeros(1, dtype=torch.int32, device=dev)      # ops.step_guard: the optimizer launch's skip word
         self.small_ws = torch.empty(64 * 1024, device=dev)
         self._queued, self._pending_lstm = [], 0
         self.per_step = self.last.cls == "lstm" and self.last.per_step
@@ -894,10 +899,11 @@ class GraphEngine:
             self.dp.wait()
         ops.sumsq(self.g, self.ss, self.small_ws)
         self.step_count += 1
+        skip = ops.step_guard(self._skip, *[nd.lstm_ws for nd in self.nodes if nd.cls == "lstm"])   # LRCNEngine._finish_step
         if self.optimizer == "adam":
-            ops.adam_apply(self.w, self.g, self.adam_m, self.adam_v, lr, self.step_count, clip_norm, self.ss, 1.0)
+            ops.adam_apply(self.w, self.g, self.adam_m, self.adam_v, lr, self.step_count, clip_norm, self.ss, 1.0, skip=skip)
         else:
-            ops.sgd_apply(self.w, self.g, lr, clip_norm, self.ss, 1.0)
+            ops.sgd_apply(self.w, self.g, lr, clip_norm, self.ss, 1.0, skip=skip)
         if not fetch:
             return None
         self._sync()

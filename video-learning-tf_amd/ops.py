@@ -552,14 +552,33 @@ def sumsq(g, out, ws, accumulate=False):
     _ffi.call("vl_sumsq", _p(g), g.numel(), _p(out), _p(ws), int(accumulate), stream())
 
 
-def sgd_apply(w, g, lr, clip_norm=0.0, sumsq_t=None, gscale=1.0):
+def _skip_word(skip):
+    if skip is not None and not (skip.is_cuda and skip.dtype == torch.int32 and skip.numel() >= 1):
+        raise _ffi.VltfError("skip must be a CUDA/HIP int32 tensor (one word)")
+    return _p(skip)
+
+
+def sgd_apply(w, g, lr, clip_norm=0.0, sumsq_t=None, gscale=1.0, skip=None):
+    """skip: optional device word (int32); non-zero at execution time = the update is dropped (step_guard)."""
     _f32(w, g, sumsq_t)
-    _ffi.call("vl_sgd_apply", _p(w), _p(g), w.numel(), lr, clip_norm, _p(sumsq_t), gscale, stream())
+    _ffi.call("vl_sgd_apply", _p(w), _p(g), w.numel(), lr, clip_norm, _p(sumsq_t), gscale, _skip_word(skip), stream())
 
 
-def adam_apply(w, g, m, v, lr, step, clip_norm=0.0, sumsq_t=None, gscale=1.0):
+def adam_apply(w, g, m, v, lr, step, clip_norm=0.0, sumsq_t=None, gscale=1.0, skip=None):
     _f32(w, g, m, v, sumsq_t)
-    _ffi.call("vl_adam_apply", _p(w), _p(g), _p(m), _p(v), w.numel(), lr, clip_norm, _p(sumsq_t), gscale, step, stream())
+    _ffi.call("vl_adam_apply", _p(w), _p(g), _p(m), _p(v), w.numel(), lr, clip_norm, _p(sumsq_t), gscale, step, _skip_word(skip), stream())
+
+
+def step_guard(skip, *lstm_workspaces):
+    """skip[0] = 1 if a cluster-form LSTM launch on any of the workspaces has timed out since its status was last read (the word is
+    sticky, lstm_seq_check reads and resets it), else 0 -- on the stream, no host round trip.  Hand `skip` to sgd_apply / adam_apply:
+    a step whose recurrence gave up (its results are invalid by the kernel's own contract) must not reach the weights."""
+    _skip_word(skip)
+    skip.zero_()
+    for ws in lstm_workspaces:
+        if ws is not None:
+            _ffi.call("vl_status_or", _p(skip), _p(ws), stream())
+    return skip
 
 
 def fill(t, value):
