@@ -2,8 +2,8 @@
 """bench.py -- clips/s of one full LRCN train step (input-prep -> forward -> loss -> backward ->
 [all-reduce] -> global-norm clip + SGD) on synthetic 16-frame 227x227x3 clips (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+  python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: starts its N ranks itself, dp.self_launch)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1 under a launcher)
 
 Workload (configs[1] of BASELINE.json): AlexNet encode at fc6 -> LSTM(256, 1 layer, avg) -> 101 classes, T = 16, the
 reference's batch_size = 64 clips (= 1024 frames) per step, fp32, dropout keep 0.5.  N = 1: the whole batch on one
@@ -151,13 +151,29 @@ def main():
     args = ap.parse_args()
 
     from vltf_amd import dp as dpmod
+    # `python bench.py --gpus N` as the driver starts it (no launcher): become the launcher -- N ranks under torch.distributed.run --
+    # before anything here touches the GPU; their one JSON line (rank 0's) passes through, their exit code is ours
+    rc = dpmod.self_launch(args.gpus)
+    if rc is not None:
+        raise SystemExit(rc)
     from vltf_amd.engine import LRCNEngine, NetConfig, init_params
 
+    if os.environ.get("VLTF_BENCH_RENDEZVOUS_ONLY") == "1":
+        # launch-path test (tests/test_launch.py, no GPU needed): the ranks meet over the backend of VLTF_DIST_BACKEND, sum their ranks,
+        # rank 0 reports and everybody leaves -- nothing is measured
+        rank, world, _ = dpmod.init_from_env()
+        t = torch.tensor([float(rank)])
+        if world > 1:
+            torch.distributed.all_reduce(t)
+            torch.distributed.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"rendezvous_only": True, "world": world, "gpus": args.gpus, "rank_sum": float(t.item())}), flush=True)
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
     rank, world, local = dpmod.init_from_env()
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: the launcher's rank count and --gpus disagree" % (args.gpus, world))
     local = local % torch.cuda.device_count()      # ranks beyond the visible GPUs share them (gloo rehearsal on a 1-GPU box only)
     dev = "cuda:%d" % local
     torch.cuda.set_device(local)

@@ -41,6 +41,29 @@ def init_from_env(backend=None, force=False):
     return rank, world, local
 
 
+def self_launch(gpus, argv=None):
+    """`python <script> --gpus N` started WITHOUT a launcher (WORLD_SIZE unset, N > 1): start the N ranks ourselves -- one process per
+    GPU under `python -m torch.distributed.run` on 127.0.0.1 with a free port -- pass their output through and return the launcher's
+    exit code (the caller exits with it).  Returns None when nothing is to be done (N == 1, or a launcher already set WORLD_SIZE).
+    Must be called BEFORE anything touches the GPU: the ranks are child processes of a parent that never initialises HIP (a process
+    that has must not exec / fork into GPU work on this platform)."""
+    if gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return None
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    argv = list(sys.argv if argv is None else argv)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs between the ranks' processes on this platform
+    return subprocess.run(cmd, env=env).returncode
+
+
 def shard_range(total, rank, world):
     """Contiguous clip range of `rank`: the first total % world ranks take one extra clip."""
     base, rem = divmod(total, world)

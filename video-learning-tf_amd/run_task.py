@@ -341,7 +341,19 @@ def main(init_file, seed=0, device=None):
     return result
 
 
-if __name__ == "__main__":
+def cli(argv=None):
+    """`python3 run_task.py <config.yml>` as in the reference (run_task.py:155-160), plus `--gpus N` (or VLTF_GPUS=N): data parallel over
+    N GPUs of this node -- the process becomes the launcher of its N ranks (dp.self_launch) before anything touches a GPU.  Under an
+    external launcher (WORLD_SIZE set) the flag is ignored and the launcher's world is used."""
     parser = argparse.ArgumentParser()
     parser.add_argument("init_file", help="Configuration .yml file for the run.")
-    main(parser.parse_args().init_file)
+    parser.add_argument("--gpus", type=int, default=int(os.environ.get("VLTF_GPUS", "1")), help="ranks to start on this node (default 1)")
+    args = parser.parse_args(argv)
+    rc = dpmod.self_launch(args.gpus)
+    if rc is not None:
+        raise SystemExit(rc)
+    return main(args.init_file)
+
+
+if __name__ == "__main__":
+    cli()
