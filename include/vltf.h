@@ -334,9 +334,10 @@ int vl_sgd_apply(float* w, const float* g, int64_t count, float lr, float clip_n
  * stay untouched too). */
 int vl_adam_apply(float* w, const float* g, float* m, float* v, int64_t count, float lr, float clip_norm,
                   const float* sumsq, float gscale, int step, const uint32_t* skip, vl_stream_t stream);
-/* *dst |= (the sticky time-out word of an LSTM cluster workspace != 0), on the stream: collects the `skip` word of a step without a
- * host round trip (dst: one zero-initialised device word per step; the workspace's own word stays set until vl_lstm_seq_status). */
-int vl_status_or(uint32_t* dst, const void* lstm_ws, vl_stream_t stream);
+/* *dst = (init ? 0 : *dst) | (the sticky time-out word of an LSTM cluster workspace != 0), on the stream: collects the `skip` word of a
+ * step without a host round trip (init != 0 for the step's first workspace; the workspace's own word stays set until
+ * vl_lstm_seq_status reads it). */
+int vl_status_or(uint32_t* dst, const void* lstm_ws, int init, vl_stream_t stream);
 
 /* ---- utilities ------------------------------------------------------------------------------- */
 int vl_fill(float* p, int64_t count, float value, vl_stream_t stream);

@@ -286,6 +286,37 @@ def test_engine_reports_an_lstm_cluster_timeout():
     assert np.isfinite(out["loss"])
 
 
+@pytest.mark.parametrize("optimizer", ["sgd", "adam"])
+def test_a_timed_out_step_does_not_reach_the_weights(optimizer):
+    """fetch=False steps never read the status on the host; a step whose LSTM cluster launch timed out must still not be applied: the
+    optimizer launch drops it on the device (ops.step_guard -> the `skip` word of vl_sgd_apply / vl_adam_apply), the next fetch raises
+    (round 3 applied such a step and went on training on its results: the advisor's finding)."""
+    from vltf_amd import ops
+    from vltf_amd._ffi import VltfError
+    rng = np.random.default_rng(8)
+    shape, ncls, fpc, b = (67, 67, 3), 7, 4, 2
+    cfg, eng = make(dict(num_classes=ncls, fpc=fpc, frame_encoding_layer="fc6", lstm_hidden=32, lstm_layers=1, fusion="avg", optimizer=optimizer),
+                    shape, b)
+    p = oracle_params(rng, cfg, shape)
+    eng.load_params(p)
+    frames = torch.tensor(rng.integers(0, 256, (b * fpc,) + shape, dtype=np.uint8), device=DEV)
+    onehot = torch.tensor(O.labels_to_one_hot([[l] for l in rng.integers(0, ncls, b)], ncls), device=DEV)
+    before = eng.w.clone()
+    try:
+        ops.lstm_seq_test_hooks(spin_limit=64, mute_workgroup=1)
+        assert eng.train_step_u8(frames, onehot, lr=0.1, clip_norm=0.0, mean_bgr=MEAN, fetch=False) is None
+        torch.cuda.synchronize()
+        assert torch.equal(eng.w, before), "a step whose recurrence timed out changed the weights"
+        with pytest.raises(VltfError, match="timed out"):
+            eng.check_status()
+    finally:
+        ops.lstm_seq_test_hooks()
+    eng.train_step_u8(frames, onehot, lr=0.1, clip_norm=0.0, mean_bgr=MEAN, fetch=False)      # a healthy step IS applied
+    torch.cuda.synchronize()
+    assert not torch.equal(eng.w, before)
+    eng.check_status()
+
+
 def test_two_stream_backward_of_the_lstm_pipeline_under_allocator_churn():
     """The single-pipeline LRCN (dcnn -> LSTM, 1 and 2 layers) on its default two-stream backward: head, LSTM, fc6 and conv parameter
     gradients and the dgrad weight transposes run on the second stream.  Many FRESH engines with the caching allocator perturbed

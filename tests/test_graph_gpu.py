@@ -190,7 +190,9 @@ def test_two_rank_graph_step_equals_one_rank(name, min_chunks):
         assert pr.exitcode == 0, "rank exited with %s" % pr.exitcode
     tag, worst, which, gn_err, issued, nchunks = q.get(timeout=10)
     assert tag == "ok" and issued == nchunks and nchunks >= min_chunks, (issued, nchunks)
-    assert worst < 1e-3 and gn_err < 1e-5, (worst, which, gn_err)
+    # parameter change relative to the largest change of that tensor; the two ranks sum half the rows each (another fp32 order):
+    # 1.2e-3 measured on `fanout` (maximum fusion + late fusion); a gradient exchanged before it was written would be O(1) off
+    assert worst < 3e-3 and gn_err < 1e-5, (worst, which, gn_err)
 
 
 def test_two_stream_backward_under_allocator_churn():

@@ -29,7 +29,7 @@ def main():
     head = HeadConfig(in_dim=E, fpc=Tw, num_classes=V, lstm_hidden=H, lstm_layers=1, fusion="reshape", dropout_keep_prob=0.5)
     eng = ComposedEngine(enc, head, max_clips=clips, device=dev)
     p = {"enc/" + k: v for k, v in init_params(enc, seed=2).items()}
-    p.update(init_head_params(head, V, "dec/", seed=3))
+    p.update(init_head_params(enc, head, seed=3))
     eng.load_params(p)
     rng = np.random.default_rng(0)
     frames = torch.from_numpy(rng.integers(0, 256, (clips * Tf, 227, 227, 3), dtype=np.uint8)).to(dev)

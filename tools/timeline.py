@@ -20,7 +20,13 @@ def main():
     ap.add_argument("--step", type=int, default=-2, help="which train step (index into the sgd_apply-delimited list)")
     ap.add_argument("--min-us", type=float, default=0.0)
     a = ap.parse_args()
-    rows = [r for r in csv.DictReader(open(a.csv)) if r["Kind"] == "KERNEL_DISPATCH"]
+    if a.csv.endswith(".csv"):
+        rows = [r for r in csv.DictReader(open(a.csv)) if r["Kind"] == "KERNEL_DISPATCH"]
+    else:                                   # a rocprofv3 results database (or the directory that holds one)
+        import glob, os, sqlite3
+        db = a.csv if a.csv.endswith(".db") else sorted(glob.glob(os.path.join(a.csv, "**", "*_results.db"), recursive=True))[-1]
+        rows = [{"Kernel_Name": n, "Start_Timestamp": s, "End_Timestamp": e, "Queue_Id": str(q), "grid": "%dx%dx%d" % (gx // max(wx, 1), gy, gz)}
+                for n, s, e, q, gx, gy, gz, wx in sqlite3.connect(db).execute("select name, start, end, queue_id, grid_x, grid_y, grid_z, workgroup_x from kernels")]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     ends = [i for i, r in enumerate(rows) if "sgd_apply_kernel" in r["Kernel_Name"] or "adam_apply" in r["Kernel_Name"]]
     if len(ends) < 3:
@@ -43,8 +49,8 @@ def main():
                 ov += max(0, min(e, int(o["End_Timestamp"])) - max(s, int(o["Start_Timestamp"])))
         busy.append((s, e))
         if (e - s) / 1e3 >= a.min_us:
-            print("%-64s %2s %9.1f %8.1f %8.1f %7.0f%%" % (short(r["Kernel_Name"]), q, (s - t0) / 1e3, (e - s) / 1e3, gap,
-                                                          100.0 * ov / max(1, e - s)))
+            print("%-64s %2s %9.1f %8.1f %8.1f %7.0f%%  %s" % (short(r["Kernel_Name"]), q[-2:], (s - t0) / 1e3, (e - s) / 1e3, gap,
+                                                              100.0 * ov / max(1, e - s), r.get("grid", "")))
     busy.sort()
     union, cur_s, cur_e = 0, busy[0][0], busy[0][1]
     for s, e in busy[1:]:

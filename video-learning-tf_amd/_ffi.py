@@ -75,7 +75,7 @@ SIGNATURES = {
     "vl_sumsq": (i32, [p, i64, p, p, i32, p]),
     "vl_sgd_apply": (i32, [p, p, i64, f32, f32, p, f32, p, p]),
     "vl_adam_apply": (i32, [p, p, p, p, i64, f32, f32, p, f32, i32, p, p]),
-    "vl_status_or": (i32, [p, p, p]),
+    "vl_status_or": (i32, [p, p, i32, p]),
     "vl_fill": (i32, [p, i64, f32, p]),
     "vl_resize_create": (i32, [C.POINTER(p), i32, i32, i32, i32, i32]),
     "vl_resize_destroy": (None, [p]),

@@ -14,15 +14,12 @@ description encoder-decoder -- behind the two-pipeline interface of round 2.  Th
 
 Every variable is scoped by its pipeline's name: "<pipeline>/<tf name>" (see graph.py).  The oracle of this composition is
 oracle.lrcn_oracle.encdec_forward / lstm_classifier_* / tensor_list_fusion (= model_forward on these two pipelines)."""
-import math
 from dataclasses import dataclass
 from typing import Optional
 
-import numpy as np
-
 from ._ffi import VltfError
 from .engine import NetConfig
-from .graph import DatasetInfo, GraphEngine, PipelineSpec, _trunc_normal
+from .graph import DatasetInfo, GraphEngine, PipelineSpec, init_params_for, model_specs
 
 
 @dataclass
@@ -42,40 +39,28 @@ class HeadConfig:
                                              # that many times (replicate_auxilliary_tensor, tf_util.py:182-192: whole batch tiled)
 
 
-def head_specs(h: HeadConfig, enc_dim: int, scope: str):
-    """[(name, shape)] of pipeline 2 (head fc, LSTM layers last to first, state fc, representation fc)."""
-    fused = h.in_dim + enc_dim if h.input_fusion == "concat" else h.in_dim       # the input fusion comes first (model.py:69-73)
-    seq_dim = h.fc_output_dim if h.representation == "fc" else fused            # then the representation (model.py:81-96)
-    H, C = h.lstm_hidden, h.num_classes
-    specs = []
-    if H != C:
-        head = "fc_convert" if h.fusion == "state" else "output_fc"
-        specs += [(scope + head + "_w", (H, C)), (scope + head + "_b", (C,))]
-    dims = [seq_dim] + [H] * (h.lstm_layers - 1)
-    for l in reversed(range(h.lstm_layers)):
-        pre = scope + "rnn/multi_rnn_cell/cell_%d/basic_lstm_cell/" % l
-        specs += [(pre + "kernel", (dims[l] + H, 4 * H)), (pre + "bias", (4 * H,))]
-    if h.input_fusion is None and enc_dim != H:
-        specs += [(scope + "input_state_fc_w", (enc_dim, H)), (scope + "input_state_fc_b", (H,))]
-    if h.representation == "fc" and h.fc_output_dim != fused:
-        specs += [(scope + "fc_convert_w", (fused, h.fc_output_dim)), (scope + "fc_convert_b", (h.fc_output_dim,))]
-    return specs
+def two_pipelines(enc_cfg: NetConfig, head: HeadConfig, max_clips: int, scopes=("enc", "dec")):
+    """([PipelineSpec, PipelineSpec], {tag: DatasetInfo}) of the two-pipeline model: what ComposedEngine hands to GraphEngine."""
+    p1 = PipelineSpec(scopes[0], ["main"], "dcnn", frame_encoding_layer=enc_cfg.frame_encoding_layer, classifier=enc_cfg.classifier,
+                      lstm_params=(enc_cfg.lstm_hidden, enc_cfg.lstm_layers, enc_cfg.fusion) if enc_cfg.classifier == "lstm" else None,
+                      frame_fusion=enc_cfg.frame_fusion if enc_cfg.classifier == "fc" else None)
+    p2 = PipelineSpec(scopes[1], ["aux", scopes[0]], head.representation, fc_output_dim=head.fc_output_dim, classifier="lstm",
+                      lstm_params=(head.lstm_hidden, head.lstm_layers, head.fusion), input_fusion=head.input_fusion)
+    datasets = {"main": DatasetInfo("video", enc_cfg.fpc, 1, max_clips, image_shape=tuple(enc_cfg.image_shape)),
+                "aux": DatasetInfo("vectors", head.fpc, head.cpv_ratio, max_clips * head.cpv_ratio, dim=head.in_dim)}
+    return [p1, p2], datasets
 
 
-def init_head_params(h: HeadConfig, enc_dim, scope, seed=0, stddev=0.05, well_scaled=False):
-    rng = np.random.default_rng(seed)
-    out = {}
-    for name, shp in head_specs(h, enc_dim, scope):
-        if name.endswith("kernel"):
-            lim = math.sqrt(6.0 / (shp[0] + shp[1]))
-            out[name] = rng.uniform(-lim, lim, shp).astype(np.float32)
-        elif name.endswith("bias"):
-            out[name] = np.zeros(shp, np.float32)
-        elif len(shp) > 1:
-            out[name] = _trunc_normal(rng, shp, math.sqrt(2.0 / shp[0]) if well_scaled else stddev)
-        else:
-            out[name] = np.full(shp, 0.1, np.float32)
-    return out
+def head_specs(enc_cfg: NetConfig, head: HeadConfig, scopes=("enc", "dec")):
+    """[(name, shape)] of pipeline 2's variables, from the ONE place that defines a model's variable list: the graph's plan
+    (graph.model_specs -> PipeNode.head_specs).  Round 3 kept a second copy of that logic here."""
+    pipes, datasets = two_pipelines(enc_cfg, head, 1, scopes)
+    return [(n, s) for n, s in model_specs(pipes, datasets, head.num_classes) if n.startswith(scopes[1] + "/")]
+
+
+def init_head_params(enc_cfg: NetConfig, head: HeadConfig, scopes=("enc", "dec"), seed=0, stddev=0.05, well_scaled=False):
+    """Reference initialisers (graph.init_params_for) for pipeline 2's variables only."""
+    return init_params_for(head_specs(enc_cfg, head, scopes), seed=seed, stddev=stddev, well_scaled=well_scaled)
 
 
 class ComposedEngine(GraphEngine):
@@ -89,14 +74,8 @@ class ComposedEngine(GraphEngine):
         if enc_cfg.classifier not in ("lstm", "fc"):
             raise VltfError("pipeline 1 of the two-pipeline model needs a classifier (lstm | fc)")
         self.h = head
-        p1 = PipelineSpec(scopes[0], ["main"], "dcnn", frame_encoding_layer=enc_cfg.frame_encoding_layer, classifier=enc_cfg.classifier,
-                          lstm_params=(enc_cfg.lstm_hidden, enc_cfg.lstm_layers, enc_cfg.fusion) if enc_cfg.classifier == "lstm" else None,
-                          frame_fusion=enc_cfg.frame_fusion if enc_cfg.classifier == "fc" else None)
-        p2 = PipelineSpec(scopes[1], ["aux", scopes[0]], head.representation, fc_output_dim=head.fc_output_dim, classifier="lstm",
-                          lstm_params=(head.lstm_hidden, head.lstm_layers, head.fusion), input_fusion=head.input_fusion)
-        datasets = {"main": DatasetInfo("video", enc_cfg.fpc, 1, max_clips, image_shape=tuple(enc_cfg.image_shape)),
-                    "aux": DatasetInfo("vectors", head.fpc, head.cpv_ratio, max_clips * head.cpv_ratio, dim=head.in_dim)}
-        super().__init__([p1, p2], datasets, head.num_classes, device, training, dp, optimizer=enc_cfg.optimizer,
+        pipes, datasets = two_pipelines(enc_cfg, head, max_clips, scopes)
+        super().__init__(pipes, datasets, head.num_classes, device, training, dp, optimizer=enc_cfg.optimizer,
                          dropout_keep_prob=head.dropout_keep_prob or enc_cfg.dropout_keep_prob, conv_math=enc_cfg.conv_math)
         self.enc_cfg = enc_cfg
         self.Ts = self.last.fpc                  # steps the second LSTM runs (one more under ibias)

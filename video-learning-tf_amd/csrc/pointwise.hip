@@ -819,9 +819,14 @@ static int launch_lrn_pool_fwd(const float* x, float* p, uint8_t* argmax, int n,
         }
     }
     VL_CHECK(prb > 0, "vl_lrn_pool_fwd: plane too wide (%d) for one band of pooled rows", w);
-    // balance the bands (e.g. 28 pooled rows, at most 5 per band -> 6 bands of 5,5,5,5,4,4 rather than 5,5,5,5,5,3)
-    const int bands = ceil_div(oh, prb);
+    // balance the bands (e.g. 28 pooled rows, at most 5 per band -> 6 bands of 5,5,5,5,4,4 rather than 5,5,5,5,5,3); few frames (one
+    // rank's 128-frame shard of the 8-GPU job: layer 2 was ONE band x 128 images = half the CUs, 98 us where 1/8 of the 1024-frame time
+    // is 37): cut more bands, up to two workgroups per CU, at the price of their shared input rows (round 4)
+    int bands = ceil_div(oh, prb);
+    const int want = ceil_div(2 * (int64_t)vl_device_cus(), n);
+    if (bands < want) bands = want < oh ? want : oh;
     prb = ceil_div(oh, bands);
+    bands = ceil_div(oh, prb);
     {
         const int need_px = ceil_div((2 * prb + 1) * w, PPT), need_out = ceil_div((int64_t)CHK * prb * ow, NSL);
         threads = ceil_div(need_px > need_out ? need_px : need_out, 64) * 64;
@@ -1041,10 +1046,17 @@ extern "C" int vl_maxpool_bwd(const float* dy, const uint8_t* argmax, float* dx,
     if (k == 3 && s == 2 && ys_c == 1 && ys_w == c && ys_h == (int64_t)ow * c && ys_n == (int64_t)oh * ow * c && n <= 65535 &&
         (size_t)64 * (oh * ow + 1) * 8 <= 48 * 1024 && !kMaxpoolGeneric) {
         // the (h, w, c)-flat pooled layout (pool5 -> fc6): LDS-transposed form
-        constexpr int CB = 64;
-        const size_t lds = (size_t)CB * (oh * ow + 1) * 8;
-        hipLaunchKernelGGL((maxpool_bwd_hwc_k3s2_kernel<CB>), dim3(ceil_div(c, CB), n), dim3(256), lds, (hipStream_t)stream, dy, argmax, dx,
-                           relu_mask, c, h, w, oh, ow, dx_halo);
+        // 64 channels per workgroup; 16 when that grid is under four workgroups per CU (128 frames: 512 workgroups of 48 serial
+        // iterations per wave took 45 us where 1/8 of the 1024-frame time is 18; round 4)
+        if ((int64_t)ceil_div(c, 64) * n >= 4ll * vl_device_cus()) {
+            constexpr int CB = 64;
+            hipLaunchKernelGGL((maxpool_bwd_hwc_k3s2_kernel<CB>), dim3(ceil_div(c, CB), n), dim3(256), (size_t)CB * (oh * ow + 1) * 8, (hipStream_t)stream,
+                               dy, argmax, dx, relu_mask, c, h, w, oh, ow, dx_halo);
+        } else {
+            constexpr int CB = 16;
+            hipLaunchKernelGGL((maxpool_bwd_hwc_k3s2_kernel<CB>), dim3(ceil_div(c, CB), n), dim3(256), (size_t)CB * (oh * ow + 1) * 8, (hipStream_t)stream,
+                               dy, argmax, dx, relu_mask, c, h, w, oh, ow, dx_halo);
+        }
         VL_LAUNCH_CHECK();
         return 0;
     }
@@ -1694,12 +1706,13 @@ __global__ void adam_apply_kernel(float* __restrict__ w, const float* __restrict
 }
 
 // *dst |= first word of an LSTM cluster workspace (its sticky time-out word, lstm_cluster.hip): the optimizer's `skip` word of a step
-__global__ void status_or_kernel(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src) {
-    if (*src) *dst = 1u;
+__global__ void status_or_kernel(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, int init) {
+    const uint32_t old = init ? 0u : *dst;
+    *dst = (*src != 0u) ? 1u : old;
 }
-extern "C" int vl_status_or(uint32_t* dst, const void* lstm_ws, vl_stream_t stream) {
+extern "C" int vl_status_or(uint32_t* dst, const void* lstm_ws, int init, vl_stream_t stream) {
     VL_CHECK(dst && lstm_ws, "vl_status_or: null argument");
-    hipLaunchKernelGGL(status_or_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, dst, (const uint32_t*)lstm_ws);
+    hipLaunchKernelGGL(status_or_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, dst, (const uint32_t*)lstm_ws, init);
     VL_LAUNCH_CHECK();
     return 0;
 }

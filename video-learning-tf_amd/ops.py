@@ -574,10 +574,11 @@ def step_guard(skip, *lstm_workspaces):
     sticky, lstm_seq_check reads and resets it), else 0 -- on the stream, no host round trip.  Hand `skip` to sgd_apply / adam_apply:
     a step whose recurrence gave up (its results are invalid by the kernel's own contract) must not reach the weights."""
     _skip_word(skip)
-    skip.zero_()
+    first = True                                  # no workspace: the word keeps the 0 it was created with (nothing ever sets it)
     for ws in lstm_workspaces:
         if ws is not None:
-            _ffi.call("vl_status_or", _p(skip), _p(ws), stream())
+            _ffi.call("vl_status_or", _p(skip), _p(ws), int(first), stream())
+            first = False
     return skip
 
 
