@@ -198,7 +198,8 @@ int vl_pool_lrn_bwd_test_ranges(int ranges);
 
 /* Fused forward of [LRN -> max_pool 3x3/2 VALID] (alexnet.py:79-98,120-139): p = max_pool(lrn(x)), argmax = window-local
  * index (0..8) of the first maximum in scan order; the LRN output is never written (vl_pool_lrn_bwd needs only x).
- * x dense NCHW [n][c][h][w]; p / argmax: NCHW with p_halo (only interiors are written). */
+ * x dense NCHW [n][c][h][w]; p / argmax: NCHW with p_halo.  The interior ROWS are written whole: the halo columns of those rows
+ * receive 0.0 in p (what a zero halo holds anyway) and unspecified bytes in argmax (its halo is never read); halo rows are not touched. */
 int vl_lrn_pool_fwd(const float* x, float* p, uint8_t* argmax, int n, int c, int h, int w, int p_halo, int radius,
                     float alpha, float beta, float bias, vl_stream_t stream);
 

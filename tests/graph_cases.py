@@ -67,6 +67,7 @@ CASES = {
     "two_stream_concat": lambda: two_stream("concat"), "fanout": fanout, "dcnn_with_state": dcnn_with_state,
     "fused_frames_avg": lambda: fused_frames("avg"), "fused_frames_maximum": lambda: fused_frames("maximum"),
     "encdec_state": lambda: encdec(), "encdec_concat_r2": lambda: encdec("concat", 2), "encdec_ibias_r3": lambda: encdec("ibias", 3),
+    "encdec_ibias_r1": lambda: encdec("ibias", 1),
     "encdec_state_r2_avg": lambda: encdec(None, 2, "avg"),
 }
 

@@ -168,12 +168,15 @@ def _dp_worker(rank, world, port, q, name):
     torch.distributed.destroy_process_group()
 
 
-@pytest.mark.parametrize("name,min_chunks", [("two_stream_avg", 5), ("dcnn_with_state", 3), ("fanout", 3), ("encdec_ibias_r3", 3)])
+@pytest.mark.parametrize("name,min_chunks", [("two_stream_avg", 5), ("dcnn_with_state", 3), ("fanout", 3), ("encdec_ibias_r1", 3)])
 def test_two_rank_graph_step_equals_one_rank(name, min_chunks):
     """Data parallel over clips for multi-pipeline models: each pipeline's head chunk, then each tower's own chunk list through its
     offset in the shared flat buffer; two ranks (gloo, one GPU) end with the parameters of one rank stepping on all the items.
-    `dcnn_with_state`, `fanout` and `encdec_ibias_r3` hold a `representation: fc` pipeline, whose fc_convert gradients round 3 exchanged
-    before they were written (tests/test_graph_cpu.py pins the order; this is the end-to-end form)."""
+    `dcnn_with_state`, `fanout` and `encdec_ibias_r1` hold a `representation: fc` pipeline, whose fc_convert gradients round 3 exchanged
+    before they were written (tests/test_graph_cpu.py pins the order; this is the end-to-end form).  (Not `encdec_ibias_r3`: at a
+    clips-per-video ratio > 1 replicate_auxilliary_tensor tiles the WHOLE batch of pipeline-1 vectors, tf_util.py:182-192, so which vector
+    meets which clip depends on the batch's composition -- a rank's shard pairs them as a smaller batch_size would in the reference, and
+    no sharding reproduces the one-rank step there.)"""
     import socket
     import torch.multiprocessing as mp
     s = socket.socket()

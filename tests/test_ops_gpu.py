@@ -439,9 +439,14 @@ def test_pool_lrn_bwd_channel_ranges(ops, request, ranges, n, h, w, c, ph, dh):
     close(nhwc(host(interior(dx, dh))), want, rtol=1e-5, atol_rel=1e-6)          # every interior element written (no NaN left)
 
 
-@pytest.mark.parametrize("n,h,w,c,ph", [(2, 9, 11, 7, 0), (3, 13, 13, 20, 1), (2, 57, 57, 96, 2), (2, 28, 28, 256, 1), (1, 31, 64, 5, 0)])
-def test_lrn_pool_fwd_fused(ops, n, h, w, c, ph):
-    """Fused kernel == lrn followed by max_pool_valid of the oracle (values and first-maximum arg-max), halo untouched."""
+@pytest.mark.parametrize("ranges", [0, 2, 3, 4])
+@pytest.mark.parametrize("n,h,w,c,ph", [(2, 9, 11, 7, 0), (3, 13, 13, 20, 1), (2, 57, 57, 96, 2), (2, 28, 28, 256, 1), (1, 31, 64, 5, 0), (2, 13, 13, 41, 1)])
+def test_lrn_pool_fwd_fused(ops, request, n, h, w, c, ph, ranges):
+    """Fused kernel == lrn followed by max_pool_valid of the oracle (values and first-maximum arg-max), halo untouched.  `ranges`: the
+    channel walk cut into that many ranges (grid z; 0 = the launcher's choice, which splits these few-image launches by itself): every
+    range restarts the LRN window two channels early and must reproduce the oracle at its seams."""
+    ops.pool_lrn_bwd_test_ranges(ranges)
+    request.addfinalizer(lambda: ops.pool_lrn_bwd_test_ranges(0))
     rng = np.random.default_rng(h * c + w)
     x = np.maximum(rng.standard_normal((n, h, w, c)) * 30, 0).astype(np.float32)
     l, _ = O.lrn(x)
@@ -461,8 +466,10 @@ def test_lrn_pool_fwd_fused(ops, n, h, w, c, ph):
         return l[np.arange(n)[:, None, None, None], ii, jj, np.arange(c)[None, None, None, :]]
     diff = np.abs(window_value(got_arg) - window_value(arg.astype(np.int64)))
     assert (got_arg != arg).mean() < 1e-3 and diff.max() <= 1e-5 * np.abs(l).max()
-    if ph:
-        assert float((p[:, :, :ph] - 5.0).abs().max()) == 0 and int(ap[:, :, :, -ph:].min()) == 77
+    if ph:      # halo ROWS untouched; the halo columns of interior rows are stored with the row: 0.0 in p, unspecified in the arg-max map
+        assert float((p[:, :, :ph] - 5.0).abs().max()) == 0 and float((p[:, :, -ph:] - 5.0).abs().max()) == 0
+        assert int(ap[:, :, :ph].min()) == 77 and int(ap[:, :, -ph:].min()) == 77
+        assert float(p[:, :, ph:-ph, :ph].abs().max()) == 0 and float(p[:, :, ph:-ph, -ph:].abs().max()) == 0
 
 
 def test_colsum(ops):

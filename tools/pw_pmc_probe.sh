@@ -45,3 +45,4 @@ for k in ("pool_lrn_bwd_1", "pool_lrn_bwd_2", "lrn_pool_fwd_1", "lrn_pool_fwd_2"
     print("                 HBM: fetched %.3f GB (FETCH_SIZE x 2: %s KB units), written %.3f GB | L2 hit %.1f %%"
           % (g("FETCH_SIZE") * 2 * 1024 / 1e9, "%.0f" % g("FETCH_SIZE"), g("WRITE_SIZE") * 1024 / 1e9, 100 * g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum"))))
 P
+find $out -name "*_results.db" -delete      # the summary is what is kept (gpurun copies at most 64 MiB back)

@@ -304,6 +304,21 @@ __global__ __launch_bounds__(256) void pool_lrn_bwd_kernel(const float* __restri
 // pooled rows, i.e. two addresses + an immediate.  x loads / dx stores are buffer accesses with a per-thread constant
 // pixel offset and a scalar channel offset: pixels past the plane fail the range check (loads 0, stores dropped).
 // Channel cc enters the x window at iteration cc; t[cc-2] is then computable, and the output of channel cc-4.
+// (band, image) of a workgroup in XCD-aware order (round 4).  Workgroup ids are dealt round-robin over the 8 XCDs, each with its own L2;
+// with the natural order (band fastest) the bands of one image -- which share input rows / pooled rows at their seams, and for the
+// backward kernel re-read each pooled row 2.25 times between them -- land on 8 different L2s and every re-read is an HBM fetch
+// (measured: 1.44 x the algorithmic bytes fetched, tools/pw_pmc_probe.sh).  Here eight consecutive images take the 8 XCDs and an
+// image's bands follow each other on ITS XCD, eight ids apart, i.e. dispatched together.  Grid = (bands, images rounded up to 8, z);
+// false = padding.  Placement affects speed only.
+__device__ __forceinline__ bool xcd_band_image(int nimg, int& band, int& img) {
+    const int nb = gridDim.x;
+    const int L = blockIdx.y * nb + blockIdx.x;
+    const int g = L / (nb * 8), r = L - g * (nb * 8);
+    band = r >> 3;
+    img = g * 8 + (r & 7);
+    return img < nimg;
+}
+
 static constexpr uint32_t PW_OOB = 0xF0000000u;   // fails the range check of every resource built below (sizes < 2^31)
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t pw_rsrc(const void* base, int64_t bytes) {
@@ -319,7 +334,7 @@ template <int CHK, int NST, bool RELU, int C8 = 0>
 __global__ __launch_bounds__(256, (C8 ? 3 : 1)) void pool_lrn_bwd_stream_kernel(const float* __restrict__ x, const float* __restrict__ dp,
                                                                   const uint8_t* __restrict__ arg, float* __restrict__ dx, int C,
                                                                   int H, int W, int OH, int OW, int64_t ps_n, int ps_c, int ps_h,
-                                                                  int64_t pooled_bytes_f, float alpha, float bias, int halo, int cper) {
+                                                                  int64_t pooled_bytes_f, float alpha, float bias, int halo, int cper, int nimg) {
     constexpr int BUF = NST * 256 + 16;                               // entries per LDS buffer (+ pad: entries -1 and one-past-the-end are read)
     // blockIdx.z owns the OUTPUT channels [R0, R1) (cper channels; the whole tensor when the grid is flat).  Its walk starts LEAD
     // channels earlier with empty windows: what it computes for channels below R0 there is wrong and dropped, and by channel R0 the x
@@ -330,8 +345,9 @@ __global__ __launch_bounds__(256, (C8 ? 3 : 1)) void pool_lrn_bwd_stream_kernel(
     const int cs = max(R0 - LEAD, 0);                                 // never below channel 0: windows that start there ARE empty
     __shared__ __attribute__((aligned(16))) uint2 stage[2 * BUF];
     const int HW = H * W;
-    const int img = blockIdx.y;
-    const int p0 = blockIdx.x * 256, p = p0 + threadIdx.x;
+    int band, img;
+    if (!xcd_band_image(nimg, band, img)) return;
+    const int p0 = band * 256, p = p0 + threadIdx.x;
     const bool valid = p < HW;
     const int pc = valid ? p : HW - 1;
     const int py = pc / W, px = pc - py * W;
@@ -508,6 +524,7 @@ __global__ __launch_bounds__(256, (C8 ? 3 : 1)) void pool_lrn_bwd_stream_kernel(
 // Channel ranges per (band, image) of the channel-stream backward: the count (<= 4) with the fewest rounds x channels walked, a
 // round = 8 workgroups per CU (56 VGPRs, 12.5 KB of LDS).  `unit`: ranges start at multiples of it (8 for the packed output).
 static int g_plb_forced_ranges = 0;
+static int g_lpf_forced_ranges = 0;            // tests: vl_pool_lrn_bwd_test_ranges forces the forward's channel-range count as well
 static int plb_channel_ranges(int64_t workgroups, int c, int unit, int lead, int* cper) {
     const int64_t slots = 8ll * vl_device_cus();
     int best = 1;
@@ -534,6 +551,7 @@ static int plb_channel_ranges(int64_t workgroups, int c, int unit, int lead, int
 extern "C" int vl_pool_lrn_bwd_test_ranges(int ranges) {
     VL_CHECK(ranges >= 0 && ranges <= 4, "vl_pool_lrn_bwd_test_ranges: 0 (automatic) .. 4");
     g_plb_forced_ranges = ranges;
+    g_lpf_forced_ranges = ranges;                 // vl_lrn_pool_fwd / _c8 split their channel walk the same way (at most 8 ranges on their own)
     return 0;
 }
 
@@ -546,7 +564,7 @@ extern "C" int vl_pool_lrn_bwd(const float* x, const float* dp, const uint8_t* a
     const int owp = ow + 2 * p_halo;
     const int64_t pplane = (int64_t)(oh + 2 * p_halo) * owp;
     const int64_t origin = (int64_t)p_halo * owp + p_halo;
-    VL_CHECK(n <= 65535, "vl_pool_lrn_bwd: batch %d exceeds the grid limit", n);
+    VL_CHECK(n <= 65528, "vl_pool_lrn_bwd: batch %d exceeds the grid limit", n);
     {   // channel-stream form: a 256-pixel band x one channel chunk of pooled entries must fit NST * 256 staging slots
         const int rows = (255 + w - 1) / w + 1;                        // input rows a 256-pixel band can touch
         const int max_prow = rows / 2 + 2;
@@ -556,16 +574,16 @@ extern "C" int vl_pool_lrn_bwd(const float* x, const float* dp, const uint8_t* a
                         !kPoolLrnChunked;
         int cper = c;
         const int nz = plb_channel_ranges((int64_t)ceil_div((int64_t)h * w, 256) * n, c, 1, 4, &cper);
-        const dim3 grid(ceil_div((int64_t)h * w, 256), n, nz);
+        const dim3 grid(ceil_div((int64_t)h * w, 256), (n + 7) / 8 * 8, nz);   // images padded to the 8 XCDs (xcd_band_image)
         const int64_t psn = (int64_t)c * pplane;
 #define VL_PLB_LAUNCH(CHK, NST)                                                                                                     \
     do {                                                                                                                            \
         if (relu_fused)                                                                                                             \
             hipLaunchKernelGGL((pool_lrn_bwd_stream_kernel<CHK, NST, true, 0>), grid, dim3(256), 0, (hipStream_t)stream, x, dp + origin, \
-                               argmax + origin, dx, c, h, w, oh, ow, psn, (int)pplane, owp, pooled_f, alpha, bias, dx_halo, cper);  \
+                               argmax + origin, dx, c, h, w, oh, ow, psn, (int)pplane, owp, pooled_f, alpha, bias, dx_halo, cper, n);  \
         else                                                                                                                        \
             hipLaunchKernelGGL((pool_lrn_bwd_stream_kernel<CHK, NST, false, 0>), grid, dim3(256), 0, (hipStream_t)stream, x, dp + origin, \
-                               argmax + origin, dx, c, h, w, oh, ow, psn, (int)pplane, owp, pooled_f, alpha, bias, dx_halo, cper);  \
+                               argmax + origin, dx, c, h, w, oh, ow, psn, (int)pplane, owp, pooled_f, alpha, bias, dx_halo, cper, n);  \
         VL_LAUNCH_CHECK();                                                                                                          \
         return 0;                                                                                                                   \
     } while (0)
@@ -596,7 +614,7 @@ extern "C" int vl_pool_lrn_bwd_c8(const void* x, int x_packed, const float* dp, 
                                   int p_halo, int radius, float alpha, float beta, float bias, int relu_fused, int dxb_halo, vl_stream_t stream) {
     VL_CHECK(x && dp && argmax && dxb && n > 0 && c > 0 && h >= 3 && w >= 3 && p_halo >= 0 && dxb_halo >= 0, "vl_pool_lrn_bwd_c8: bad argument");
     VL_CHECK(radius == 2 && beta == 0.75f, "vl_pool_lrn_bwd_c8: only depth_radius 2, beta 0.75 are built (alexnet.py:81-84)");
-    VL_CHECK(n <= 65535, "vl_pool_lrn_bwd_c8: batch %d exceeds the grid limit", n);
+    VL_CHECK(n <= 65528, "vl_pool_lrn_bwd_c8: batch %d exceeds the grid limit", n);
     const int oh = (h - 3) / 2 + 1, ow = (w - 3) / 2 + 1;
     const int owp = ow + 2 * p_halo;
     const int64_t pplane = (int64_t)(oh + 2 * p_halo) * owp;
@@ -608,12 +626,12 @@ extern "C" int vl_pool_lrn_bwd_c8(const void* x, int x_packed, const float* dp, 
              "vl_pool_lrn_bwd_c8: plane too large for the channel-stream form");
     int cper = c;
     const int nz = plb_channel_ranges((int64_t)ceil_div((int64_t)h * w, 256) * n, c, 8, 8, &cper);
-    const dim3 grid(ceil_div((int64_t)h * w, 256), n, nz);
+    const dim3 grid(ceil_div((int64_t)h * w, 256), (n + 7) / 8 * 8, nz);
     const int64_t psn = (int64_t)c * pplane;
     const float* xf = (const float*)x;
 #define VL_PLBC(RELU, MODE)                                                                                                             \
     hipLaunchKernelGGL((pool_lrn_bwd_stream_kernel<8, 5, RELU, MODE>), grid, dim3(256), 0, (hipStream_t)stream, xf, dp + origin, argmax + origin, \
-                       (float*)dxb, c, h, w, oh, ow, psn, (int)pplane, owp, pooled_f, alpha, bias, dxb_halo, cper)
+                       (float*)dxb, c, h, w, oh, ow, psn, (int)pplane, owp, pooled_f, alpha, bias, dxb_halo, cper, n)
     if (relu_fused && x_packed) VL_PLBC(true, 2);
     else if (relu_fused) VL_PLBC(true, 1);
     else if (x_packed) VL_PLBC(false, 2);
@@ -658,14 +676,25 @@ extern "C" int vl_lrn_bwd(const float* x, const float* dy, float* dx, int n, int
 // C8: pout is the packed-bf16 "c8" tensor [image][C / 8][pooled plane][8] (conv_c8.hip) instead of fp32 NCHW: each pooled output is
 // stored as one bf16 (nearest even) at its channel's slot of the pixel's chunk; the arg-max map is unchanged.
 // C8 == 2: x is packed too ([image][C / 8][H][W][8] bf16, no halo): a 16-byte load per pixel brings 8 channels = four 2-channel chunks.
-template <int CHK, int PPT, int NSL, int C8 = 0>
+// VEC (fp32 input only; PPT = 4): a thread owns FOUR CONSECUTIVE pixels and fetches them with one 16-byte load per channel (any 4-byte
+// alignment) instead of PPT pixels a workgroup-width apart with one dword load each.  Round 4: the dword form moved 3.9 TB/s whatever its
+// band size, barrier width or prefetch depth (PMC: 70 % of wave cycles waiting, VALU 8 % busy, LDS 1 %) -- the rate of 4-byte-per-lane
+// streams on this chip (the 16-byte-per-lane kernels, sgd_apply, reach 6.5).
+template <int CHK, int PPT, int NSL, int C8 = 0, int DEPTH = 1, bool VEC = false, int SKIP = 0>   // SKIP: experiments (parts compiled out)
 __global__ __launch_bounds__(512) void lrn_pool_fwd_kernel(const float* __restrict__ x, float* __restrict__ pout,
                                                            uint8_t* __restrict__ argout, int C, int H, int W, int OH, int OW, int prb,
-                                                           int pplane, int owp, int p_halo, float alpha, float bias) {
+                                                           int pplane, int owp, int p_halo, float alpha, float bias, int cper, int nimg) {
     extern __shared__ __attribute__((aligned(16))) float lbuf[];      // [2][CHK][npix]
+    // blockIdx.z owns the OUTPUT channels [R0, R1) (cper of them, a multiple of CHK; the whole tensor when the grid is flat): its walk
+    // starts two channels (one chunk) early so that the LRN window of channel R0 is complete, and ends two channels late.  Few-frame
+    // launches only (round 4): 128 frames of layer 2 were 512 two-wave workgroups walking 256 channels each, 79 us where 1/8 of the
+    // 1024-frame time is 37.
+    const int R0 = blockIdx.z * cper, R1 = min(C, R0 + cper);
+    const int cs = max(R0 - CHK, 0);                                  // CHK >= 2 = the LRN radius
     const int T = blockDim.x;
-    const int img = blockIdx.y;
-    const int oh_a = blockIdx.x * prb;
+    int band, img;
+    if (!xcd_band_image(nimg, band, img)) return;                     // bands of an image share an input row at every seam
+    const int oh_a = band * prb;
     const int nprow = min(prb, OH - oh_a);                            // pooled rows of this band
     const int npix = (2 * nprow + 1) * W;                             // input pixels of this band
     const int p_base = 2 * oh_a * W;
@@ -680,21 +709,33 @@ __global__ __launch_bounds__(512) void lrn_pool_fwd_kernel(const float* __restri
     int lpix[PPT];                                                    // band-local pixel, -1 = none
 #pragma unroll
     for (int q = 0; q < PPT; ++q) {
-        const int pix = threadIdx.x + q * T;
+        const int pix = VEC ? PPT * (int)threadIdx.x + q : (int)threadIdx.x + q * T;
         lpix[q] = pix < npix ? pix : -1;                              // (-1: its LRN values go to the buffer's spare slot)
         voff_x[q] = pix < npix ? (uint32_t)(p_base + pix) * (C8 == 2 ? 16u : 4u) : PW_OOB;
     }
+    static_assert(!VEC || (PPT == 4 && C8 != 2), "vector form: four consecutive fp32 pixels per thread");
     // pooled outputs of a chunk: o = tid + s T  <->  (slab ci, pooled row, pooled column)
+    // fp32 output: the slots enumerate WHOLE rows of the halo layout, halo columns included (they store 0.0 = what the halo holds by
+    // contract; the arg-max map's halo is never read), so that a wave's stores are runs of full 32-byte sectors.  Round 4, parts of the
+    // kernel compiled out (VL_LRN_POOL_FORM, experiment build): loads + LRN + LDS writes alone ran at 5.4 - 5.9 TB/s, the two stores per
+    // pooled output -- 112-byte value rows and 28-byte arg-max rows at a 128- / 32-byte pitch: every sector of the arg-max map written
+    // partially -- cost a third of the kernel.  The packed output (C8) keeps interior slots (2-byte stores into 16-byte chunks).
+    constexpr bool ROWS = C8 == 0;
     int s_lds[NSL], s_out[NSL];                                       // LDS float offset of the window origin | ci << 24 | output element offset
-    const int per_slab = nprow * OW;
+    uint32_t s_halo = 0;                                              // bit sl: slot sl is a halo column (stores 0)
+    const int row_w = ROWS ? owp : OW;
+    const int per_slab = nprow * row_w;
 #pragma unroll
     for (int sl = 0; sl < NSL; ++sl) {
         const int o = threadIdx.x + sl * T;
         const int ci = o / per_slab, rem = o - ci * per_slab;
-        const int ohl = rem / OW, ow = rem - ohl * OW;
+        const int ohl = rem / row_w, col = rem - ohl * row_w;
+        const int ow = ROWS ? col - p_halo : col;
         const bool ok = ci < CHK;
-        s_lds[sl] = ok ? ci * npix + 2 * ohl * W + 2 * ow : 0;
+        const bool inner = ow >= 0 && ow < OW;
+        s_lds[sl] = (ok && inner) ? ci * npix + 2 * ohl * W + 2 * ow : 0;
         s_out[sl] = ok ? (ci << 24) | ((oh_a + ohl + p_halo) * owp + ow + p_halo) : -1;
+        if (ok && !inner) s_halo |= 1u << sl;
     }
     const int x_cs = HW * 4;
     float xa[PPT][CHK], xb[PPT][CHK];
@@ -702,9 +743,17 @@ __global__ __launch_bounds__(512) void lrn_pool_fwd_kernel(const float* __restri
 #pragma unroll
         for (int i = 0; i < CHK; ++i) {
             const int cc = c0 + i;                                    // uniform; channels past C: the range check answers 0
+            if constexpr (VEC) {                                      // the quad may run past the band's last pixel: in-range memory or
+                typedef float f4 __attribute__((ext_vector_type(4))); // range-checked zeros, its values go to the spare slot
+                typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+                const f4 w = __builtin_bit_cast(f4, __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)(cc < C ? voff_x[0] : PW_OOB), cc * x_cs, 0)));
 #pragma unroll
-            for (int q = 0; q < PPT; ++q)
-                v[q][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, (int)(cc < C ? voff_x[q] : PW_OOB), cc * x_cs, 0));
+                for (int q = 0; q < PPT; ++q) v[q][i] = w[q];
+            } else {
+#pragma unroll
+                for (int q = 0; q < PPT; ++q)
+                    v[q][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, (int)(cc < C ? voff_x[q] : PW_OOB), cc * x_cs, 0));
+            }
         }
     };
     float xw[PPT][5];
@@ -725,16 +774,16 @@ __global__ __launch_bounds__(512) void lrn_pool_fwd_kernel(const float* __restri
 #pragma unroll
                 for (int d = 0; d < 5; ++d) sq += xw[q][d] * xw[q][d];
                 const float sc = bias + alpha * sq;
-                const float rq = __builtin_amdgcn_rsqf(sc);
-                const float l = xw[q][2] * (rq * __builtin_amdgcn_sqrtf(rq));   // x * sc^-0.75 (pow_neg's beta = 0.75 form)
+                const float rq = (SKIP & 4) ? sc : __builtin_amdgcn_rsqf(sc);
+                const float l = xw[q][2] * ((SKIP & 4) ? rq : rq * __builtin_amdgcn_sqrtf(rq));   // x * sc^-0.75 (pow_neg's beta = 0.75 form)
                 lb[lpix[q] >= 0 ? i * npix + lpix[q] : CHK * npix] = l;
             }
         }
-        __syncthreads();
+        if (!(SKIP & 8)) __syncthreads();
 #pragma unroll
-        for (int sl = 0; sl < NSL; ++sl) {
+        for (int sl = 0; sl < ((SKIP & 2) ? 0 : NSL); ++sl) {
             const int c = c0 - 2 + (s_out[sl] >> 24);
-            const bool live = s_out[sl] >= 0 && c >= 0 && c < C;      // dead lanes scan slab 0's first window and store out of range
+            const bool live = s_out[sl] >= 0 && c >= R0 && c < R1;    // dead lanes scan slab 0's first window and store out of range
             {
                 const float* wp = lb + s_lds[sl];
                 float best = -INFINITY;
@@ -750,18 +799,22 @@ __global__ __launch_bounds__(512) void lrn_pool_fwd_kernel(const float* __restri
                         }
                     }
                 const int off = c * pplane + (s_out[sl] & 0xffffff);
+                if (ROWS && ((s_halo >> sl) & 1u)) {                  // halo column: dead lanes scanned slab 0's first window
+                    best = 0.f;
+                    bi = 0;
+                }
                 if constexpr (C8 != 0) {
                     const __bf16 hb = (__bf16)best;
                     __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(uint16_t, hb), rs_p,
                                                           live ? ((c >> 3) * pplane + (s_out[sl] & 0xffffff)) * 16 + (c & 7) * 2 : (int)PW_OOB, 0, 0);
                 } else {
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, best), rs_p, live ? off * 4 : (int)PW_OOB, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, best), rs_p, (live && !(SKIP & 1)) ? off * 4 : (int)PW_OOB, 0, 0);
                 }
-                __builtin_amdgcn_raw_buffer_store_b8((uint8_t)bi, rs_a, live ? off : (int)PW_OOB, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b8((uint8_t)bi, rs_a, (live && !(SKIP & 1)) ? off : (int)PW_OOB, 0, 0);
             }
         }
     };
-    const int nchunks = (C + 2 + CHK - 1) / CHK;
+    const int nchunks = (R1 + 2 - cs + CHK - 1) / CHK;
     if constexpr (C8 == 2) {
         static_assert(C8 != 2 || CHK == 2, "packed input: 2-channel chunks (one dword of a pixel's 16-byte block)");
         typedef uint32_t u4 __attribute__((ext_vector_type(4)));
@@ -771,12 +824,15 @@ __global__ __launch_bounds__(512) void lrn_pool_fwd_kernel(const float* __restri
             for (int q = 0; q < PPT; ++q)
                 v[q] = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)(kb < CB ? voff_x[q] : PW_OOB), kb * HW * 16, 0));
         };
-        blk_load(0, cur);
-        for (int kb = 0; kb * 4 < nchunks; ++kb) {
+        // (channel ranges of the packed form are multiples of 8: cs = R0 - 2 lies in the block before R0's; the walk starts at that
+        // block's first chunk and the chunks below cs only fill the window -- they compute channels the `live` test drops)
+        const int kb0 = cs >> 3, kend = (R1 + 2 + CHK - 1) / CHK;     // first block; chunk index (from channel 0) behind the last one
+        blk_load(kb0, cur);
+        for (int kb = kb0; kb * 4 < kend; ++kb) {
             blk_load(kb + 1, nxt);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                if (kb * 4 + j >= nchunks) break;
+                if (kb * 4 + j >= kend) break;
                 float xin[PPT][CHK];
 #pragma unroll
                 for (int q = 0; q < PPT; ++q) {
@@ -790,17 +846,35 @@ __global__ __launch_bounds__(512) void lrn_pool_fwd_kernel(const float* __restri
         }
         return;
     }
-    x_load(0, xa);
+    if constexpr (DEPTH > 1) {
+        // DEPTH chunks of loads in flight (a ring of DEPTH + 1 register sets, the loop unrolled by that): with one chunk ahead a wave
+        // waited a whole memory latency per 2-channel chunk (PMC: 70 % of wave cycles in waitcnt / barrier, VALU 8 % busy: round 4)
+        constexpr int R = DEPTH + 1;
+        static_assert(R % 2 == 0, "ring length even: the LDS double buffer's parity then follows the ring slot");
+        float xr[R][PPT][CHK];
+#pragma unroll
+        for (int j = 0; j < DEPTH; ++j) x_load(cs + j * CHK, xr[j]);
+        for (int k = 0; k < nchunks; k += R) {
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                if (k + j >= nchunks) break;
+                x_load(cs + (k + j + DEPTH) * CHK, xr[(j + DEPTH) % R]);
+                chunk(cs + (k + j) * CHK, j & 1, xr[j]);
+            }
+        }
+        return;
+    }
+    x_load(cs, xa);
     for (int k = 0; k < nchunks; k += 2) {                            // unrolled by two: the x registers alternate without copies
-        x_load((k + 1) * CHK, xb);
-        chunk(k * CHK, 0, xa);
+        x_load(cs + (k + 1) * CHK, xb);
+        chunk(cs + k * CHK, 0, xa);
         if (k + 1 >= nchunks) break;
-        x_load((k + 2) * CHK, xa);
-        chunk((k + 1) * CHK, 1, xb);
+        x_load(cs + (k + 2) * CHK, xa);
+        chunk(cs + (k + 1) * CHK, 1, xb);
     }
 }
 
-template <int CHK, int PPT, int NSL, int C8 = 0>
+template <int CHK, int PPT, int NSL, int C8 = 0, int DEPTH = 1, bool VEC = false, int SKIP = 0>
 static int launch_lrn_pool_fwd(const float* x, float* p, uint8_t* argmax, int n, int c, int h, int w, int p_halo, float alpha, float bias,
                                hipStream_t stream) {
     const int oh = (h - 3) / 2 + 1, ow = (w - 3) / 2 + 1;
@@ -811,7 +885,7 @@ static int launch_lrn_pool_fwd(const float* x, float* p, uint8_t* argmax, int n,
     int prb = 0, threads = 0;
     for (int cand = oh; cand >= 1 && !prb; --cand) {
         const int npix = (2 * cand + 1) * w;
-        const int need_px = ceil_div(npix, PPT), need_out = ceil_div((int64_t)CHK * cand * ow, NSL);
+        const int need_px = ceil_div(npix, PPT), need_out = ceil_div((int64_t)CHK * cand * (C8 == 0 ? owp : ow), NSL);
         int t = ceil_div(need_px > need_out ? need_px : need_out, 64) * 64;
         if (t <= 512 && (size_t)2 * (CHK * npix + 1) * sizeof(float) <= 64 * 1024) {
             prb = cand;
@@ -823,19 +897,36 @@ static int launch_lrn_pool_fwd(const float* x, float* p, uint8_t* argmax, int n,
     // rank's 128-frame shard of the 8-GPU job: layer 2 was ONE band x 128 images = half the CUs, 98 us where 1/8 of the 1024-frame time
     // is 37): cut more bands, up to two workgroups per CU, at the price of their shared input rows (round 4)
     int bands = ceil_div(oh, prb);
-    const int want = ceil_div(2 * (int64_t)vl_device_cus(), n);
+    int want = ceil_div(2 * (int64_t)vl_device_cus(), n);
+    static const int exp_prb = vl_exp_env("VL_LRN_POOL_PRB") ? atoi(vl_exp_env("VL_LRN_POOL_PRB")) : 0;   // experiments: pooled rows per band
+    if (exp_prb > 0) want = ceil_div(oh, exp_prb);
     if (bands < want) bands = want < oh ? want : oh;
     prb = ceil_div(oh, bands);
     bands = ceil_div(oh, prb);
     {
-        const int need_px = ceil_div((2 * prb + 1) * w, PPT), need_out = ceil_div((int64_t)CHK * prb * ow, NSL);
+        const int need_px = ceil_div((2 * prb + 1) * w, PPT), need_out = ceil_div((int64_t)CHK * prb * (C8 == 0 ? owp : ow), NSL);
         threads = ceil_div(need_px > need_out ? need_px : need_out, 64) * 64;
     }
     const size_t lds = (size_t)2 * (CHK * (2 * prb + 1) * w + 1) * sizeof(float);       // two buffers, each with a spare slot
     static const bool verbose = vl_exp_env("VL_LRN_POOL_VERBOSE") != nullptr;
     if (verbose) fprintf(stderr, "lrn_pool_fwd<%d,%d,%d>: bands %d prb %d threads %d lds %zu\n", CHK, PPT, NSL, bands, prb, threads, lds);
-    hipLaunchKernelGGL((lrn_pool_fwd_kernel<CHK, PPT, NSL, C8>), dim3(bands, n), dim3(threads), lds, stream, x, p, argmax, c, h,
-                       w, oh, ow, prb, (int)pplane, owp, p_halo, alpha, bias);
+    // channel ranges (grid z) until the launch holds eight workgroups per CU, in units of 8 channels (whole packed blocks, whole chunks),
+    // at least 32 channels each: every range re-reads 2 + 2 channels of its neighbours
+    int nz = 1, cper = c;
+    {
+        const int64_t wgs = (int64_t)bands * n, slots = 8ll * vl_device_cus();
+        const int can = c / 32 > 0 ? c / 32 : 1;
+        int wantz = (int)((slots + wgs - 1) / wgs);
+        wantz = wantz > 8 ? 8 : wantz;
+        wantz = wantz > can ? can : wantz;
+        if (g_lpf_forced_ranges >= 1) wantz = g_lpf_forced_ranges;
+        if (wantz > 1) {
+            cper = ((c + wantz - 1) / wantz + 7) / 8 * 8;
+            nz = (c + cper - 1) / cper;
+        }
+    }
+    hipLaunchKernelGGL((lrn_pool_fwd_kernel<CHK, PPT, NSL, C8, DEPTH, VEC, SKIP>), dim3(bands, (n + 7) / 8 * 8, nz), dim3(threads), lds, stream, x, p, argmax, c, h,
+                       w, oh, ow, prb, (int)pplane, owp, p_halo, alpha, bias, cper, n);
     VL_LAUNCH_CHECK();
     return 0;
 }
@@ -844,7 +935,7 @@ extern "C" int vl_lrn_pool_fwd(const float* x, float* p, uint8_t* argmax, int n,
                                float alpha, float beta, float bias, vl_stream_t stream) {
     VL_CHECK(x && p && argmax && n > 0 && c > 0 && h >= 3 && w >= 3 && p_halo >= 0, "vl_lrn_pool_fwd: bad argument");
     VL_CHECK(radius == 2 && beta == 0.75f, "vl_lrn_pool_fwd: only depth_radius 2, beta 0.75 are built (alexnet.py:81-84)");
-    VL_CHECK(n <= 65535, "vl_lrn_pool_fwd: batch %d exceeds the grid limit", n);
+    VL_CHECK(n <= 65528, "vl_lrn_pool_fwd: batch %d exceeds the grid limit", n);
     const int oh = (h - 3) / 2 + 1, ow = (w - 3) / 2 + 1;
     const int owp = ow + 2 * p_halo;
     const int64_t pplane = (int64_t)(oh + 2 * p_halo) * owp;
@@ -857,7 +948,20 @@ extern "C" int vl_lrn_pool_fwd(const float* x, float* p, uint8_t* argmax, int n,
     static const bool r1 = vl_exp_env("VL_LRN_POOL_R1") != nullptr;
     hipStream_t s = (hipStream_t)stream;
     if (r1) return launch_lrn_pool_fwd<8, 3, 6>(x, p, argmax, n, c, h, w, p_halo, alpha, bias, s);
-    return launch_lrn_pool_fwd<2, 2, 1>(x, p, argmax, n, c, h, w, p_halo, alpha, bias, s);
+    static const int form = vl_exp_env("VL_LRN_POOL_FORM") ? atoi(vl_exp_env("VL_LRN_POOL_FORM")) : 0;   // experiments (round 4 sweep)
+    if (form == 1) return launch_lrn_pool_fwd<2, 2, 1, 0, 1>(x, p, argmax, n, c, h, w, p_halo, alpha, bias, s);          // round 3's dword form
+    if (form == 3) return launch_lrn_pool_fwd<2, 2, 1, 0, 3>(x, p, argmax, n, c, h, w, p_halo, alpha, bias, s);          // + 3 chunks in flight
+    if (form == 11) return launch_lrn_pool_fwd<2, 4, 2, 0, 1, true>(x, p, argmax, n, c, h, w, p_halo, alpha, bias, s);   // 16-byte loads
+    if (form == 13) return launch_lrn_pool_fwd<2, 4, 2, 0, 3, true>(x, p, argmax, n, c, h, w, p_halo, alpha, bias, s);   // + 3 chunks in flight
+    if (form == 21) return launch_lrn_pool_fwd<4, 4, 4, 0, 1, true>(x, p, argmax, n, c, h, w, p_halo, alpha, bias, s);   // 4-channel chunks
+#ifdef VL_EXPERIMENTS
+    if (form == 31) return launch_lrn_pool_fwd<2, 2, 1, 0, 1, false, 1>(x, p, argmax, n, c, h, w, p_halo, alpha, bias, s);    // no stores
+    if (form == 32) return launch_lrn_pool_fwd<2, 2, 1, 0, 1, false, 2>(x, p, argmax, n, c, h, w, p_halo, alpha, bias, s);    // no pooling phase
+    if (form == 34) return launch_lrn_pool_fwd<2, 2, 1, 0, 1, false, 4>(x, p, argmax, n, c, h, w, p_halo, alpha, bias, s);    // no transcendentals
+    if (form == 40) return launch_lrn_pool_fwd<2, 2, 1, 0, 1, false, 10>(x, p, argmax, n, c, h, w, p_halo, alpha, bias, s);   // no pooling, no barrier
+    if (form == 46) return launch_lrn_pool_fwd<2, 2, 1, 0, 1, false, 14>(x, p, argmax, n, c, h, w, p_halo, alpha, bias, s);   // loads + LRN adds + LDS writes only
+#endif
+    return launch_lrn_pool_fwd<2, 2, 1, 0, 1>(x, p, argmax, n, c, h, w, p_halo, alpha, bias, s);
 }
 
 /* vl_lrn_pool_fwd with the pooled output written as packed bf16 (pb: "c8" layout of the bf16 conv path, p_halo; nearest even) instead of
@@ -866,7 +970,7 @@ extern "C" int vl_lrn_pool_fwd_c8(const void* x, int x_packed, void* pb, uint8_t
                                   float alpha, float beta, float bias, vl_stream_t stream) {
     VL_CHECK(x && pb && argmax && n > 0 && c > 0 && h >= 3 && w >= 3 && p_halo >= 0, "vl_lrn_pool_fwd_c8: bad argument");
     VL_CHECK(radius == 2 && beta == 0.75f, "vl_lrn_pool_fwd_c8: only depth_radius 2, beta 0.75 are built (alexnet.py:81-84)");
-    VL_CHECK(n <= 65535, "vl_lrn_pool_fwd_c8: batch %d exceeds the grid limit", n);
+    VL_CHECK(n <= 65528, "vl_lrn_pool_fwd_c8: batch %d exceeds the grid limit", n);
     const int oh = (h - 3) / 2 + 1, ow = (w - 3) / 2 + 1;
     const int64_t pplane = (int64_t)(oh + 2 * p_halo) * (ow + 2 * p_halo);
     VL_CHECK((int64_t)(c + 16) * h * w * 4 < (1ll << 31) && (int64_t)((c + 7) / 8) * pplane * 16 < (1ll << 31) && pplane < (1 << 24),
