@@ -125,18 +125,20 @@ def test_config5_clip_length_in_the_bf16_conv_arithmetics(math, logit_tol, loss_
         assert abs(out["grad_norm"] - gq) <= 0.08 * gq
 
 
-def test_bf16_path_full_geometry_gradients_against_the_rounding_aware_oracle():
-    """The packed-bf16 conv path (BASELINE config 5) at full geometry, every gradient tensor: 2 clips x 4 frames of 227 x 227,
-    well-scaled weights.  The oracle runs with the path's operand roundings (q = bf16_round on every tensor the path stores as packed
-    bf16: frames, weights, conv1..conv4 outputs, pooled outputs, fc6 / LSTM-projection operands, the packed gradients) and with the
-    DEVICE's ReLU / arg-max decisions, so the comparison is rounding against rounding.  It is still not fp32-tight: a value within
-    an fp32 ulp of a bf16 rounding boundary rounds the other way on the device than in fp64 (forward tensors agree to 2e-5 after
-    conv1, 1e-3 at fc6), and the LSTM amplifies that (its outputs agree to ~1e-2).  Bound per tensor: 0.15 relative L2 below the
-    LSTM, 0.02 for the head (measured at 8 clips x 16 frames: 3.5e-2 .. 1.0e-1 and 5e-3); against the EXACT oracle the same
-    gradients sit at 0.2 .. 0.4 -- the distance of the arithmetic itself."""
+@pytest.mark.parametrize("b,fpc", [(2, 4), (8, 16)])
+def test_bf16_path_full_geometry_gradients_against_the_rounding_aware_oracle(b, fpc):
+    """The packed-bf16 conv path (BASELINE config 5) at full geometry, EVERY gradient tensor: 2 clips x 4 frames and -- round 4: the
+    per-tensor bound at a realistic sequence length -- 8 clips x 16 frames of 227 x 227 (one rank's shard of the 8-GPU job), well-scaled
+    weights.  The oracle runs with the path's operand roundings (q = bf16_round on every tensor the path stores as packed bf16: frames,
+    weights, conv1..conv4 outputs, pooled outputs, fc6 / LSTM-projection operands, the packed gradients) and with the DEVICE's ReLU /
+    arg-max decisions, so the comparison is rounding against rounding.  It is still not fp32-tight: a value within an fp32 ulp of a bf16
+    rounding boundary rounds the other way on the device than in fp64 (forward tensors agree to 2e-5 after conv1, 1e-3 at fc6), and the
+    LSTM amplifies that (its outputs agree to ~1e-2).  Bound per tensor: 0.15 relative L2 below the LSTM, 0.02 for the head (measured at
+    8 x 16: 3.5e-2 .. 1.0e-1 and 5e-3); against the EXACT oracle the same gradients sit at 0.2 .. 0.4 -- the distance of the arithmetic
+    itself (printed for the small case only: the large one costs the CPU ~2 minutes per oracle pass).  With the reference's sigma = 0.05
+    initialiser the LSTM gates saturate and no per-tensor bound can be defended: that case holds logits / loss / norm only."""
     import dataclasses
     from vltf_amd.engine import LRCNEngine, NetConfig, init_params
-    fpc, b = 4, 2
     cfg = NetConfig(image_shape=SHAPE, num_classes=NCLS, fpc=fpc, lstm_hidden=HID)
     p = init_params(cfg, seed=7, well_scaled=True)
     rng = np.random.default_rng(70)
@@ -147,19 +149,22 @@ def test_bf16_path_full_geometry_gradients_against_the_rounding_aware_oracle():
     out = eng.train_step_u8(torch.from_numpy(frames).to(DEV), torch.from_numpy(onehot).to(DEV), lr=0.0, clip_norm=0.0, mean_bgr=MEAN)
     gates = device_gates_bf16(eng, b * fpc)
     x = frames.astype(np.float32) - MEAN
-    logits, cache = O.lrcn_forward(p, x, fpc, keep=True, chunk=4, q=O.bf16_round)
+    logits, cache = O.lrcn_forward(p, x, fpc, keep=True, chunk=8, q=O.bf16_round)
     loss, dlogits = O.softmax_xent_mean(logits, onehot)
     assert np.abs(eng.logits_host() - logits).max() <= 3e-2
     assert abs(out["loss"] - loss) <= 5e-3 * max(1.0, abs(loss))
     want = O.lrcn_backward(p, cache, dlogits, fpc, gates=gates, q=O.bf16_round)
-    exact_logits, ecache = O.lrcn_forward(p, x, fpc, keep=True, chunk=4)
-    _, edl = O.softmax_xent_mean(exact_logits, onehot)
-    exact = O.lrcn_backward(p, ecache, edl, fpc)
+    del cache
     g = eng.get_grads()
     rel = lambda a, w: np.linalg.norm((a - w).ravel()) / (np.linalg.norm(w.ravel()) + 1e-30)
-    worst = {k: (rel(g[k], want[k]), rel(g[k], exact[k])) for k in p}
-    print("relative L2 per tensor (vs rounding-aware oracle with device gates, vs exact oracle):", {k: "%.1e / %.1e" % v for k, v in worst.items()})
-    for k, (err, _) in worst.items():
+    worst = {k: rel(g[k], want[k]) for k in p}
+    print("%d clips x %d frames, relative L2 per tensor vs the rounding-aware oracle with device gates:" % (b, fpc), {k: "%.1e" % v for k, v in worst.items()})
+    if b * fpc <= 8:
+        exact_logits, ecache = O.lrcn_forward(p, x, fpc, keep=True, chunk=4)
+        _, edl = O.softmax_xent_mean(exact_logits, onehot)
+        exact = O.lrcn_backward(p, ecache, edl, fpc)
+        print("   vs the exact oracle:", {k: "%.1e" % rel(g[k], exact[k]) for k in p})
+    for k, err in worst.items():
         assert err < (0.02 if k.startswith("output_fc") else 0.15), "grad %s: relative L2 error %.3e" % (k, err)
 
 

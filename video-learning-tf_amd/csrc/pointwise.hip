@@ -676,11 +676,7 @@ extern "C" int vl_lrn_bwd(const float* x, const float* dy, float* dx, int n, int
 // C8: pout is the packed-bf16 "c8" tensor [image][C / 8][pooled plane][8] (conv_c8.hip) instead of fp32 NCHW: each pooled output is
 // stored as one bf16 (nearest even) at its channel's slot of the pixel's chunk; the arg-max map is unchanged.
 // C8 == 2: x is packed too ([image][C / 8][H][W][8] bf16, no halo): a 16-byte load per pixel brings 8 channels = four 2-channel chunks.
-// VEC (fp32 input only; PPT = 4): a thread owns FOUR CONSECUTIVE pixels and fetches them with one 16-byte load per channel (any 4-byte
-// alignment) instead of PPT pixels a workgroup-width apart with one dword load each.  Round 4: the dword form moved 3.9 TB/s whatever its
-// band size, barrier width or prefetch depth (PMC: 70 % of wave cycles waiting, VALU 8 % busy, LDS 1 %) -- the rate of 4-byte-per-lane
-// streams on this chip (the 16-byte-per-lane kernels, sgd_apply, reach 6.5).
-template <int CHK, int PPT, int NSL, int C8 = 0, int DEPTH = 1, bool VEC = false, int SKIP = 0>   // SKIP: experiments (parts compiled out)
+template <int CHK, int PPT, int NSL, int C8 = 0>
 __global__ __launch_bounds__(512) void lrn_pool_fwd_kernel(const float* __restrict__ x, float* __restrict__ pout,
                                                            uint8_t* __restrict__ argout, int C, int H, int W, int OH, int OW, int prb,
                                                            int pplane, int owp, int p_halo, float alpha, float bias, int cper, int nimg) {
@@ -709,11 +705,10 @@ __global__ __launch_bounds__(512) void lrn_pool_fwd_kernel(const float* __restri
     int lpix[PPT];                                                    // band-local pixel, -1 = none
 #pragma unroll
     for (int q = 0; q < PPT; ++q) {
-        const int pix = VEC ? PPT * (int)threadIdx.x + q : (int)threadIdx.x + q * T;
+        const int pix = threadIdx.x + q * T;
         lpix[q] = pix < npix ? pix : -1;                              // (-1: its LRN values go to the buffer's spare slot)
         voff_x[q] = pix < npix ? (uint32_t)(p_base + pix) * (C8 == 2 ? 16u : 4u) : PW_OOB;
     }
-    static_assert(!VEC || (PPT == 4 && C8 != 2), "vector form: four consecutive fp32 pixels per thread");
     // pooled outputs of a chunk: o = tid + s T  <->  (slab ci, pooled row, pooled column)
     // fp32 output: the slots enumerate WHOLE rows of the halo layout, halo columns included (they store 0.0 = what the halo holds by
     // contract; the arg-max map's halo is never read), so that a wave's stores are runs of full 32-byte sectors.  Round 4, parts of the
@@ -743,17 +738,9 @@ __global__ __launch_bounds__(512) void lrn_pool_fwd_kernel(const float* __restri
 #pragma unroll
         for (int i = 0; i < CHK; ++i) {
             const int cc = c0 + i;                                    // uniform; channels past C: the range check answers 0
-            if constexpr (VEC) {                                      // the quad may run past the band's last pixel: in-range memory or
-                typedef float f4 __attribute__((ext_vector_type(4))); // range-checked zeros, its values go to the spare slot
-                typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-                const f4 w = __builtin_bit_cast(f4, __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)(cc < C ? voff_x[0] : PW_OOB), cc * x_cs, 0)));
 #pragma unroll
-                for (int q = 0; q < PPT; ++q) v[q][i] = w[q];
-            } else {
-#pragma unroll
-                for (int q = 0; q < PPT; ++q)
-                    v[q][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, (int)(cc < C ? voff_x[q] : PW_OOB), cc * x_cs, 0));
-            }
+            for (int q = 0; q < PPT; ++q)
+                v[q][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, (int)(cc < C ? voff_x[q] : PW_OOB), cc * x_cs, 0));
         }
     };
     float xw[PPT][5];
@@ -774,14 +761,14 @@ __global__ __launch_bounds__(512) void lrn_pool_fwd_kernel(const float* __restri
 #pragma unroll
                 for (int d = 0; d < 5; ++d) sq += xw[q][d] * xw[q][d];
                 const float sc = bias + alpha * sq;
-                const float rq = (SKIP & 4) ? sc : __builtin_amdgcn_rsqf(sc);
-                const float l = xw[q][2] * ((SKIP & 4) ? rq : rq * __builtin_amdgcn_sqrtf(rq));   // x * sc^-0.75 (pow_neg's beta = 0.75 form)
+                const float rq = __builtin_amdgcn_rsqf(sc);
+                const float l = xw[q][2] * (rq * __builtin_amdgcn_sqrtf(rq));   // x * sc^-0.75 (pow_neg's beta = 0.75 form)
                 lb[lpix[q] >= 0 ? i * npix + lpix[q] : CHK * npix] = l;
             }
         }
-        if (!(SKIP & 8)) __syncthreads();
+        __syncthreads();
 #pragma unroll
-        for (int sl = 0; sl < ((SKIP & 2) ? 0 : NSL); ++sl) {
+        for (int sl = 0; sl < NSL; ++sl) {
             const int c = c0 - 2 + (s_out[sl] >> 24);
             const bool live = s_out[sl] >= 0 && c >= R0 && c < R1;    // dead lanes scan slab 0's first window and store out of range
             {
@@ -804,13 +791,15 @@ __global__ __launch_bounds__(512) void lrn_pool_fwd_kernel(const float* __restri
                     bi = 0;
                 }
                 if constexpr (C8 != 0) {
+                    // (round 4, measured and dropped: gathering a pixel's 8-channel block in registers and storing it as ONE 16-byte
+                    // word -- the pooling phase then runs on half the threads with two windows each and the kernel got 10 % slower)
                     const __bf16 hb = (__bf16)best;
                     __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(uint16_t, hb), rs_p,
                                                           live ? ((c >> 3) * pplane + (s_out[sl] & 0xffffff)) * 16 + (c & 7) * 2 : (int)PW_OOB, 0, 0);
                 } else {
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, best), rs_p, (live && !(SKIP & 1)) ? off * 4 : (int)PW_OOB, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, best), rs_p, live ? off * 4 : (int)PW_OOB, 0, 0);
                 }
-                __builtin_amdgcn_raw_buffer_store_b8((uint8_t)bi, rs_a, (live && !(SKIP & 1)) ? off : (int)PW_OOB, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b8((uint8_t)bi, rs_a, live ? off : (int)PW_OOB, 0, 0);
             }
         }
     };
@@ -846,24 +835,6 @@ __global__ __launch_bounds__(512) void lrn_pool_fwd_kernel(const float* __restri
         }
         return;
     }
-    if constexpr (DEPTH > 1) {
-        // DEPTH chunks of loads in flight (a ring of DEPTH + 1 register sets, the loop unrolled by that): with one chunk ahead a wave
-        // waited a whole memory latency per 2-channel chunk (PMC: 70 % of wave cycles in waitcnt / barrier, VALU 8 % busy: round 4)
-        constexpr int R = DEPTH + 1;
-        static_assert(R % 2 == 0, "ring length even: the LDS double buffer's parity then follows the ring slot");
-        float xr[R][PPT][CHK];
-#pragma unroll
-        for (int j = 0; j < DEPTH; ++j) x_load(cs + j * CHK, xr[j]);
-        for (int k = 0; k < nchunks; k += R) {
-#pragma unroll
-            for (int j = 0; j < R; ++j) {
-                if (k + j >= nchunks) break;
-                x_load(cs + (k + j + DEPTH) * CHK, xr[(j + DEPTH) % R]);
-                chunk(cs + (k + j) * CHK, j & 1, xr[j]);
-            }
-        }
-        return;
-    }
     x_load(cs, xa);
     for (int k = 0; k < nchunks; k += 2) {                            // unrolled by two: the x registers alternate without copies
         x_load(cs + (k + 1) * CHK, xb);
@@ -874,7 +845,7 @@ __global__ __launch_bounds__(512) void lrn_pool_fwd_kernel(const float* __restri
     }
 }
 
-template <int CHK, int PPT, int NSL, int C8 = 0, int DEPTH = 1, bool VEC = false, int SKIP = 0>
+template <int CHK, int PPT, int NSL, int C8 = 0>
 static int launch_lrn_pool_fwd(const float* x, float* p, uint8_t* argmax, int n, int c, int h, int w, int p_halo, float alpha, float bias,
                                hipStream_t stream) {
     const int oh = (h - 3) / 2 + 1, ow = (w - 3) / 2 + 1;
@@ -897,9 +868,7 @@ static int launch_lrn_pool_fwd(const float* x, float* p, uint8_t* argmax, int n,
     // rank's 128-frame shard of the 8-GPU job: layer 2 was ONE band x 128 images = half the CUs, 98 us where 1/8 of the 1024-frame time
     // is 37): cut more bands, up to two workgroups per CU, at the price of their shared input rows (round 4)
     int bands = ceil_div(oh, prb);
-    int want = ceil_div(2 * (int64_t)vl_device_cus(), n);
-    static const int exp_prb = vl_exp_env("VL_LRN_POOL_PRB") ? atoi(vl_exp_env("VL_LRN_POOL_PRB")) : 0;   // experiments: pooled rows per band
-    if (exp_prb > 0) want = ceil_div(oh, exp_prb);
+    const int want = ceil_div(2 * (int64_t)vl_device_cus(), n);
     if (bands < want) bands = want < oh ? want : oh;
     prb = ceil_div(oh, bands);
     bands = ceil_div(oh, prb);
@@ -925,7 +894,7 @@ static int launch_lrn_pool_fwd(const float* x, float* p, uint8_t* argmax, int n,
             nz = (c + cper - 1) / cper;
         }
     }
-    hipLaunchKernelGGL((lrn_pool_fwd_kernel<CHK, PPT, NSL, C8, DEPTH, VEC, SKIP>), dim3(bands, (n + 7) / 8 * 8, nz), dim3(threads), lds, stream, x, p, argmax, c, h,
+    hipLaunchKernelGGL((lrn_pool_fwd_kernel<CHK, PPT, NSL, C8>), dim3(bands, (n + 7) / 8 * 8, nz), dim3(threads), lds, stream, x, p, argmax, c, h,
                        w, oh, ow, prb, (int)pplane, owp, p_halo, alpha, bias, cper, n);
     VL_LAUNCH_CHECK();
     return 0;
@@ -948,20 +917,7 @@ extern "C" int vl_lrn_pool_fwd(const float* x, float* p, uint8_t* argmax, int n,
     static const bool r1 = vl_exp_env("VL_LRN_POOL_R1") != nullptr;
     hipStream_t s = (hipStream_t)stream;
     if (r1) return launch_lrn_pool_fwd<8, 3, 6>(x, p, argmax, n, c, h, w, p_halo, alpha, bias, s);
-    static const int form = vl_exp_env("VL_LRN_POOL_FORM") ? atoi(vl_exp_env("VL_LRN_POOL_FORM")) : 0;   // experiments (round 4 sweep)
-    if (form == 1) return launch_lrn_pool_fwd<2, 2, 1, 0, 1>(x, p, argmax, n, c, h, w, p_halo, alpha, bias, s);          // round 3's dword form
-    if (form == 3) return launch_lrn_pool_fwd<2, 2, 1, 0, 3>(x, p, argmax, n, c, h, w, p_halo, alpha, bias, s);          // + 3 chunks in flight
-    if (form == 11) return launch_lrn_pool_fwd<2, 4, 2, 0, 1, true>(x, p, argmax, n, c, h, w, p_halo, alpha, bias, s);   // 16-byte loads
-    if (form == 13) return launch_lrn_pool_fwd<2, 4, 2, 0, 3, true>(x, p, argmax, n, c, h, w, p_halo, alpha, bias, s);   // + 3 chunks in flight
-    if (form == 21) return launch_lrn_pool_fwd<4, 4, 4, 0, 1, true>(x, p, argmax, n, c, h, w, p_halo, alpha, bias, s);   // 4-channel chunks
-#ifdef VL_EXPERIMENTS
-    if (form == 31) return launch_lrn_pool_fwd<2, 2, 1, 0, 1, false, 1>(x, p, argmax, n, c, h, w, p_halo, alpha, bias, s);    // no stores
-    if (form == 32) return launch_lrn_pool_fwd<2, 2, 1, 0, 1, false, 2>(x, p, argmax, n, c, h, w, p_halo, alpha, bias, s);    // no pooling phase
-    if (form == 34) return launch_lrn_pool_fwd<2, 2, 1, 0, 1, false, 4>(x, p, argmax, n, c, h, w, p_halo, alpha, bias, s);    // no transcendentals
-    if (form == 40) return launch_lrn_pool_fwd<2, 2, 1, 0, 1, false, 10>(x, p, argmax, n, c, h, w, p_halo, alpha, bias, s);   // no pooling, no barrier
-    if (form == 46) return launch_lrn_pool_fwd<2, 2, 1, 0, 1, false, 14>(x, p, argmax, n, c, h, w, p_halo, alpha, bias, s);   // loads + LRN adds + LDS writes only
-#endif
-    return launch_lrn_pool_fwd<2, 2, 1, 0, 1>(x, p, argmax, n, c, h, w, p_halo, alpha, bias, s);
+    return launch_lrn_pool_fwd<2, 2, 1>(x, p, argmax, n, c, h, w, p_halo, alpha, bias, s);
 }
 
 /* vl_lrn_pool_fwd with the pooled output written as packed bf16 (pb: "c8" layout of the bf16 conv path, p_halo; nearest even) instead of
