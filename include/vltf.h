@@ -181,7 +181,7 @@ int vl_lrn_bwd(const float* x, const float* dy, float* dx, int n, int c, int hw,
 /* Fused backward of [LRN -> max_pool 3x3/2 VALID] (alexnet.py:79-98,120-139): dx = LRN'(x) applied to the
  * pooled gradient routed through argmax, + optional ReluGrad of x; the gradient wrt the LRN output is never
  * written.  x dense NCHW [n][c][h][w] (the LRN input); dp / argmax: pool-output layout NCHW with p_halo;
- * dx: NCHW with dx_halo. */
+ * dx: NCHW with dx_halo; its interior ROWS are written whole (the halo columns of those rows receive the 0.0 a zero halo holds). */
 int vl_pool_lrn_bwd(const float* x, const float* dp, const uint8_t* argmax, float* dx, int n, int c, int h, int w,
                     int p_halo, int radius, float alpha, float beta, float bias, int relu_fused, int dx_halo,
                     vl_stream_t stream);

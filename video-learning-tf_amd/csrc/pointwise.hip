@@ -347,11 +347,17 @@ __global__ __launch_bounds__(256, (C8 ? 3 : 1)) void pool_lrn_bwd_stream_kernel(
     const int HW = H * W;
     int band, img;
     if (!xcd_band_image(nimg, band, img)) return;
+    // fp32 output in a halo layout: the lanes enumerate WHOLE rows of that layout, halo columns included -- those lanes load nothing
+    // (their x and routed gradient are 0, so the value they compute IS the 0.0 a halo holds) and a wave's stores are runs of full
+    // sectors instead of 112-byte pieces at a 128-byte pitch (round 4: lrn_pool_fwd's lesson, profiles/r04_lrn_pool_fwd_experiments.txt)
+    const int Wq = C8 == 0 ? W + 2 * halo : W, HWq = H * Wq;
     const int p0 = band * 256, p = p0 + threadIdx.x;
-    const bool valid = p < HW;
-    const int pc = valid ? p : HW - 1;
-    const int py = pc / W, px = pc - py * W;
-    const int r0 = p0 / W, r1 = min(p0 + 255, HW - 1) / W;            // input rows of the band
+    const bool inplane = p < HWq;
+    const int pc = inplane ? p : HWq - 1;
+    const int py = pc / Wq, pxq = pc - py * Wq, pxr = pxq - (Wq - W) / 2;
+    const bool valid = inplane && pxr >= 0 && pxr < W;
+    const int px = min(max(pxr, 0), W - 1);
+    const int r0 = p0 / Wq, r1 = min(p0 + 255, HWq - 1) / Wq;         // input rows of the band
     const int oh0 = (r0 >> 1) - 1;                                    // first pooled row that can reach the band
     const int prow = (r1 >> 1) - oh0 + 1;
     const int rowlen = prow * OW;
@@ -397,8 +403,9 @@ __global__ __launch_bounds__(256, (C8 ? 3 : 1)) void pool_lrn_bwd_stream_kernel(
                                             : pw_rsrc(dx + (int64_t)img * C * dplane, (int64_t)C * dplane * 4);
     const __amdgpu_buffer_rsrc_t rs_dp = pw_rsrc(dp + (int64_t)img * ps_n, pooled_bytes_f);
     const __amdgpu_buffer_rsrc_t rs_arg = pw_rsrc(arg + (int64_t)img * ps_n, pooled_bytes_f / 4);
-    const uint32_t voff_x = valid ? (uint32_t)p * (C8 == 2 ? 16u : 4u) : PW_OOB;
-    const uint32_t voff_dx = valid ? (uint32_t)((py + halo) * wp + px + halo) * (C8 ? 16u : 4u) : PW_OOB;
+    const uint32_t voff_x = valid ? (uint32_t)(py * W + px) * (C8 == 2 ? 16u : 4u) : PW_OOB;
+    const uint32_t voff_dx = C8 == 0 ? (inplane ? (uint32_t)((py + halo) * wp + pxq) * 4u : PW_OOB)
+                                     : (valid ? (uint32_t)((py + halo) * wp + px + halo) * 16u : PW_OOB);
     const int x_cs = HW * 4, dx_cs = dplane * 4;                      // channel strides in bytes
 
     float dpv[NST];
@@ -483,6 +490,8 @@ __global__ __launch_bounds__(256, (C8 ? 3 : 1)) void pool_lrn_bwd_stream_kernel(
                     const u2 w = {__builtin_bit_cast(uint32_t, __builtin_convertvector(f2{rr[0], rr[1]}, b2)),
                                   __builtin_bit_cast(uint32_t, __builtin_convertvector(f2{rr[2], rr[3]}, b2))};
                     const int blk = (oc - 3) >> 3;                    // uniform; outside [0, CB): dropped by the range check
+                    // (round 4, measured and dropped: holding the lower half of a chunk in registers and storing the whole 16-byte chunk
+                    // at once -- 0.54 -> 0.75 ms on layer 1)
                     __builtin_amdgcn_raw_buffer_store_b64(w, rs_dx, (int)((oc - 3 >= R0 && oc - 3 < R1 && blk < CB) ? voff_dx + (((oc - 3) & 7) * 2) : PW_OOB),
                                                           blk * dplane * 16, 0);
                 }
@@ -573,8 +582,8 @@ extern "C" int vl_pool_lrn_bwd(const float* x, const float* dp, const uint8_t* a
         const bool ok = beta == 0.75f && bytes_x < (1ll << 31) && bytes_dx < (1ll << 31) && pooled_f < (1ll << 31) && pplane < (1 << 24) &&
                         !kPoolLrnChunked;
         int cper = c;
-        const int nz = plb_channel_ranges((int64_t)ceil_div((int64_t)h * w, 256) * n, c, 1, 4, &cper);
-        const dim3 grid(ceil_div((int64_t)h * w, 256), (n + 7) / 8 * 8, nz);   // images padded to the 8 XCDs (xcd_band_image)
+        const int nz = plb_channel_ranges((int64_t)ceil_div((int64_t)h * (w + 2 * dx_halo), 256) * n, c, 1, 4, &cper);
+        const dim3 grid(ceil_div((int64_t)h * (w + 2 * dx_halo), 256), (n + 7) / 8 * 8, nz);   // bands over halo-layout rows; images padded to the 8 XCDs
         const int64_t psn = (int64_t)c * pplane;
 #define VL_PLB_LAUNCH(CHK, NST)                                                                                                     \
     do {                                                                                                                            \
@@ -1062,11 +1071,17 @@ __global__ __launch_bounds__(256) void maxpool_bwd_hwc_k3s2_kernel(const float* 
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wp = W + 2 * halo;
     const int64_t pp = (int64_t)(H + 2 * halo) * wp;
-    for (int pc = 0; pc * 64 < HW; ++pc) {
-        const int p = pc * 64 + lane;
-        const bool valid = p < HW;
-        const int pcl = valid ? p : HW - 1;
-        const int ih = pcl / W, iw = pcl - ih * W;
+    // (round 4) the lanes enumerate whole rows of dx's halo layout, halo columns included (they store the 0.0 a halo holds): 13-float
+    // rows at a 15-float pitch left every sector partially written -- pool_lrn_bwd gained 22 % from the same change
+    const int HWq = H * wp;
+    for (int pc = 0; pc * 64 < HWq; ++pc) {
+        const int pq = pc * 64 + lane;
+        const bool inplane = pq < HWq;
+        const int pcl = inplane ? pq : HWq - 1;
+        const int ih = pcl / wp, iwq = pcl - ih * wp, iwr = iwq - halo;
+        const bool valid = inplane && iwr >= 0 && iwr < W;
+        const int iw = min(max(iwr, 0), W - 1);
+        const int p = ih * W + iw;
         int off[4], wl[4];
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
@@ -1074,12 +1089,12 @@ __global__ __launch_bounds__(256) void maxpool_bwd_hwc_k3s2_kernel(const float* 
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
                 const int ow = (iw >> 1) - b, lc = (iw & 1) + 2 * b;
-                const bool ok = oh >= 0 && oh < OH && lr <= 2 && ow >= 0 && ow < OW && lc <= 2;
+                const bool ok = valid && oh >= 0 && oh < OH && lr <= 2 && ow >= 0 && ow < OW && lc <= 2;
                 off[a * 2 + b] = ok ? oh * OW + ow : OHW;              // entry OHW of a row: the pad, never a match
                 wl[a * 2 + b] = ok ? lr * 3 + lc : 254;
             }
         }
-        const int64_t dxo = (int64_t)(ih + halo) * wp + iw + halo;
+        const int64_t dxo = (int64_t)(ih + halo) * wp + iwq;
         for (int cl = wave; cl < nch; cl += 4) {
             const int64_t plane = (int64_t)img * C + c0 + cl;
             const float mk = (mask && valid) ? mask[plane * HW + p] : 1.f;
@@ -1091,7 +1106,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_hwc_k3s2_kernel(const float* 
                 acc += ((int)e.y == wl[k]) ? __uint_as_float(e.x) : 0.f;
             }
             if (!(mk > 0.f)) acc = 0.f;
-            if (valid) dx[plane * pp + dxo] = acc;
+            if (inplane) dx[plane * pp + dxo] = acc;                   // halo columns: no window matched, acc = 0
         }
     }
 }
