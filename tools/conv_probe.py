@@ -31,7 +31,9 @@ def main():
     padded = os.environ.get("VL_PROBE_DENSE") is None          # default: the engine's zero-halo layout
     xh = conv.same_pad() if padded else 0
     dyh = conv.same_pad() if (padded and s == 1) else 0
-    conv.set_halo(xh, 0, dyh, 0)
+    yh = int(os.environ.get("VL_PROBE_YHALO", "0"))             # halo of the OUTPUT (y of fwd, dx of dgrad): the engine's 13 x 13 layers write
+    dxh = int(os.environ.get("VL_PROBE_DXHALO", "0"))           # into halo layouts (y3, y4: 1; dp2, dy3, dy4: 1; dp1: 2)
+    conv.set_halo(xh, yh, dyh, dxh)
     if s > 1 and padded and os.environ.get("VL_PROBE_NO_PHASE") is None:
         conv.set_x_phase_split(True)            # the engine's layout of a strided conv's input (vl_conv_set_x_phase_split)
 
@@ -50,9 +52,9 @@ def main():
         x = xs
     wt = torch.randn(k, k, cin // g, cout, device=dev) * 0.05
     b = torch.zeros(cout, device=dev)
-    y = torch.empty(n, cout, conv.oh, conv.ow, device=dev)
+    y = torch.zeros(n, cout, conv.oh + 2 * yh, conv.ow + 2 * yh, device=dev)
     dy = haloed(cout, conv.oh, conv.ow, dyh)
-    dx = torch.empty(n, cin, h, w, device=dev)
+    dx = torch.zeros(n, cin, h + 2 * dxh, w + 2 * dxh, device=dev)
     dw = torch.empty_like(wt)
     wtt = torch.empty(wt.numel(), device=dev)
     ws = torch.empty(max(conv.wgrad_ws_bytes(n) // 4, 1), device=dev)
