@@ -212,6 +212,8 @@ def main():
             gar.broadcast_params(eng.w)
         return eng
 
+    host_issue = [0.0]
+
     def timed(eng, frames, onehot, clips, global_clips, probe):
         """W warm-up steps, then exactly K steps between barrier + synchronize on both sides; MAX over ranks."""
         def step(fetch=False):
@@ -229,7 +231,8 @@ def main():
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
-        torch.cuda.synchronize()
+        host_issue[0] = (time.perf_counter() - t0) / args.steps * 1e3      # ms per step the host needed to ENQUEUE (no device wait in it
+        torch.cuda.synchronize()                                             # unless the queue fills): close to ms_per_step = host-bound
         barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
@@ -253,6 +256,7 @@ def main():
         eng.step_count = 0
     eng_chunks = list(eng.grad_chunks)
     elapsed, times, out = timed(eng, frames, onehot, clips, total_clips, probe=True)
+    host_issue_main = host_issue[0]
     overlapped = clips > 0 and eng._side_stream() is not None      # the backward ran its independent launches on two streams
     serial_times = None
     if overlapped and world == 1:
@@ -385,6 +389,7 @@ def main():
                   "clips/sec (%d-frame 227x227) LRCN train step" % args.fpc,
         "value": round(value, 2), "unit": "clips/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+        "host_issue_ms_per_step": round(host_issue_main, 3),      # this rank's host time to enqueue a step (<< ms_per_step: not launch-bound)
         "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": "f32" if args.conv_math == "f32" else "%s conv / GEMM products (opt-in, --conv-math), fp32 accumulate and elsewhere" % args.conv_math,
         "data": "synthetic",
