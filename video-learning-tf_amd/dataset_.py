@@ -32,7 +32,12 @@ class Dataset:
         self.frames, self.labels = [], []
         self.rng = random.Random()          # the reference uses the unseeded `random` module (dataset_.py:454,498)
         if data_format != defs.data_format.tfrecord:
-            error("Only data_format tfrecord is on the hot path (got [%s])" % data_format)
+            # `data_format: raw` cannot run in the reference either: Dataset.get_next_batch (dataset_.py:246-262) indexes the current
+            # batch as (paths, labels) -- `currentBatch[0]` -- but calculate_batches (dataset_.py:603-609) fills self.batches with batch
+            # SIZES (ints) since the legacy initialize_data (616-696) went dead: the first batch raises TypeError.  Serialise the frame
+            # folders instead (serialize.py writes the TFRecord + .size this reader takes).
+            error("data_format [%s] is broken in the reference (dataset_.py:246-262 indexes an int batch size) and not built; "
+                  "serialize the frames to a TFRecord (serialize.py) and use defs.data_format.tfrecord" % data_format)
         if batch_item != defs.batch_item.default:
             error("batch_item [%s] is not supported (broken in the reference, dataset_.py:415)" % batch_item)
 
