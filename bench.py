@@ -153,6 +153,9 @@ def main():
     from vltf_amd import dp as dpmod
     # `python bench.py --gpus N` as the driver starts it (no launcher): become the launcher -- N ranks under torch.distributed.run --
     # before anything here touches the GPU; their one JSON line (rank 0's) passes through, their exit code is ours
+    # ... and, first of all, send a tiny GPU process ahead: the first GPU process on a freshly acquired box runs short kernels slower
+    # for its whole life (dp.pretouch_gpu; the ranks inherit the marker and do not repeat it)
+    pretouched = False if os.environ.get("VLTF_BENCH_RENDEZVOUS_ONLY") == "1" else dpmod.pretouch_gpu()
     rc = dpmod.self_launch(args.gpus)
     if rc is not None:
         raise SystemExit(rc)
@@ -389,7 +392,8 @@ def main():
                   "clips/sec (%d-frame 227x227) LRCN train step" % args.fpc,
         "value": round(value, 2), "unit": "clips/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-        "host_issue_ms_per_step": round(host_issue_main, 3),      # this rank's host time to enqueue a step (<< ms_per_step: not launch-bound)
+        "host_issue_ms_per_step": round(host_issue_main, 3),
+        "gpu_pretouch_process": bool(pretouched or os.environ.get("VLTF_GPU_PRETOUCHED") == "1"),   # dp.pretouch_gpu ran before this process      # this rank's host time to enqueue a step (<< ms_per_step: not launch-bound)
         "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": "f32" if args.conv_math == "f32" else "%s conv / GEMM products (opt-in, --conv-math), fp32 accumulate and elsewhere" % args.conv_math,
         "data": "synthetic",

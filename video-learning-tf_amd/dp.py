@@ -41,6 +41,29 @@ def init_from_env(backend=None, force=False):
     return rank, world, local
 
 
+def pretouch_gpu():
+    """Run a tiny GPU process to completion BEFORE this process (or its ranks) initialises HIP; True if one ran.
+    Measured on this pool (round 4): the FIRST GPU process on a freshly acquired MI355X box executes short kernels slower
+    for its whole life -- the 8-clip train step in 6.1 - 6.6 ms instead of 5.2 (4 of 5 fresh boxes; host issue time identical; 2,500
+    warm-up steps or re-allocating the engine's memory do not cure it) -- while every later process runs at full speed, also when the
+    first one only summed a vector (3 of 3 fresh boxes).  A benchmark that may be the first process on its box therefore sends such a
+    process ahead.  VLTF_NO_PRETOUCH=1 skips it; the marker VLTF_GPU_PRETOUCHED keeps ranks from repeating it."""
+    if os.environ.get("VLTF_GPU_PRETOUCHED") == "1" or os.environ.get("VLTF_NO_PRETOUCH") == "1":
+        return False
+    import subprocess
+    import sys
+    code = ("import torch\n"
+            "if torch.cuda.is_available():\n"
+            "    x = torch.zeros(1 << 24, device='cuda')\n"
+            "    float((x + 1).sum().item())\n")
+    try:
+        subprocess.run([sys.executable, "-c", code], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900)
+    except Exception:
+        return False
+    os.environ["VLTF_GPU_PRETOUCHED"] = "1"
+    return True
+
+
 def self_launch(gpus, argv=None):
     """`python <script> --gpus N` started WITHOUT a launcher (WORLD_SIZE unset, N > 1): start the N ranks ourselves -- one process per
     GPU under `python -m torch.distributed.run` on 127.0.0.1 with a free port -- pass their output through and return the launcher's
