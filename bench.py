@@ -155,7 +155,7 @@ def main():
     # before anything here touches the GPU; their one JSON line (rank 0's) passes through, their exit code is ours
     # ... and, first of all, send a tiny GPU process ahead: the first GPU process on a freshly acquired box runs short kernels slower
     # for its whole life (dp.pretouch_gpu; the ranks inherit the marker and do not repeat it)
-    pretouched = False if os.environ.get("VLTF_BENCH_RENDEZVOUS_ONLY") == "1" else dpmod.pretouch_gpu()
+    pretouched = False if os.environ.get("VLTF_BENCH_RENDEZVOUS_ONLY") == "1" else dpmod.pretouch_gpu(args.gpus)
     rc = dpmod.self_launch(args.gpus)
     if rc is not None:
         raise SystemExit(rc)

@@ -60,6 +60,26 @@ def test_self_launch_returns_the_ranks_exit_code(tmp_path):
     assert r.returncode == 0 and "rank0_of_1" in os.listdir(tmp_path)      # N = 1: no launcher, the process itself is rank 0
 
 
+def test_the_process_sent_ahead_touches_this_ranks_card_only(monkeypatch):
+    """N ranks under a launcher must not put N extra processes on card 0: each sends its process to its own card; without a
+    launcher one process visits cards 0 .. gpus-1 in turn, and the ranks started afterwards inherit the marker."""
+    from vltf_amd import dp
+    seen = []
+    monkeypatch.setattr(subprocess, "run", lambda cmd, **kw: seen.append(cmd[-1]))
+    monkeypatch.delenv("VLTF_GPU_PRETOUCHED", raising=False)
+    monkeypatch.delenv("VLTF_NO_PRETOUCH", raising=False)
+    monkeypatch.setenv("LOCAL_RANK", "3")
+    assert dp.pretouch_gpu(8) is True
+    assert "for d in [3]:" in seen[-1]
+    assert dp.pretouch_gpu(8) is False and len(seen) == 1              # the marker is set: not repeated
+    monkeypatch.delenv("VLTF_GPU_PRETOUCHED")
+    monkeypatch.delenv("LOCAL_RANK")
+    assert dp.pretouch_gpu(4) is True
+    assert "for d in [0, 1, 2, 3]:" in seen[-1]
+    compile(seen[-1], "<pretouch>", "exec")
+    monkeypatch.delenv("VLTF_GPU_PRETOUCHED")
+
+
 @pytest.mark.gpu
 def test_bench_gpus_2_runs_the_data_parallel_benchmark_by_itself():
     """The driver's command for N = 2, on the one GPU of the test box: gloo instead of RCCL (two ranks cannot share a GPU under RCCL),

@@ -41,21 +41,29 @@ def init_from_env(backend=None, force=False):
     return rank, world, local
 
 
-def pretouch_gpu():
+def pretouch_gpu(gpus=1):
     """Run a tiny GPU process to completion BEFORE this process (or its ranks) initialises HIP; True if one ran.
     Measured on this pool (round 4): the FIRST GPU process on a freshly acquired MI355X box executes short kernels slower
     for its whole life -- the 8-clip train step in 6.1 - 6.6 ms instead of 5.2 (4 of 5 fresh boxes; host issue time identical; 2,500
     warm-up steps or re-allocating the engine's memory do not cure it) -- while every later process runs at full speed, also when the
     first one only summed a vector (3 of 3 fresh boxes).  A benchmark that may be the first process on its box therefore sends such a
-    process ahead.  VLTF_NO_PRETOUCH=1 skips it; the marker VLTF_GPU_PRETOUCHED keeps ranks from repeating it."""
+    process ahead.  Which cards it touches: under a launcher (LOCAL_RANK set) only this rank's own -- N ranks must not put N extra
+    processes on card 0 -- else cards 0 .. gpus-1, one after the other in ONE process (the ranks `self_launch` starts inherit the
+    marker and skip it).  VLTF_NO_PRETOUCH=1 skips it; the marker VLTF_GPU_PRETOUCHED keeps ranks from repeating it."""
     if os.environ.get("VLTF_GPU_PRETOUCHED") == "1" or os.environ.get("VLTF_NO_PRETOUCH") == "1":
         return False
     import subprocess
     import sys
+    if "LOCAL_RANK" in os.environ:
+        cards = [int(os.environ["LOCAL_RANK"])]
+    else:
+        cards = list(range(max(1, int(gpus))))
     code = ("import torch\n"
             "if torch.cuda.is_available():\n"
-            "    x = torch.zeros(1 << 24, device='cuda')\n"
-            "    float((x + 1).sum().item())\n")
+            "    for d in %r:\n"
+            "        if d < torch.cuda.device_count():\n"
+            "            x = torch.zeros(1 << 24, device='cuda:%%d' %% d)\n"
+            "            float((x + 1).sum().item())\n" % (cards,))
     try:
         subprocess.run([sys.executable, "-c", code], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900)
     except Exception:
