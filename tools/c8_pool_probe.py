@@ -29,4 +29,10 @@ for (c, h, halo_p, halo_dx) in ((96, 57, 2, 1), (256, 28, 1, 2)):
     t2 = timed(lambda: ops.lrn_pool_fwd_c8(x, pb, arg, p_halo=halo_p))
     t3 = timed(lambda: ops.pool_lrn_bwd(x, dp, arg, dx, p_halo=halo_p, dx_halo=halo_dx))
     t4 = timed(lambda: ops.pool_lrn_bwd_c8(x, dp, arg, dxb, p_halo=halo_p, dxb_halo=halo_dx))
-    print("c %3d h %2d: lrn_pool_fwd %.3f ms  _c8 %.3f ms | pool_lrn_bwd %.3f ms  _c8 %.3f ms" % (c, h, t1, t2, t3, t4), flush=True)
+    # the forms the bf16 path's step launches: x packed too (the conv's packed output, no halo)
+    xb = torch.zeros(ops.c8_shape(n, c, h, h, 0), dtype=torch.bfloat16, device=dev)
+    ops.pack_c8(x, xb, 0, 0)
+    t5 = timed(lambda: ops.lrn_pool_fwd_c8(xb, pb, arg, p_halo=halo_p, channels=c))
+    t6 = timed(lambda: ops.pool_lrn_bwd_c8(xb, dp, arg, dxb, p_halo=halo_p, dxb_halo=halo_dx))
+    print("c %3d h %2d: lrn_pool_fwd %.3f ms  _c8 %.3f ms  packed x %.3f ms | pool_lrn_bwd %.3f ms  _c8 %.3f ms  packed x %.3f ms"
+          % (c, h, t1, t2, t5, t3, t4, t6), flush=True)
