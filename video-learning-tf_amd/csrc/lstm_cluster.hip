@@ -115,17 +115,17 @@ struct LstmClusterArgs {
 __global__ __launch_bounds__(LNT) void lstm_cluster_fwd_kernel(const LstmClusterArgs p) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int H = p.H, Hp = p.Hp, H4 = 4 * p.H, T = p.T;
-    float* Ks = sm;                   // [H][LC]
-    float* hb = Ks + (size_t)H * LC;  // [CPG][Hp]   h_{t-1} of the group's clips
+    float* Ks = sm;                   // [Hp][LC]  (rows H .. Hp - 1: zeros)
+    float* hb = Ks + (size_t)Hp * LC; // [CPG][Hp]   h_{t-1} of the group's clips
     float* zb = hb + CPG * Hp;        // [KP][2 S][LC] recurrent part of the own columns' pre-activations per reduction slice (KP * 2 S = 8 rows)
     const int tid = threadIdx.x;
     const int grp = blockIdx.x % p.G, w = blockIdx.x / p.G;
     const int clip0 = grp * p.cpg;
     const int nclips = min(p.cpg, p.B - clip0);
     // the weight slice, once
-    for (int i = tid; i < H * LC; i += LNT) {
+    for (int i = tid; i < Hp * LC; i += LNT) {
         const int k = i / LC, j = i - k * LC, q = j / LU, u = w * LU + (j - q * LU);
-        Ks[i] = u < H ? p.kh[(int64_t)k * H4 + q * H + u] : 0.f;
+        Ks[i] = (u < H && k < H) ? p.kh[(int64_t)k * H4 + q * H + u] : 0.f;
     }
     for (int i = tid; i < CPG * Hp; i += LNT) {
         const int c = i / Hp, k = i - c * Hp;
@@ -183,13 +183,30 @@ __global__ __launch_bounds__(LNT) void lstm_cluster_fwd_kernel(const LstmCluster
             const float* h0p = hb + slot * Hp;
             const float* h1p = hb + (slot + S) * Hp;
             const float* kp = Ks + j;
-            for (int k = kbeg; k < kend; k += 4) {             // Hp is a multiple of 4; hb holds zeros from H to Hp, Ks is not read there
+            // Hp is a multiple of 4; hb and Ks hold zeros from H to Hp.  Four reduction quads per pass, their 24 LDS reads issued
+            // together: the loop is LDS LATENCY, not bandwidth (one quad per pass: 2.3 us of a 4.6 us step at 64 positions per wave,
+            // 4.2 us at 256 -- profiles/r04_lstm_step_parts.txt)
+            int k = kbeg;
+            for (; k + 16 <= kend; k += 16) {
+                float4 a[4], b[4];
+                float wq[4][4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    a[u] = *reinterpret_cast<const float4*>(h0p + k + 4 * u);
+                    b[u] = *reinterpret_cast<const float4*>(h1p + k + 4 * u);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) wq[u][e] = kp[(k + 4 * u + e) * LC];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {                  // the order of the sums is the one-quad loop's: same bits
+                    z0 += a[u].x * wq[u][0] + a[u].y * wq[u][1] + a[u].z * wq[u][2] + a[u].w * wq[u][3];
+                    z1 += b[u].x * wq[u][0] + b[u].y * wq[u][1] + b[u].z * wq[u][2] + b[u].w * wq[u][3];
+                }
+            }
+            for (; k < kend; k += 4) {
                 const float4 a = *reinterpret_cast<const float4*>(h0p + k);
                 const float4 b = *reinterpret_cast<const float4*>(h1p + k);
-                const float w0 = kp[(k + 0) * LC];
-                const float w1 = k + 1 < H ? kp[(k + 1) * LC] : 0.f;
-                const float w2 = k + 2 < H ? kp[(k + 2) * LC] : 0.f;
-                const float w3 = k + 3 < H ? kp[(k + 3) * LC] : 0.f;
+                const float w0 = kp[(k + 0) * LC], w1 = kp[(k + 1) * LC], w2 = kp[(k + 2) * LC], w3 = kp[(k + 3) * LC];
                 z0 += a.x * w0 + a.y * w1 + a.z * w2 + a.w * w3;
                 z1 += b.x * w0 + b.y * w1 + b.z * w2 + b.w * w3;
             }
@@ -227,10 +244,29 @@ __device__ __forceinline__ void publish_partials(const float* KsT, const float* 
         float acc[NC];
 #pragma unroll
         for (int c = 0; c < NC; ++c) acc[c] = 0.f;
-        for (int jj = 0; jj < LC; ++jj) {
-            const float wv = KsT[jj * Hp + k];
+        // eight columns per pass, their LDS reads (8 weights, NC x 2 quads of dz -- broadcast reads) issued together: as in the forward
+        // product the loop is LDS latency, not bandwidth; the sums keep the one-column-per-pass order (same bits)
+        for (int jj = 0; jj < LC; jj += 8) {
+            float wv[8];
+            float4 za[NC], zc[NC];
 #pragma unroll
-            for (int c = 0; c < NC; ++c) acc[c] += zl[c * LC + jj] * wv;
+            for (int e = 0; e < 8; ++e) wv[e] = KsT[(jj + e) * Hp + k];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                za[c] = *reinterpret_cast<const float4*>(zl + c * LC + jj);
+                zc[c] = *reinterpret_cast<const float4*>(zl + c * LC + jj + 4);
+            }
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                acc[c] += za[c].x * wv[0];
+                acc[c] += za[c].y * wv[1];
+                acc[c] += za[c].z * wv[2];
+                acc[c] += za[c].w * wv[3];
+                acc[c] += zc[c].x * wv[4];
+                acc[c] += zc[c].y * wv[5];
+                acc[c] += zc[c].z * wv[6];
+                acc[c] += zc[c].w * wv[7];
+            }
         }
 #pragma unroll
         for (int c = 0; c < NC; ++c)
@@ -366,7 +402,7 @@ int vl_lstm_cluster_run(bool bwd, LstmClusterArgs a, int batch, void* ws, size_t
     a.Hp = c.Hp;
     a.status = (unsigned*)ws;
     a.xch = (u64*)((char*)ws + STATUS_BYTES);
-    const size_t lds = bwd ? sizeof(float) * ((size_t)LC * c.Hp + CPG * LC) : sizeof(float) * ((size_t)a.H * LC + CPG * c.Hp + CPG * LC);   // zb: KP * clips <= 8 rows
+    const size_t lds = bwd ? sizeof(float) * ((size_t)LC * c.Hp + CPG * LC) : sizeof(float) * ((size_t)c.Hp * LC + CPG * c.Hp + CPG * LC);   // zb: KP * clips <= 8 rows
     static bool attr_set[2] = {false, false};
     const void* kern = bwd ? reinterpret_cast<const void*>(lstm_cluster_bwd_kernel) : reinterpret_cast<const void*>(lstm_cluster_fwd_kernel);
     if (!attr_set[bwd]) {
