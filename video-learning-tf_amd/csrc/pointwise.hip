@@ -22,32 +22,40 @@ static inline int grid_for(int64_t work, int threads, int cap) {
 }
 
 // ---- input prep (dataset_.py:481-501) ---------------------------------------------------------
-__global__ void input_prep_u8_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst, int n, int rh, int rw, int oh,
-                                     int ow, const int32_t* __restrict__ cy, const int32_t* __restrict__ cx,
-                                     const uint8_t* __restrict__ mir, const float* __restrict__ mean, int halo, int phase) {
-    // phase > 1: column-phase-split destination [c][phase][oh + 2 halo][ceil((ow + 2 halo) / phase)] (vl_conv_set_x_phase_split)
-    // Threads walk the DESTINATION: (image, row, phase, column within the phase plane), so a wave writes contiguous floats in
-    // each of the three channel planes; with one thread per source pixel the phase-split layout turned a wave's stores into
-    // 12 short segments.  The source bytes of a wave are then `phase` pixels apart (12 B), all within a few cache lines.
-    const int wp = (ow + 2 * halo + phase - 1) / phase;
+// Threads walk the DESTINATION plane by plane: thread -> (phase plane ph, row y, column q of the plane), an image per blockIdx.y.  The
+// interior rows of a (channel, phase) plane are one contiguous run when every column of a row is written -- the halo / padding columns
+// too, as the 0.0 they hold by contract -- so a wave's stores are whole 256-byte runs in each of the three channel planes.  (Round 1 -
+// 3: (row, phase, column) order with the halo columns skipped: 236-byte row pieces, every piece's end sectors written partially, and
+// three 64-bit divisions per element; 0.25 ms per 1024 frames = 3.1 TB/s.)  The source bytes of a wave are `phase` pixels apart (12 B
+// at phase 4), all within a few cache lines.
+__global__ __launch_bounds__(256) void input_prep_u8_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst, int rh, int rw, int oh,
+                                                            int ow, const int32_t* __restrict__ cy, const int32_t* __restrict__ cx,
+                                                            const uint8_t* __restrict__ mir, const float* __restrict__ mean, int halo, int phase,
+                                                            int wp, FastDiv d_plane, FastDiv d_wp) {
+    // phase > 1: column-phase-split destination [c][phase][oh + 2 halo][wp = ceil((ow + 2 halo) / phase)] (vl_conv_set_x_phase_split)
+    const int img = blockIdx.y;
+    const uint32_t plane_in = (uint32_t)oh * wp, per_img = plane_in * phase;      // interior rows of one plane; of all phase planes
     const int64_t pp = (int64_t)(oh + 2 * halo) * wp;
-    const int64_t per_img = (int64_t)oh * phase * wp, total = per_img * n;
     const float m0 = mean ? mean[0] : 0.f, m1 = mean ? mean[1] : 0.f, m2 = mean ? mean[2] : 0.f;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int img = (int)(e / per_img);
-        int r = (int)(e - (int64_t)img * per_img);
-        const int y = r / (phase * wp);
-        r -= y * phase * wp;
-        const int ph = r / wp, q = r - ph * wp;
-        const int x = q * phase + ph - halo;                          // physical column q * phase + ph of the haloed row
-        if (x < 0 || x >= ow) continue;                               // halo / padding columns stay zero
-        const int sy = y + (cy ? cy[img] : 0);
-        const int sx = ((mir && mir[img]) ? ow - 1 - x : x) + (cx ? cx[img] : 0);
-        const uint8_t* s = src + (((int64_t)img * rh + sy) * rw + sx) * 3;
-        float* d = dst + ((int64_t)img * 3 * phase + ph) * pp + (int64_t)(y + halo) * wp + q;
-        d[0] = (float)s[0] - m0;
-        d[phase * pp] = (float)s[1] - m1;
-        d[2 * phase * pp] = (float)s[2] - m2;
+    const int oy = cy ? cy[img] : 0, ox = cx ? cx[img] : 0;
+    const bool flip = mir && mir[img];
+    const uint8_t* simg = src + (int64_t)img * rh * rw * 3;
+    float* dimg = dst + (int64_t)img * 3 * phase * pp + (int64_t)halo * wp;
+    for (uint32_t e = blockIdx.x * 256u + threadIdx.x; e < per_img; e += gridDim.x * 256u) {
+        const uint32_t ph = fd_div(e, d_plane), r = e - ph * plane_in;
+        const uint32_t y = fd_div(r, d_wp), q = r - y * wp;
+        const int x = (int)(q * phase + ph) - halo;                   // physical column q * phase + ph of the haloed row
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f;                           // halo / padding columns: the zeros they hold
+        if (x >= 0 && x < ow) {
+            const uint8_t* sp = simg + ((int64_t)(y + oy) * rw + (flip ? ow - 1 - x : x) + ox) * 3;
+            v0 = (float)sp[0] - m0;
+            v1 = (float)sp[1] - m1;
+            v2 = (float)sp[2] - m2;
+        }
+        float* d = dimg + (int64_t)ph * pp + r;                        // r = y * wp + q: the plane's interior rows are contiguous
+        d[0] = v0;
+        d[(int64_t)phase * pp] = v1;
+        d[2 * (int64_t)phase * pp] = v2;
     }
 }
 
@@ -56,9 +64,14 @@ extern "C" int vl_input_prep_u8(const uint8_t* src, float* dst, int n, int raw_h
                                 int dst_halo, int dst_phase, vl_stream_t stream) {
     VL_CHECK(src && dst && dst_halo >= 0 && dst_phase >= 1, "vl_input_prep_u8: bad argument");
     VL_CHECK(n > 0 && out_h > 0 && out_w > 0 && out_h <= raw_h && out_w <= raw_w, "vl_input_prep_u8: bad shape");
-    const int64_t total = (int64_t)n * out_h * dst_phase * ((out_w + 2 * dst_halo + dst_phase - 1) / dst_phase);
-    hipLaunchKernelGGL(input_prep_u8_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, (hipStream_t)stream, src, dst, n,
-                       raw_h, raw_w, out_h, out_w, crop_y, crop_x, mirror, mean_bgr, dst_halo, dst_phase);
+    VL_CHECK(n <= 65535, "vl_input_prep_u8: batch %d exceeds the grid limit", n);
+    const int wp = (out_w + 2 * dst_halo + dst_phase - 1) / dst_phase;
+    const int64_t per_img = (int64_t)out_h * dst_phase * wp;
+    VL_CHECK(per_img < (1ll << 31), "vl_input_prep_u8: image too large");
+    int bx = (int)((per_img + 1023) / 1024);                          // ~4 elements per thread
+    if ((int64_t)bx * n < 8ll * vl_device_cus()) bx = (int)((per_img + 255) / 256);   // few frames: one element per thread
+    hipLaunchKernelGGL(input_prep_u8_kernel, dim3(bx, n), dim3(256), 0, (hipStream_t)stream, src, dst, raw_h, raw_w, out_h, out_w,
+                       crop_y, crop_x, mirror, mean_bgr, dst_halo, dst_phase, wp, make_fastdiv((uint32_t)out_h * wp), make_fastdiv((uint32_t)wp));
     VL_LAUNCH_CHECK();
     return 0;
 }
