@@ -256,7 +256,8 @@ int vl_lstm_step_bwd(const float* dout, const float* dh_next, const float* act, 
  * LDS for the whole sequence and exchange h_t (forward) / partial dh_{t-1} (backward) through tagged 8-byte words in `ws`
  * (agent-scope atomics, bounded spins); larger H: one workgroup per clip streaming kh every step.
  * ws: device scratch of vl_lstm_seq_ws_bytes(batch, T, H) bytes, ZEROED ONCE by the caller when it is allocated: its first word is
- * the sticky time-out flag of vl_lstm_seq_status, which no launch clears; the rest is scratch. */
+ * the sticky time-out flag of vl_lstm_seq_status, which no launch clears; the rest holds the exchange words, whose tags are unique
+ * per launch within the process (no launch zeroes them), so it must not be handed anything else to scribble on. */
 size_t vl_lstm_seq_ws_bytes(int batch, int T, int H);
 int vl_lstm_seq_fwd(const float* gx, const float* kh, const float* h0, const float* c0, float* act, float* cseq, float* hseq,
                     float* hprev, int batch, int T, int H, float forget_bias, void* ws, size_t ws_bytes, vl_stream_t stream);

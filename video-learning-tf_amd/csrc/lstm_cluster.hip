@@ -19,9 +19,11 @@
 // Exchange = the "data is the flag" granule form of the CDNA guide (Guideline 16, R2): every handed-off float travels as
 // one aligned 8-byte {tag = epoch, value} word written by ONE relaxed agent-scope atomic store (write-through, sc1) and read
 // by relaxed agent-scope atomic loads (bypass L1) until the tag matches; no flag, no fence, placement independent.
-// Epochs count steps within the call (1..T, never 0); buffers alternate by epoch parity (a workgroup can be at most one step
-// ahead of another, see below); the launcher zeroes the granules before every call.  Spins are bounded: a workgroup that never
-// sees its granules sets the status word and goes on (wrong results, no hang).  The status word is STICKY: no launch clears it,
+// Epochs count steps within the call (1..T); the TAG of a granule is the launch's base + epoch, bases taken from one process-wide
+// counter that advances by T + 1 per launch, so a tag never repeats and no granule of an earlier launch can match (the workspace is
+// zeroed once when it is allocated, vltf.h; round 1 - 3 zeroed the granules before every launch: a 5 us memset in front of both
+// recurrences of every step).  Buffers alternate by epoch parity (a workgroup can be at most one step ahead of another, see below).
+// Spins are bounded: a workgroup that never sees its granules sets the status word and goes on (wrong results, no hang).  The status word is STICKY: no launch clears it,
 // vl_lstm_seq_status reads AND resets it, so a forward call's time-out is still there after the backward call and the engine's
 // one check per step (engine._finish_step) sees every launch of that step.
 //
@@ -50,6 +52,7 @@ static constexpr unsigned SPIN_LIMIT = 1u << 18;   // polls before giving up (~t
 // tests/ can see the time-out path end to end; defaults = production behaviour
 static unsigned g_spin_limit = SPIN_LIMIT;
 static int g_mute_workgroup = -1;
+static unsigned g_epoch_base = 0;                  // tag base of the next launch (see the header comment)
 static constexpr size_t STATUS_BYTES = 256;        // status block at the start of the workspace (word 0: timed-out flag)
 
 template <int I> struct IntK { static constexpr int value = I; };
@@ -109,6 +112,7 @@ struct LstmClusterArgs {
     float forget_bias;
     unsigned spin_limit;
     int mute;             // test hook: this workgroup (blockIdx.x) publishes nothing; -1 = none
+    unsigned ebase;       // tag of epoch e = ebase + e (unique per launch)
 };
 
 // ---- forward ------------------------------------------------------------------------------------------------------------
@@ -163,7 +167,7 @@ __global__ __launch_bounds__(LNT) void lstm_cluster_fwd_kernel(const LstmCluster
                 constexpr int N = decltype(tag)::value;
                 float v[N];
                 gather_granules<N>(src, myn, [&](int m) { const int i = tid + LNT * m; const int c = i / H; return c * Hp + (i - c * H); },
-                                   (unsigned)t, v, p.status, p.spin_limit);
+                                   p.ebase + (unsigned)t, v, p.status, p.spin_limit);
 #pragma unroll
                 for (int m = 0; m < N; ++m)
                     if (m < myn) {
@@ -223,7 +227,7 @@ __global__ __launch_bounds__(LNT) void lstm_cluster_fwd_kernel(const LstmCluster
             const float gi = sigm(zi), gj = tanhf(zj), gf = sigm(zf + p.forget_bias), go = sigm(zo);
             cst = cst * gf + gi * gj;
             const float h = tanhf(cst) * go;
-            if (t + 1 < T && (int)blockIdx.x != p.mute) store_granule(xg + (t & 1) * xpar + gc * Hp + gu, (unsigned)(t + 1), h);
+            if (t + 1 < T && (int)blockIdx.x != p.mute) store_granule(xg + (t & 1) * xpar + gc * Hp + gu, p.ebase + (unsigned)(t + 1), h);
             float* a = p.act + r * H4 + gu;
             a[0] = gi; a[H] = gj; a[2 * H] = gf; a[3 * H] = go;
             p.cseq[r * H + gu] = cst;
@@ -301,7 +305,7 @@ __global__ __launch_bounds__(LNT) void lstm_cluster_bwd_kernel(const LstmCluster
         auto run = [&](auto tag) {
             constexpr int N = decltype(tag)::value;
             float v[N];
-            gather_granules<N>(src, glive ? W : 0, [&](int m) { return (size_t)m * wstride; }, epoch, v, p.status, p.spin_limit);
+            gather_granules<N>(src, glive ? W : 0, [&](int m) { return (size_t)m * wstride; }, p.ebase + epoch, v, p.status, p.spin_limit);
             float s = 0.f;
 #pragma unroll
             for (int m = 0; m < N; ++m)
@@ -342,10 +346,10 @@ __global__ __launch_bounds__(LNT) void lstm_cluster_bwd_kernel(const LstmCluster
         __syncthreads();                                        // own dz_t in LDS
         if ((t > 0 || p.dh0) && (int)blockIdx.x != p.mute) {
             u64* dst = pg + (epoch & 1) * ppar + (size_t)w * CPG * Hp;
-            if (nclips > 4) publish_partials<8>(KsT, zl, dst, H, Hp, nclips, epoch, tid);
-            else if (nclips > 2) publish_partials<4>(KsT, zl, dst, H, Hp, nclips, epoch, tid);
-            else if (nclips > 1) publish_partials<2>(KsT, zl, dst, H, Hp, nclips, epoch, tid);
-            else publish_partials<1>(KsT, zl, dst, H, Hp, nclips, epoch, tid);
+            if (nclips > 4) publish_partials<8>(KsT, zl, dst, H, Hp, nclips, p.ebase + epoch, tid);
+            else if (nclips > 2) publish_partials<4>(KsT, zl, dst, H, Hp, nclips, p.ebase + epoch, tid);
+            else if (nclips > 1) publish_partials<2>(KsT, zl, dst, H, Hp, nclips, p.ebase + epoch, tid);
+            else publish_partials<1>(KsT, zl, dst, H, Hp, nclips, p.ebase + epoch, tid);
         }
         __syncthreads();                                        // zl consumed before the next step rewrites it
     }
@@ -431,11 +435,14 @@ int vl_lstm_cluster_run(bool bwd, LstmClusterArgs a, int batch, void* ws, size_t
         a.dz = dz ? dz + ro * 4 * a.H : nullptr;
         a.dh0 = dh0 ? dh0 + so : nullptr;
         a.dc0 = dc0 ? dc0 + so : nullptr;
-        // zero exactly the granules this launch can poll (tags of an earlier call would match its epochs)
-        const size_t gran = bwd ? (size_t)2 * G * c.W * CPG * c.Hp : (size_t)2 * G * CPG * c.Hp;
-        a.xch = (u64*)((char*)ws + STATUS_BYTES);
-        // the kernels index parity blocks by their own G: [parity][G][...]
-        VL_HIP(hipMemsetAsync(a.xch, 0, gran * sizeof(u64), s));
+        a.xch = (u64*)((char*)ws + STATUS_BYTES);                 // the kernels index parity blocks by their own G: [parity][G][...]
+        // this launch's tags: base + 1 .. base + T, never used before in this process (any workspace, either direction)
+        a.ebase = __atomic_fetch_add(&g_epoch_base, (unsigned)a.T + 1u, __ATOMIC_RELAXED);
+        if (a.ebase > 0xfff00000u) {                             // (after ~10^8 launches) start over behind a memset of the whole exchange
+            VL_HIP(hipMemsetAsync(a.xch, 0, ws_bytes - STATUS_BYTES, s));
+            __atomic_store_n(&g_epoch_base, (unsigned)a.T + 1u, __ATOMIC_RELAXED);
+            a.ebase = 0;
+        }
         if (bwd) hipLaunchKernelGGL(lstm_cluster_bwd_kernel, dim3(G * c.W), dim3(LNT), lds, s, a);
         else hipLaunchKernelGGL(lstm_cluster_fwd_kernel, dim3(G * c.W), dim3(LNT), lds, s, a);
         VL_LAUNCH_CHECK();
