@@ -1177,9 +1177,19 @@ __global__ void bias_grad_stage1(const float* __restrict__ dy, float* __restrict
     const int c = blockIdx.x, s = blockIdx.y;
     const int n0 = s * per, n1 = min(n, n0 + per);
     float acc = 0.f;
-    for (int img = n0; img < n1; ++img) {
+    // eight images' loads in flight per pass (one image per pass was one dependent round trip per image: conv3's 15 x 15 planes, 36
+    // images per workgroup, ran at 3 TB/s -- latency, not bandwidth; round 4)
+    const int64_t istride = (int64_t)C * HW;
+    for (int img = n0; img < n1; img += 8) {
         const float* p = dy + ((int64_t)img * C + c) * HW;
-        for (int i = threadIdx.x; i < HW; i += 256) acc += p[i];
+        const int cnt = min(8, n1 - img);
+        for (int i = threadIdx.x; i < HW; i += 256) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = e < cnt ? p[e * istride + i] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc += v[e];
+        }
     }
     acc = block_sum_256(acc, sm);
     if (threadIdx.x == 0) ws[s * C + c] = acc;
@@ -1189,7 +1199,15 @@ __global__ void sum_partials_kernel(const float* __restrict__ ws, float* __restr
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= count) return;
     float a = 0.f;
-    for (int s = 0; s < S; ++s) a += ws[(int64_t)s * count + c];
+    int s = 0;
+    for (; s + 8 <= S; s += 8) {                                       // eight loads in flight, added in slice order
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = ws[(int64_t)(s + e) * count + c];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a += v[e];
+    }
+    for (; s < S; ++s) a += ws[(int64_t)s * count + c];
     out[c] = a;
 }
 
