@@ -1060,7 +1060,7 @@ extern "C" int vl_maxpool_fwd(const float* x, float* y, uint8_t* argmax, int n, 
 // 0.176 ms at 1024 frames (tools/pool5_probe.py; VL_MAXPOOL_GENERIC=1 runs the element-per-thread kernel).  The same treatment
 // of the FORWARD (64 planes copied to LDS, lane = channel) was slower than the element-per-thread kernel (0.105 vs 0.071 ms) and
 // was dropped: its strided writes are absorbed by the L2, the serial copy phase is not.
-template <int CB>
+template <int CB, bool MASK>
 __global__ __launch_bounds__(256) void maxpool_bwd_hwc_k3s2_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ arg,
                                                                    float* __restrict__ dx, const float* __restrict__ mask, int C, int H,
                                                                    int W, int OH, int OW, int halo) {
@@ -1071,10 +1071,25 @@ __global__ __launch_bounds__(256) void maxpool_bwd_hwc_k3s2_kernel(const float* 
     const int nch = min(CB, C - c0);
     const float* dyp = dy + (int64_t)img * OHW * C;
     const uint8_t* ap = arg + (int64_t)img * OHW * C;
-    for (int e = threadIdx.x; e < CB * OHW; e += 256) {
-        const int p = e / CB, cl = e - p * CB;                        // lanes walk c: contiguous in the (h, w, c) source
-        const bool ok = cl < nch;
-        sp[cl * SP + p] = make_uint2(ok ? __float_as_uint(dyp[(int64_t)p * C + c0 + cl]) : 0u, ok ? (uint32_t)ap[(int64_t)p * C + c0 + cl] : 255u);
+    // Round 4: every loop of this kernel was ONE load, its wait, its use -- hipcc had turned the conditional loads into branches
+    // (exec-mask tests around each), 9 + 64 dependent round trips per thread.  Now: clamped addresses instead of conditions, the
+    // loads of four entries / four channels issued before the first is used, selects instead of branches.
+    constexpr int EU = 4;
+    for (int e0 = threadIdx.x; e0 < CB * OHW; e0 += 256 * EU) {
+        uint32_t dv[EU], av[EU];
+#pragma unroll
+        for (int u = 0; u < EU; ++u) {
+            const int e = min(e0 + 256 * u, CB * OHW - 1);
+            const int p = e / CB, cl = min(e - p * CB, nch - 1);       // lanes walk c: contiguous in the (h, w, c) source
+            dv[u] = __float_as_uint(dyp[(int64_t)p * C + c0 + cl]);
+            av[u] = (uint32_t)ap[(int64_t)p * C + c0 + cl];
+        }
+#pragma unroll
+        for (int u = 0; u < EU; ++u) {
+            const int e = e0 + 256 * u;
+            const int p = e / CB, cl = e - p * CB;
+            if (e < CB * OHW) sp[cl * SP + p] = cl < nch ? make_uint2(dv[u], av[u]) : make_uint2(0u, 255u);
+        }
     }
     if ((int)threadIdx.x < CB) sp[threadIdx.x * SP + OHW] = make_uint2(0u, 255u);   // the pad entry unreachable windows read
     __syncthreads();
@@ -1094,7 +1109,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_hwc_k3s2_kernel(const float* 
         const int ih = pcl / wp, iwq = pcl - ih * wp, iwr = iwq - halo;
         const bool valid = inplane && iwr >= 0 && iwr < W;
         const int iw = min(max(iwr, 0), W - 1);
-        const int p = ih * W + iw;
+        const int p = ih * W + iw;                                     // (clamped: always a pixel of the plane)
         int off[4], wl[4];
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
@@ -1108,18 +1123,28 @@ __global__ __launch_bounds__(256) void maxpool_bwd_hwc_k3s2_kernel(const float* 
             }
         }
         const int64_t dxo = (int64_t)(ih + halo) * wp + iwq;
-        for (int cl = wave; cl < nch; cl += 4) {
-            const int64_t plane = (int64_t)img * C + c0 + cl;
-            const float mk = (mask && valid) ? mask[plane * HW + p] : 1.f;
-            const uint2* row = sp + cl * SP;
-            float acc = 0.f;
+        constexpr int CU = 4;                                          // channels per pass
+        for (int cb = wave; cb < nch; cb += 4 * CU) {
+            float mk[CU];
+            uint2 en[CU][4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint2 e = row[off[k]];
-                acc += ((int)e.y == wl[k]) ? __uint_as_float(e.x) : 0.f;
+            for (int u = 0; u < CU; ++u) {
+                const int cl = min(cb + 4 * u, nch - 1);               // (clamped: a repeated channel is computed and not stored)
+                if constexpr (MASK) mk[u] = mask[((int64_t)img * C + c0 + cl) * HW + p];
+                else mk[u] = 1.f;
+                const uint2* row = sp + cl * SP;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) en[u][k] = row[off[k]];
             }
-            if (!(mk > 0.f)) acc = 0.f;
-            if (inplane) dx[plane * pp + dxo] = acc;                   // halo columns: no window matched, acc = 0
+#pragma unroll
+            for (int u = 0; u < CU; ++u) {
+                const int cl = cb + 4 * u;
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc += ((int)en[u][k].y == wl[k]) ? __uint_as_float(en[u][k].x) : 0.f;
+                if (!(mk[u] > 0.f)) acc = 0.f;
+                if (inplane && cl < nch) dx[((int64_t)img * C + c0 + cl) * pp + dxo] = acc;   // halo columns: no window matched, acc = 0
+            }
         }
     }
 }
@@ -1138,11 +1163,13 @@ extern "C" int vl_maxpool_bwd(const float* dy, const uint8_t* argmax, float* dx,
         // iterations per wave took 45 us where 1/8 of the 1024-frame time is 18; round 4)
         if ((int64_t)ceil_div(c, 64) * n >= 4ll * vl_device_cus()) {
             constexpr int CB = 64;
-            hipLaunchKernelGGL((maxpool_bwd_hwc_k3s2_kernel<CB>), dim3(ceil_div(c, CB), n), dim3(256), (size_t)CB * (oh * ow + 1) * 8, (hipStream_t)stream,
+            auto k = relu_mask ? maxpool_bwd_hwc_k3s2_kernel<CB, true> : maxpool_bwd_hwc_k3s2_kernel<CB, false>;
+            hipLaunchKernelGGL(k, dim3(ceil_div(c, CB), n), dim3(256), (size_t)CB * (oh * ow + 1) * 8, (hipStream_t)stream,
                                dy, argmax, dx, relu_mask, c, h, w, oh, ow, dx_halo);
         } else {
             constexpr int CB = 16;
-            hipLaunchKernelGGL((maxpool_bwd_hwc_k3s2_kernel<CB>), dim3(ceil_div(c, CB), n), dim3(256), (size_t)CB * (oh * ow + 1) * 8, (hipStream_t)stream,
+            auto k = relu_mask ? maxpool_bwd_hwc_k3s2_kernel<CB, true> : maxpool_bwd_hwc_k3s2_kernel<CB, false>;
+            hipLaunchKernelGGL(k, dim3(ceil_div(c, CB), n), dim3(256), (size_t)CB * (oh * ow + 1) * 8, (hipStream_t)stream,
                                dy, argmax, dx, relu_mask, c, h, w, oh, ow, dx_halo);
         }
         VL_LAUNCH_CHECK();
