@@ -18,7 +18,8 @@ if [ "$part" = a ]; then
     rocprofv3 --kernel-trace --pmc $c -d "$d" -o runc -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-split-math > "$d.json" 2> "$d.err" || { echo pmc $c failed; exit 1; }
   done
   python tools/summarize_profile.py $out $out/n1 | tail -3
-  python tools/timeline.py $out/prof --step -2 > $out/timeline_clips64.txt 2>&1; tail -1 $out/timeline_clips64.txt
+  python tools/timeline.py $out/prof --step 13 > $out/timeline_clips64.txt 2>&1; tail -1 $out/timeline_clips64.txt
+  python tools/timeline.py $out/prof --step 5 > $out/timeline_clips64_two_streams.txt 2>&1; tail -1 $out/timeline_clips64_two_streams.txt
   find $out -name "*_results.db" -delete
   # 4. one rank under the launcher, and the self-launch path with one rank
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --no-split-math > $out/bench_torchrun1.json 2> $out/bench_torchrun1.err
@@ -30,7 +31,8 @@ if [ "$part" = b ]; then
   done
   rocprofv3 --kernel-trace --stats -d $out/prof_c8 -o runc -- python3 bench.py --clips-per-gpu 8 --no-split-math --no-cpu-baseline --steps 10 --warmup 2 > $out/prof_c8.json 2> $out/prof_c8.err
   python tools/summarize_profile.py $out $out/c8 --prof prof_c8 | tail -2
-  python tools/timeline.py $out/prof_c8 --step -2 > $out/timeline_clips8.txt 2>&1; tail -1 $out/timeline_clips8.txt
+  python tools/timeline.py $out/prof_c8 --step 17 > $out/timeline_clips8.txt 2>&1; tail -1 $out/timeline_clips8.txt
+  python tools/timeline.py $out/prof_c8 --step 7 > $out/timeline_clips8_two_streams.txt 2>&1; tail -1 $out/timeline_clips8_two_streams.txt   # a step of the timed region
   find $out -name "*_results.db" -delete
   python bench.py --fpc 32 --no-split-math --no-cpu-baseline --steps 10 > $out/bench_fpc32.json 2> $out/bench_fpc32.err; python -c "$J" fpc32 < $out/bench_fpc32.json
   python bench.py --conv-math bf16 --no-split-math --no-cpu-baseline --steps 20 > $out/bench_bf16_path_fpc16.json 2> $out/bench_bf16_16.err; python -c "$J" bf16_fpc16 < $out/bench_bf16_path_fpc16.json
