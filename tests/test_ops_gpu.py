@@ -645,6 +645,31 @@ def test_lstm_cluster_is_deterministic_and_reentrant(ops):
     assert np.abs(res[0][1]).max() > 0
 
 
+def test_lstm_cluster_calls_of_different_lengths_share_a_workspace(ops):
+    """The exchange words are never cleared between launches (round 4): their tags are unique per launch.  A long call, then a short
+    one with another batch on the same workspace, then the long one again -- every call must equal its run on a fresh workspace,
+    bitwise (a stale word of an earlier call that satisfied a later one would change the values)."""
+    H = 256
+
+    def run(b, T, ws, seed):
+        r = np.random.default_rng(seed)
+        gx = dev((r.standard_normal((b * T, 4 * H)) * 1.5).astype(np.float32))
+        kh = dev((r.standard_normal((H, 4 * H)) * 0.05).astype(np.float32))
+        dout = dev(r.standard_normal((b * T, H)).astype(np.float32))
+        act, cseq = torch.zeros((b * T, 4 * H), device=DEV), torch.zeros((b * T, H), device=DEV)
+        hseq, hprev, dz = torch.zeros((b * T, H), device=DEV), torch.zeros((b * T, H), device=DEV), torch.zeros((b * T, 4 * H), device=DEV)
+        ops.lstm_seq_fwd(gx, kh, act, cseq, hseq, hprev, b, T, H, ws=ws)
+        ops.lstm_seq_bwd(dout, kh, act, cseq, dz, b, T, H, ws=ws)
+        assert not ops.lstm_seq_timed_out(ws)
+        return host(hseq), host(dz)
+
+    shared = ops.lstm_seq_ws(64, 16, H, DEV)
+    for b, T, seed in ((64, 16, 1), (5, 3, 2), (64, 16, 1), (17, 7, 3), (5, 3, 2)):
+        got = run(b, T, shared, seed)
+        want = run(b, T, ops.lstm_seq_ws(64, 16, H, DEV), seed)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), (b, T)
+
+
 def test_lstm_cluster_timeout_is_sticky_until_read(ops):
     """A workgroup that never hears from a peer gives up after the spin limit and raises the status word (wrong results, no
     hang).  The word is sticky: a later healthy launch on the same workspace does not clear it; reading it does.
@@ -681,7 +706,6 @@ def test_lstm_cluster_timeout_is_sticky_until_read(ops):
 
 @pytest.mark.parametrize("method", ["avg", "last"])
 def test_temporal_fusion(ops, method):
-    rng = np.random.default_rng(5)
     b, T, H = 3, 5, 7
     x = rng.standard_normal((b, T, H)).astype(np.float32)
     y = torch.empty((b, H), device=DEV)
