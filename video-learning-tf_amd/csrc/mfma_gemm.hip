@@ -1898,6 +1898,7 @@ static void launch_reduce_slabs(hipStream_t s, const float* ws, float* out, int6
 static const bool kConvStaged = vl_exp_env("VL_CONV_STAGED") != nullptr;
 static const bool kGemmNoSplit = vl_exp_env("VL_GEMM_NOSPLIT") != nullptr;
 static const bool kConvNoWideStore = vl_exp_env("VL_CONV_NO_WIDE_STORE") != nullptr;   // A/B: per-accumulator stores in conv_dma16_kernel's epilogue
+static const bool kConvNoTailSplit = vl_exp_env("VL_CONV_NO_TAIL_SPLIT") != nullptr;   // A/B: never split a few-frame launch's last round off
 static const bool kConvNoLoadPick = vl_exp_env("VL_CONV_NO_LOAD_PICK") != nullptr;   // A/B: tile width by padded rows only (round-1 rule)
 static const bool kWgradDword = vl_exp_env("VL_WGRAD_DWORD") != nullptr;  // split-product wgrad: keep the dword fetches where 16-byte ones apply
 static const bool kRing8 = vl_exp_env("VL_CONV_RING8") != nullptr;      // bf16x3, 128-channel layers: the 8-wave conv_ring_kernel instead of conv_ring4_kernel
@@ -2510,16 +2511,54 @@ static int dispatch_conv(const ConvGeom& g, const float* w, int64_t w_ld, int w_
     const bool few = px * ceil_div(Cog, 128) * ngrp < 8 * cus;        // under 8 workgroups per CU at the widest tile: quantisation matters
     if (PADDED && few && (int64_t)g.K * w_ld * 4 < MAX_BUF_BYTES && !kConvStaged && !kConvNoLoadPick) {
         const int widths[3] = {128, 96, 48};
-        int best = 0;
+        auto pick = [&](int64_t pxt, int64_t& load) {                 // width with the smallest per-CU load for pxt pixel tiles
+            int b = 0;
+            for (int i = 0; i < 3; ++i) {
+                const int64_t l = ceil_div(pxt * ceil_div(Cog, widths[i]) * ngrp, cus) * widths[i];
+                if (i == 0 || l < load) { b = i; load = l; }
+            }
+            return b;
+        };
+        auto run = [&](int wi, const ConvGeom& gg, const ConvOut& oo) {
+            if (wi == 0) return launch_conv_dma<128>(gg, w, w_ld, w_grp_stride, row_tab, Cog, Cout_total, oo, s);
+            if (wi == 1) return launch_conv_dma<96>(gg, w, w_ld, w_grp_stride, row_tab, Cog, Cout_total, oo, s);
+            return launch_conv_dma<48>(gg, w, w_ld, w_grp_stride, row_tab, Cog, Cout_total, oo, s);
+        };
         int64_t best_load = 0;
-        for (int i = 0; i < 3; ++i) {
-            const int64_t wgs = px * ceil_div(Cog, widths[i]) * ngrp;
-            const int64_t load = ceil_div(wgs, cus) * widths[i];
-            if (i == 0 || load < best_load) { best = i; best_load = load; }
+        const int best = pick(px, best_load);
+        // A last round that is mostly empty (conv2 forward at 128 frames: 1568 workgroups = 6.1 rounds of 256 CUs, paid as 7): the
+        // leading frames fill whole rounds at that width, the remaining few frames run as a second launch at the width that suits THEM
+        // (conv2: 125 frames in 6 rounds of 128-wide tiles + 3 frames as 114 48-wide tiles: load 816 + a launch instead of 896).
+        // The second launch runs one narrow tile per CU, whose reduction loop is then fetch LATENCY per stage (measured: 1.3 us per
+        // stage for conv2's 5 x 5 over 28 x 28, 2.9 for conv5's 3 x 3 over 13 x 13) against the 1.9 us per stage and 128 rows the saved
+        // round would have cost: conv2 forward at 128 frames 0.511 -> 0.490 ms (8-clip step 5.16 -> 5.135), conv5 forward at 512 frames
+        // 0.612 -> 0.666.  So only where the model gains >= 5 % with the second launch charged half a 128-row tile AND at least six
+        // whole rounds remain in the first (the second launch is then < 1/6 of a round's worth of frames): conv2's case, not conv5's.
+        const int nimg = g.M / g.OHW;
+        const int64_t wgs_per_px = (int64_t)ceil_div(Cog, widths[best]) * ngrp;
+        const int64_t rounds = px * wgs_per_px / cus;                  // whole rounds
+        if (rounds >= 6 && !kConvNoTailSplit) {
+            const int64_t px_a = rounds * cus / wgs_per_px;            // pixel tiles that fit them
+            const int n_a = (int)(px_a * 128 / g.OHW);                 // whole frames within those tiles
+            const int n_b = nimg - n_a;
+            if (n_a > 0 && n_b > 0) {
+                int64_t load_b = 0;
+                const int64_t px_b = ceil_div((int64_t)n_b * g.OHW, 128);
+                const int wb = pick(px_b, load_b);
+                const int64_t load_a = ceil_div(ceil_div((int64_t)n_a * g.OHW, 128) * wgs_per_px, cus) * widths[best];
+                if ((load_a + (load_b > 64 ? load_b : 64) + 16) * 100 <= best_load * 95) {
+                    ConvGeom ga = g, gb = g;
+                    ga.M = n_a * g.OHW; ga.total = g.img_stride * n_a;
+                    gb.x = g.x + (int64_t)n_a * g.img_stride; gb.M = n_b * g.OHW; gb.total = g.img_stride * n_b;
+                    ConvOut ob = o;
+                    ob.y = o.y + (int64_t)n_a * Cout_total * (o.OH + 2 * o.y_halo) * (o.OW + 2 * o.y_halo);
+                    if (o.mask) ob.mask = o.mask + (int64_t)n_a * Cout_total * (o.OH + 2 * o.m_halo) * (o.OW + 2 * o.m_halo);
+                    if (int rc = run(best, ga, o)) return rc;
+                    return run(wb, gb, ob);
+                }
+            }
         }
-        if (best == 0) return launch_conv_dma<128>(g, w, w_ld, w_grp_stride, row_tab, Cog, Cout_total, o, s);
-        if (best == 1) return launch_conv_dma<96>(g, w, w_ld, w_grp_stride, row_tab, Cog, Cout_total, o, s);
-        return launch_conv_dma<48>(g, w, w_ld, w_grp_stride, row_tab, Cog, Cout_total, o, s);
+        return run(best, g, o);
     }
     if (w128 <= w96 && w128 <= w64) {
         // 128-wide tiles in the padded layout: the LDS-DMA kernel
