@@ -259,6 +259,33 @@ def test_conv_fwd_bwd(ops, conv_math, padded, n, h, w, cin, cout, k, s, g):
             conv.dgrad(dyd, wd, torch.empty_like(xd))
 
 
+
+def test_conv_forward_with_its_last_round_split_off_equals_the_two_half_batches(ops):
+    """conv2's geometry at one rank's 128-frame shard: 1568 workgroups = 6.1 rounds of the chip, so the launcher runs 125 frames on
+    128-wide tiles and the trailing 3 on 48-wide ones (dispatch_conv's tail split).  An output frame does not depend on the batch
+    it was computed in (same reduction order per output in every tile width): the 128-frame call must equal two 64-frame calls,
+    which are not split (and run on 48-wide tiles), bit for bit."""
+    rng = np.random.default_rng(28)
+    n, h, w, cin, cout, k, g = 128, 28, 28, 96, 256, 5, 2
+    conv = ops.Conv(cin, h, w, cout, k, k, 1, g)
+    conv.set_halo(conv.same_pad(), 1, k - 1, 2)
+    xh = conv.same_pad()
+    x = torch.zeros((n, cin, h + 2 * xh, w + 2 * xh), device=DEV)
+    x[:, :, xh:-xh, xh:-xh] = torch.from_numpy(rng.standard_normal((n, cin, h, w)).astype(np.float32)).to(DEV)
+    wt = dev((rng.standard_normal((k, k, cin // g, cout)) * 0.03).astype(np.float32))
+    b = dev(rng.standard_normal(cout).astype(np.float32))
+    y = torch.zeros((n, cout, h + 2, w + 2), device=DEV)
+    conv.fwd(x, wt, b, y, relu=True)
+    yy = torch.zeros_like(y)
+    for lo in (0, 64):
+        conv.fwd(x[lo:lo + 64], wt, b, yy[lo:lo + 64], relu=True)
+    assert torch.equal(y, yy)
+    assert float(y[125:].abs().max()) > 0 and float(y[:, :, 0].abs().max()) == 0       # the trailing frames were written; halo untouched
+    # one frame against the oracle (the split's second launch: frame 126)
+    z = O.grouped_conv(nhwc(host(x[126:127, :, xh:-xh, xh:-xh])), host(wt), host(b), 1, g)
+    close(nhwc(host(y[126:127, :, 1:-1, 1:-1])), np.maximum(z, 0), msg="frame 126")
+
+
 @pytest.mark.parametrize("conv_math", ["bf16"], indirect=True)
 @pytest.mark.parametrize("n,h,w,cin,cout,k,s,g", [(2, 28, 28, 96, 256, 5, 1, 2), (3, 13, 13, 256, 384, 3, 1, 1)])
 def test_conv_plain_bf16_mode(ops, conv_math, n, h, w, cin, cout, k, s, g):
