@@ -733,6 +733,7 @@ def test_lstm_cluster_timeout_is_sticky_until_read(ops):
 
 @pytest.mark.parametrize("method", ["avg", "last"])
 def test_temporal_fusion(ops, method):
+    rng = np.random.default_rng(5)
     b, T, H = 3, 5, 7
     x = rng.standard_normal((b, T, H)).astype(np.float32)
     y = torch.empty((b, H), device=DEV)
