@@ -40,8 +40,9 @@ int vl_device_count(void);
 
 /* ---- input preparation: Dataset.process_image (dataset_.py:481-501) on device ------------------
  * src: uint8 [n][raw_h][raw_w][3] HWC, BGR (the TFRecord 'image_raw' bytes, dataset_.py:125-126).
- * dst: fp32  [n][3][out_h + 2*dst_halo][out_w + 2*dst_halo] NCHW; only the interior is written (the halo
- * must have been zeroed once: it is conv1's SAME padding, see vl_conv_set_halo).  crop_y/crop_x: int32[n] top-left crop offsets
+ * dst: fp32  [n][3][out_h + 2*dst_halo][out_w + 2*dst_halo] NCHW; the interior ROWS are written whole -- their halo (and, in the
+ * phase-split layout, padding) columns with the 0.0 a halo holds -- the halo rows above and below are not touched (they must have
+ * been zeroed once: the halo is conv1's SAME padding, see vl_conv_set_halo).  n <= 65535.  crop_y/crop_x: int32[n] top-left crop offsets
  * (center: floor((raw-want)/2), dataset_.py:572-573); mirror: uint8[n] flips the W axis
  * (dataset_.py:497-499); mean_bgr: float[3] subtracted per channel (dataset_.py:521-530), may be NULL.
  * crop_y, crop_x, mirror may be NULL (= 0).  dst_phase = 1, or the consuming conv's vl_conv_x_phase(): dst is then the
